@@ -1,0 +1,73 @@
+"""GPU parity: HIP monotonic alignment search vs the CPU oracle — bit-exact (integer path)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mas
+from tts_amd import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(rng, B, TX, TY, ties=False, full=False):
+    tx = np.full(B, TX) if full else rng.integers(max(1, TX // 2), TX + 1, B)
+    ty = np.full(B, TY) if full else rng.integers(max(TX, TY // 2), TY + 1, B)
+    tx[0], ty[0] = TX, TY
+    ty = np.maximum(ty, tx)
+    mask = (mas.sequence_mask(tx, TX)[:, :, None] & mas.sequence_mask(ty, TY)[:, None, :]).astype(np.float32)
+    v = (rng.integers(-2, 3, (B, TX, TY)) if ties else rng.standard_normal((B, TX, TY))).astype(np.float32)
+    return v, mask, tx.astype(np.int32), ty.astype(np.int32)
+
+
+SHAPES = [(4, 17, 40), (3, 64, 64), (2, 65, 200), (5, 1, 9), (2, 7, 7), (1, 130, 257), (3, 1, 1),
+          (2, 300, 641), (1, 520, 1100), (1, 1030, 1200), (32, 257, 770)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("ties", [False, True])
+def test_maximum_path_bit_exact(gpu, shape, ties):
+    rng = np.random.default_rng(sum(shape) * 2 + ties)
+    v, mask, tx, ty = _problem(rng, *shape, ties=ties)
+    want = mas.maximum_path(v, mask, "c")
+    got = helpers.maximum_path(torch.from_numpy(v).to(gpu), torch.from_numpy(mask).to(gpu))
+    assert got.dtype == torch.float32 and got.shape == tuple(v.shape)
+    assert np.array_equal(got.cpu().numpy().astype(np.int32), want)
+
+
+@pytest.mark.parametrize("shape", [(4, 17, 40), (2, 130, 257), (3, 257, 770)])
+def test_maximum_path_c_mirror_in_place_values(gpu, shape):
+    """Device mirror of core.pyx:42: values updated in place bit-identically, paths pre-zeroed."""
+    rng = np.random.default_rng(5)
+    v, mask, tx, ty = _problem(rng, *shape)
+    v = v * mask
+    want_v = v.copy()
+    want_p = np.zeros(v.shape, np.int32)
+    mas.maximum_path_c(want_p, want_v, tx, ty)
+    dv = torch.from_numpy(v).to(gpu)
+    dp = torch.zeros(v.shape, dtype=torch.int32, device=gpu)
+    helpers.maximum_path_c(dp, dv, torch.from_numpy(tx).to(gpu), torch.from_numpy(ty).to(gpu))
+    assert np.array_equal(dp.cpu().numpy(), want_p)
+    assert np.array_equal(dv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+
+
+def test_non_rectangular_mask_is_applied(gpu):
+    """value*mask happens inside the kernel (helpers.py:184) even for masks with holes."""
+    rng = np.random.default_rng(9)
+    v, mask, tx, ty = _problem(rng, 3, 40, 90, full=True)
+    mask[:, 5:9, 20:30] = 0.0  # holes inside the band; lengths (row/col 0 sums) unchanged
+    want = mas.maximum_path(v, mask, "c")
+    got = helpers.maximum_path(torch.from_numpy(v).to(gpu), torch.from_numpy(mask).to(gpu))
+    assert np.array_equal(got.cpu().numpy().astype(np.int32), want)
+
+
+def test_full_size_property(gpu):
+    """BASELINE MAS shape 32x257x770: size-independent properties (one cell per column, monotone)."""
+    rng = np.random.default_rng(0)
+    v, mask, tx, ty = _problem(rng, 32, 257, 770)
+    got = helpers.maximum_path(torch.from_numpy(v).to(gpu), torch.from_numpy(mask).to(gpu)).cpu().numpy()
+    for i in range(32):
+        cols = got[i].sum(0)
+        assert (cols[: ty[i]] == 1).all() and (cols[ty[i]:] == 0).all()
+        rows = got[i].argmax(0)[: ty[i]]
+        assert rows[0] == 0 and rows[-1] == tx[i] - 1
+        assert ((np.diff(rows) == 0) | (np.diff(rows) == 1)).all()

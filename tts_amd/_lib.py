@@ -1,0 +1,67 @@
+"""ctypes binding of the C ABI in include/tts_amd.h (libtts_amd.so).
+
+north_star asks for a cffi layer; `cffi` is not installed in this image, the ABI
+is plain C so `ctypes` binds the identical symbols.  There is NO CPU/PyTorch fallback: if the
+HIP library is missing or a call fails this raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtts_amd.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "tts_amd.h")
+
+_lib = None
+
+
+class TtsAmdError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function name declared in include/tts_amd.h (used by the CPU-side ABI test)."""
+    src = open(HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ttsamd_\w+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TtsAmdError(
+                "libtts_amd.so is missing (%s): build it with `python -m tts_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
+            )
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ttsamd_last_error.restype = ctypes.c_char_p
+        _lib.ttsamd_arch.restype = ctypes.c_char_p
+        _lib.ttsamd_maximum_path_workspace_bytes.restype = ctypes.c_size_t
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ttsamd_last_error().decode("utf-8", "replace")
+        raise TtsAmdError("%s failed (rc=%d): %s" % (what or "tts_amd call", rc, msg))
+
+
+def P(t):
+    """Device pointer of a torch tensor (or NULL for None)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t, name="tensor"):
+    if not t.is_cuda:
+        raise TtsAmdError(
+            "%s must live on the GPU: tts_amd runs only hand-written HIP kernels (no CPU fallback)" % name
+        )

@@ -1,0 +1,330 @@
+// Monotonic alignment search (MAS) for gfx950.
+//
+// Replaces TTS/tts/utils/monotonic_align/core.pyx:11-47 (maximum_path_each / maximum_path_c) and
+// the host glue of TTS/tts/utils/helpers.py:178-194 (value*mask, lengths from the mask, D2H/H2D).
+//
+// Design (one workgroup of 8 wavefronts per batch item; integer/fp32 add-compare work, HBM/latency
+// bound — deliberately NOT reshaped into a GEMM):
+//   * forward DP  — wave 0 sweeps the columns y=0..t_y-1.  Lane l owns rows x = r*64 + l
+//     (r < R = ceil(t_x/64)); the previous column lives in registers and the x-1 neighbour
+//     comes from a wavefront shuffle (`__shfl_up`; lane 0 takes lane 63 of the previous row
+//     group).  Waves 1..7 stream [T_x x 32]-column tiles HBM -> LDS with coalesced 128-byte
+//     row segments, transposing into a [y][x] LDS image (row pitch 64R+1 => conflict-free both
+//     ways), double-buffered against the DP wave, and stream finished tiles back.
+//     Each cell is ONE fp32 add on the same operands as the reference, so values and therefore
+//     the path are bit-exact for any traversal order.
+//   * the backtrack needs only `value[x,y-1] < value[x-1,y-1]`; the DP wave gets that predicate
+//     for free (it already holds both operands) and stores it as ballot bit-planes
+//     dirs[b][y][r] (8 bytes per 64 rows) instead of re-reading 4-byte values.
+//   * backtrack — per 64-column chunk every lane extracts a 64-row window of its column's
+//     bit-plane around the current index, then wave 0 walks the chunk with scalar readlane ops;
+//     all waves then write complete 256-byte path row segments (zeros included).
+#include "common.h"
+
+namespace ttsamd {
+
+constexpr int kMasThreads = 512;          // 8 waves: 1 DP + 7 tile movers
+constexpr int kMasMovers = kMasThreads / kWave - 1;
+
+template <int YT> struct MasTile {
+    static constexpr int kShift = (YT == 32) ? 5 : (YT == 16) ? 4 : 3;
+    static constexpr int kRowsPerInstr = kWave / YT;
+};
+
+// ---- tile movers -----------------------------------------------------------------------------
+template <int YT>
+__device__ __forceinline__ void mas_stage_tile(float *lds, const float *in,
+                                               const float *__restrict__ mask, long base, int Tx,
+                                               int Ty, int XP, int tile, int mover, int lane)
+{
+    const int yl = lane & (YT - 1);
+    const int xs = lane >> MasTile<YT>::kShift;
+    const int y = tile * YT + yl;
+    const int ngroups = (Tx + MasTile<YT>::kRowsPerInstr - 1) / MasTile<YT>::kRowsPerInstr;
+#pragma unroll 8
+    for (int g = mover; g < ngroups; g += kMasMovers) {
+        const int x = g * MasTile<YT>::kRowsPerInstr + xs;
+        if (x < Tx && y < Ty) {
+            const long off = base + (long)x * Ty + y;
+            float v = in[off];
+            if (mask) v *= mask[off];
+            lds[yl * XP + x] = v;
+        }
+    }
+}
+
+template <int YT>
+__device__ __forceinline__ void mas_writeback_tile(const float *lds, float *out,
+                                                   long base, int Tx, int Ty, int XP, int tile,
+                                                   int mover, int lane)
+{
+    const int yl = lane & (YT - 1);
+    const int xs = lane >> MasTile<YT>::kShift;
+    const int y = tile * YT + yl;
+    const int ngroups = (Tx + MasTile<YT>::kRowsPerInstr - 1) / MasTile<YT>::kRowsPerInstr;
+#pragma unroll 8
+    for (int g = mover; g < ngroups; g += kMasMovers) {
+        const int x = g * MasTile<YT>::kRowsPerInstr + xs;
+        if (x < Tx && y < Ty) out[base + (long)x * Ty + y] = lds[yl * XP + x];
+    }
+}
+
+// ---- forward DP ------------------------------------------------------------------------------
+template <int RMAX, int YT>
+__global__ __launch_bounds__(kMasThreads) void mas_forward_kernel(
+    const float *in_values /* may alias dp_values (in-place mirror) */,
+    const float *__restrict__ mask, float *dp_values, unsigned long long *__restrict__ dirs,
+    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R, float neg)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int XP = 64 * R + 1;
+    float *buf0 = smem;
+    float *buf1 = smem + YT * XP;
+    const int t_x = min(t_xs[b], Tx);
+    const int t_y = min(t_ys[b], Ty);
+    const long base = (long)b * Tx * Ty;
+    const int nt = (Ty + YT - 1) / YT;
+    const bool need_copy = (dp_values != nullptr);
+    // With no dp_values output only the columns the DP touches have to be staged.
+    const int nt_work = need_copy ? nt : ((t_x > 0 && t_y > 0) ? (min(t_y, Ty) + YT - 1) / YT : 0);
+
+    float prev[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) prev[r] = 0.f;
+
+    if (wave > 0 && nt_work > 0)
+        mas_stage_tile<YT>(buf0, in_values, mask, base, Tx, Ty, XP, 0, wave - 1, lane);
+    __syncthreads();
+
+    for (int t = 0; t < nt_work; ++t) {
+        float *cur = (t & 1) ? buf1 : buf0;
+        float *oth = (t & 1) ? buf0 : buf1;
+        if (wave == 0) {
+            const int y_end = min(t_y, min(Ty, (t + 1) * YT));
+            if (t_x > 0) {
+                for (int y = t * YT; y < y_end; ++y) {
+                    const int yl = y - t * YT;
+                    const int x_lo = max(0, t_x + y - t_y);
+                    const int x_hi = min(t_x, y + 1);
+                    float up[RMAX];
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) {
+                        if (r < R) {
+                            float u = __shfl_up(prev[r], 1);
+                            if (r > 0) {
+                                const float carry = __shfl(prev[r - 1], 63);
+                                if (lane == 0) u = carry;
+                            }
+                            up[r] = u;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) {
+                        if (r < R) {
+                            const int x = r * 64 + lane;
+                            // direction bit-plane of column y-1: value[x,y-1] < value[x-1,y-1]
+                            if (y > 0) {
+                                const unsigned long long bits = __ballot(x >= 1 && prev[r] < up[r]);
+                                if (lane == 0) dirs[((long)b * Ty + (y - 1)) * R + r] = bits;
+                            }
+                            const float c = (x < Tx) ? cur[yl * XP + x] : 0.f;
+                            const float v_cur = (x == y) ? neg : prev[r];
+                            const float v_prev = (x == 0) ? (y == 0 ? 0.f : neg) : up[r];
+                            const float nv = fmaxf(v_cur, v_prev) + c;
+                            const bool inb = (x >= x_lo) && (x < x_hi);
+                            const float keep = inb ? nv : c;
+                            prev[r] = keep;
+                            if (need_copy && inb) cur[yl * XP + x] = keep;
+                        }
+                    }
+                }
+            }
+        } else {
+            if (need_copy && t > 0)
+                mas_writeback_tile<YT>(oth, dp_values, base, Tx, Ty, XP, t - 1, wave - 1, lane);
+            if (t + 1 < nt_work)
+                mas_stage_tile<YT>(oth, in_values, mask, base, Tx, Ty, XP, t + 1, wave - 1, lane);
+        }
+        __syncthreads();
+    }
+    if (need_copy && nt_work > 0 && wave > 0) {
+        const float *last = ((nt_work - 1) & 1) ? buf1 : buf0;
+        mas_writeback_tile<YT>(last, dp_values, base, Tx, Ty, XP, nt_work - 1, wave - 1, lane);
+    }
+}
+
+// ---- backtrack -------------------------------------------------------------------------------
+template <typename PathT>
+__global__ __launch_bounds__(256) void mas_backtrack_kernel(
+    PathT *__restrict__ paths, const unsigned long long *__restrict__ dirs,
+    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R,
+    int prezeroed)
+{
+    __shared__ int s_idx[64];
+    const int b = blockIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int t_x = min(t_xs[b], Tx);
+    const int t_y = min(t_ys[b], Ty);
+    const bool valid = (t_x > 0) && (t_y > 0);
+    const long base = (long)b * Tx * Ty;
+    int idx = t_x - 1;  // wave-uniform (core.pyx:18)
+    const int nchunks = (Ty + 63) / 64;
+    for (int c = nchunks - 1; c >= 0; --c) {
+        const int y_lo = c * 64;
+        const int y = y_lo + lane;
+        if (wave == 0) {
+            int myidx = -1;
+            if (valid && y_lo < t_y) {
+                const int idx0 = idx;
+                const int r0 = idx0 >> 6;
+                unsigned long long hi = 0ull, lo = 0ull;
+                if (y >= 1 && y < t_y) {
+                    const unsigned long long *d = dirs + ((long)b * Ty + (y - 1)) * R;
+                    hi = d[r0];
+                    if (r0 > 0) lo = d[r0 - 1];
+                }
+                const int s = (idx0 & 63) + 1;  // window bit k <-> row idx0-63+k
+                const unsigned long long window = (s == 64) ? hi : ((lo >> s) | (hi << (64 - s)));
+                const int wlo = (int)(unsigned)(window & 0xffffffffull);
+                const int whi = (int)(unsigned)(window >> 32);
+                const int jmax = min(63, t_y - 1 - y_lo);
+                for (int j = jmax; j >= 0; --j) {          // core.pyx:34-37
+                    const int yy = y_lo + j;
+                    if (lane == j) myidx = idx;
+                    const unsigned ulo = (unsigned)__builtin_amdgcn_readlane(wlo, j);
+                    const unsigned uhi = (unsigned)__builtin_amdgcn_readlane(whi, j);
+                    const unsigned long long w = ((unsigned long long)uhi << 32) | ulo;
+                    const int k = idx - idx0 + 63;
+                    const bool dec = (idx != 0) && (yy > 0) && ((idx == yy) || ((w >> k) & 1ull));
+                    idx -= dec ? 1 : 0;
+                }
+            }
+            s_idx[lane] = myidx;
+        }
+        __syncthreads();
+        const int m = s_idx[lane];
+        if (prezeroed) {
+            if (wave == 0 && m >= 0) paths[base + (long)m * Ty + y] = (PathT)1;
+        } else if (y < Ty) {
+            for (int x = wave; x < Tx; x += 4) paths[base + (long)x * Ty + y] = (x == m) ? (PathT)1 : (PathT)0;
+        }
+        __syncthreads();
+    }
+}
+
+// t_xs[b] = sum_x mask[b,x,0]; t_ys[b] = sum_y mask[b,0,y]   (helpers.py:191-192)
+__global__ void mask_lengths_kernel(int *__restrict__ t_xs, int *__restrict__ t_ys,
+                                    const float *__restrict__ mask, int Tx, int Ty)
+{
+    __shared__ float red[2][4];
+    const int b = blockIdx.x;
+    const float *m = mask + (long)b * Tx * Ty;
+    float sx = 0.f, sy = 0.f;
+    for (int x = threadIdx.x; x < Tx; x += blockDim.x) sx += m[(long)x * Ty];
+    for (int y = threadIdx.x; y < Ty; y += blockDim.x) sy += m[y];
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_down(sx, o);
+        sy += __shfl_down(sy, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = sx; red[1][wave] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, c = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[0][w]; c += red[1][w]; }
+        t_xs[b] = (int)a;
+        t_ys[b] = (int)c;
+    }
+}
+
+template <int RMAX, int YT>
+static int launch_forward(const float *in, const float *mask, float *dp, unsigned long long *dirs,
+                          const int *t_xs, const int *t_ys, int B, int Tx, int Ty, int R, float neg,
+                          hipStream_t st)
+{
+    const size_t lds = (size_t)2 * YT * (64 * R + 1) * sizeof(float);
+    auto kern = mas_forward_kernel<RMAX, YT>;
+    TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kMasThreads), lds, st, in, mask, dp, dirs, t_xs, t_ys, Tx,
+                       Ty, R, neg);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+}  // namespace ttsamd
+
+using namespace ttsamd;
+
+extern "C" size_t ttsamd_maximum_path_workspace_bytes(int b, int t_x, int t_y)
+{
+    if (b <= 0 || t_x <= 0 || t_y <= 0) return 0;
+    const size_t R = (size_t)(t_x + 63) / 64;
+    return (size_t)b * (size_t)t_y * R * sizeof(unsigned long long);
+}
+
+extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const float *mask,
+                                   float *dp_values_out, const int32_t *t_xs, const int32_t *t_ys,
+                                   int b, int t_x, int t_y, float max_neg_val, void *workspace,
+                                   size_t workspace_bytes, int flags, void *stream)
+{
+    TTSAMD_CHECK_ARG(b >= 0 && t_x >= 0 && t_y >= 0, "maximum_path: negative shape");
+    if (b == 0 || t_x == 0 || t_y == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(paths && values_in && t_xs && t_ys, "maximum_path: NULL pointer");
+    const int R = (t_x + 63) / 64;
+    if (R > 32) {
+        set_error("maximum_path: t_x=%d exceeds the supported maximum of 2048", t_x);
+        return TTSAMD_ERR_UNSUPPORTED;
+    }
+    const size_t need = ttsamd_maximum_path_workspace_bytes(b, t_x, t_y);
+    TTSAMD_CHECK_ARG(workspace && workspace_bytes >= need, "maximum_path: workspace too small (%zu < %zu)",
+                     workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    auto *dirs = reinterpret_cast<unsigned long long *>(workspace);
+    int rc;
+    if (R <= 1)       rc = launch_forward<1, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+    else if (R <= 2)  rc = launch_forward<2, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+    else if (R <= 4)  rc = launch_forward<4, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+    else if (R <= 8)  rc = launch_forward<8, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+    else if (R <= 16) rc = launch_forward<16, 16>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+    else              rc = launch_forward<32, 8>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+    if (rc != TTSAMD_OK) return rc;
+    const int prezeroed = (flags & TTSAMD_MAS_PATHS_PREZEROED) ? 1 : 0;
+    if (flags & TTSAMD_MAS_PATHS_F32)
+        hipLaunchKernelGGL(mas_backtrack_kernel<float>, dim3(b), dim3(256), 0, st, (float *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
+    else
+        hipLaunchKernelGGL(mas_backtrack_kernel<int>, dim3(b), dim3(256), 0, st, (int *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_maximum_path_c(int32_t *paths, float *values, const int32_t *t_xs,
+                                     const int32_t *t_ys, int b, int t_x, int t_y, float max_neg_val,
+                                     void *stream)
+{
+    const size_t need = ttsamd_maximum_path_workspace_bytes(b, t_x, t_y);
+    if (need == 0) return TTSAMD_OK;
+    hipStream_t st = as_stream(stream);
+    void *ws = nullptr;
+    TTSAMD_HIP(hipMallocAsync(&ws, need, st));
+    const int rc = ttsamd_maximum_path(paths, values, nullptr, values, t_xs, t_ys, b, t_x, t_y, max_neg_val,
+                                       ws, need, TTSAMD_MAS_PATHS_PREZEROED, stream);
+    hipError_t e = hipFreeAsync(ws, st);
+    if (rc != TTSAMD_OK) return rc;
+    TTSAMD_HIP(e);
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, int t_x,
+                                   int t_y, void *stream)
+{
+    TTSAMD_CHECK_ARG(b >= 0 && t_x > 0 && t_y > 0 && t_xs && t_ys && mask, "mask_lengths: bad args");
+    if (b == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(mask_lengths_kernel, dim3(b), dim3(256), 0, as_stream(stream), t_xs, t_ys, mask, t_x, t_y);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
