@@ -1,0 +1,639 @@
+"""TEST INFRASTRUCTURE ONLY — CPU fp32 restatement (plain torch ops) of the reference's VITS /
+Glow-TTS / HiFiGAN inference path, driven by a reference-layout `state_dict`.
+
+This is the parity checker for the floating-point HIP kernels (tolerances are written in the
+tests).  It is a *restatement*: every function cites the reference file:line it follows and is
+pinned against the reference's own `nn.Module`s (imported through oracle/ref_shim.py in the build
+container; see tests/test_oracle_pin.py and the committed fixtures under tests/golden/ made by
+tests/golden/make_golden.py).  It runs without /root/reference (GPU box).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product
+package `tts_amd` never does.
+
+Conventions: `sd` is a flat dict name -> tensor with the reference's parameter names
+(weight-norm'ed convs appear as `<name>.parametrizations.weight.original0/1`, legacy
+`weight_g/weight_v`, or already-folded `<name>.weight`), `p` is the key prefix ending in '.'.
+All tensors fp32, channels-first [B, C, T].
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.1  # hifigan_generator.py:11
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter access
+# ----------------------------------------------------------------------------------------------
+def weight(sd, name):
+    """Effective conv weight. torch weight_norm: w = v * (g / ||v||), norm over all dims but 0
+    (`torch._weight_norm(v, g, 0)`) — for ConvTranspose1d dim 0 is in_channels."""
+    if name + ".weight" in sd:
+        return sd[name + ".weight"]
+    g = sd.get(name + ".parametrizations.weight.original0", sd.get(name + ".weight_g"))
+    v = sd.get(name + ".parametrizations.weight.original1", sd.get(name + ".weight_v"))
+    if g is None or v is None:
+        raise KeyError(name)
+    return torch._weight_norm(v, g, 0)
+
+
+def bias(sd, name):
+    return sd.get(name + ".bias")
+
+
+def conv1d(sd, name, x, dilation=1, padding=0, groups=1):
+    return F.conv1d(x, weight(sd, name), bias(sd, name), 1, padding, dilation, groups)
+
+
+def sequence_mask(lengths, max_len=None):
+    """TTS/tts/utils/helpers.py:43-57."""
+    if max_len is None:
+        max_len = int(lengths.max())
+    r = torch.arange(max_len, dtype=lengths.dtype, device=lengths.device)
+    return r.unsqueeze(0) < lengths.unsqueeze(1)
+
+
+def generate_path(duration, mask):
+    """TTS/tts/utils/helpers.py:154-169."""
+    b, t_x, t_y = mask.shape
+    cum = torch.cumsum(duration, 1)
+    path = sequence_mask(cum.view(b * t_x), t_y).to(mask.dtype).view(b, t_x, t_y)
+    path = path - F.pad(path, [0, 0, 1, 0, 0, 0])[:, :-1]
+    return path * mask
+
+
+# ----------------------------------------------------------------------------------------------
+# HiFiGAN generator — TTS/vocoder/models/hifigan_generator.py
+# ----------------------------------------------------------------------------------------------
+def get_padding(k, d):
+    return int((k * d - d) / 2)  # hifigan_generator.py:14-15
+
+
+def resblock1(sd, p, x, k, dil):
+    """ResBlock1.forward, hifigan_generator.py:83-98."""
+    for i, d in enumerate(dil):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = conv1d(sd, p + "convs1.%d" % i, xt, dilation=d, padding=get_padding(k, d))
+        xt = F.leaky_relu(xt, LRELU_SLOPE)
+        xt = conv1d(sd, p + "convs2.%d" % i, xt, dilation=1, padding=get_padding(k, 1))
+        x = xt + x
+    return x
+
+
+def resblock2(sd, p, x, k, dil):
+    """ResBlock2.forward, hifigan_generator.py:150-155."""
+    for i, d in enumerate(dil):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = conv1d(sd, p + "convs.%d" % i, xt, dilation=d, padding=get_padding(k, d))
+        x = xt + x
+    return x
+
+
+def hifigan_forward(sd, p, x, cfg, g=None):
+    """HifiganGenerator.forward, hifigan_generator.py:236-265.
+
+    cfg keys (constructor args, hifigan_generator.py:163-178): resblock_type, resblock_dilation_sizes,
+    resblock_kernel_sizes, upsample_kernel_sizes, upsample_factors (upsample_initial_channel is
+    implied by the weights)."""
+    o = conv1d(sd, p + "conv_pre", x, padding=3)
+    if g is not None and (p + "cond_layer.weight") in sd:
+        o = o + conv1d(sd, p + "cond_layer", g)
+    nk = len(cfg["resblock_kernel_sizes"])
+    rb = resblock1 if str(cfg["resblock_type"]) == "1" else resblock2
+    for i, (u, k) in enumerate(zip(cfg["upsample_factors"], cfg["upsample_kernel_sizes"])):
+        o = F.leaky_relu(o, LRELU_SLOPE)
+        o = F.conv_transpose1d(o, weight(sd, p + "ups.%d" % i), bias(sd, p + "ups.%d" % i), u, (k - u) // 2)
+        z_sum = None
+        for j in range(nk):
+            r = rb(sd, p + "resblocks.%d." % (i * nk + j), o, cfg["resblock_kernel_sizes"][j],
+                   cfg["resblock_dilation_sizes"][j])
+            z_sum = r if z_sum is None else z_sum + r
+        o = z_sum / nk
+    o = F.leaky_relu(o)  # default slope 0.01 (hifigan_generator.py:262)
+    o = conv1d(sd, p + "conv_post", o, padding=3)
+    return torch.tanh(o)
+
+
+def hifigan_inference(sd, p, c, cfg):
+    """HifiganGenerator.inference, hifigan_generator.py:267-282 (replicate pad, no crop)."""
+    pad = cfg.get("inference_padding", 5)
+    c = F.pad(c, (pad, pad), "replicate")
+    return hifigan_forward(sd, p, c, cfg)
+
+
+# ----------------------------------------------------------------------------------------------
+# WaveNet block / coupling flows — generic/wavenet.py, vits/networks.py
+# ----------------------------------------------------------------------------------------------
+def wn_forward(sd, p, x, x_mask, hidden, kernel_size, dilation_rate, num_layers, g=None):
+    """WN.forward, TTS/tts/layers/generic/wavenet.py:92-116 (+ fused gate :6-13)."""
+    output = torch.zeros_like(x)
+    if g is not None:
+        g = conv1d(sd, p + "cond_layer", g)
+    for i in range(num_layers):
+        d = dilation_rate ** i
+        x_in = conv1d(sd, p + "in_layers.%d" % i, x, dilation=d, padding=int((kernel_size * d - d) / 2))
+        if g is not None:
+            g_l = g[:, i * 2 * hidden:(i + 1) * 2 * hidden, :]
+        else:
+            g_l = torch.zeros_like(x_in)
+        in_act = x_in + g_l
+        acts = torch.tanh(in_act[:, :hidden]) * torch.sigmoid(in_act[:, hidden:])
+        rs = conv1d(sd, p + "res_skip_layers.%d" % i, acts)
+        if i < num_layers - 1:
+            x = (x + rs[:, :hidden]) * x_mask
+            output = output + rs[:, hidden:]
+        else:
+            output = output + rs
+    return output * x_mask
+
+
+def residual_coupling_reverse(sd, p, x, x_mask, cfg, g=None):
+    """ResidualCouplingBlock.forward(reverse=True), vits/networks.py:138-166 (mean_only=True)."""
+    half = x.shape[1] // 2
+    x0, x1 = x[:, :half], x[:, half:]
+    h = conv1d(sd, p + "pre", x0) * x_mask
+    h = wn_forward(sd, p + "enc.", h, x_mask, cfg["hidden"], cfg["kernel_size"], cfg["dilation_rate"],
+                   cfg["num_layers"], g=g)
+    stats = conv1d(sd, p + "post", h) * x_mask
+    if stats.shape[1] == half:  # mean_only
+        m, log_scale = stats, torch.zeros_like(stats)
+    else:
+        m, log_scale = stats[:, :half], stats[:, half:]
+    x1 = (x1 - m) * torch.exp(-log_scale) * x_mask
+    return torch.cat([x0, x1], 1)
+
+
+def residual_coupling_blocks_reverse(sd, p, x, x_mask, cfg, g=None):
+    """ResidualCouplingBlocks.forward(reverse=True), vits/networks.py:226-232."""
+    for i in reversed(range(cfg.get("num_flows", 4))):
+        x = torch.flip(x, [1])
+        x = residual_coupling_reverse(sd, p + "flows.%d." % i, x, x_mask, cfg, g=g)
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# relative-position transformer — glow_tts/transformer.py
+# ----------------------------------------------------------------------------------------------
+def layer_norm2(sd, name, x, eps=1e-5):
+    """LayerNorm2, generic/normalization.py:42-53 (torch layer_norm over channels)."""
+    c = x.shape[1]
+    return F.layer_norm(x.transpose(1, -1), (c,), sd[name + ".gamma"], sd[name + ".beta"], eps).transpose(1, -1)
+
+
+def layer_norm1(sd, name, x, eps=1e-4):
+    """LayerNorm, generic/normalization.py:23-28 (biased variance, rsqrt(var+eps), gamma/beta [1,C,1])."""
+    mean = torch.mean(x, 1, keepdim=True)
+    variance = torch.mean((x - mean) ** 2, 1, keepdim=True)
+    x = (x - mean) * torch.rsqrt(variance + eps)
+    return x * sd[name + ".gamma"].view(1, -1, 1) + sd[name + ".beta"].view(1, -1, 1)
+
+
+def _get_relative_embeddings(emb, length, window):
+    """transformer.py:196-207."""
+    pad_length = max(length - (window + 1), 0)
+    s = max((window + 1) - length, 0)
+    e = s + 2 * length - 1
+    if pad_length > 0:
+        emb = F.pad(emb, [0, 0, pad_length, pad_length, 0, 0])
+    return emb[:, s:e]
+
+
+def _rel_to_abs(x):
+    """transformer.py:209-225."""
+    b, h, l, _ = x.size()
+    x = F.pad(x, [0, 1, 0, 0, 0, 0, 0, 0])
+    x_flat = x.view([b, h, l * 2 * l])
+    x_flat = F.pad(x_flat, [0, l - 1, 0, 0, 0, 0])
+    return x_flat.view([b, h, l + 1, 2 * l - 1])[:, :, :l, l - 1:]
+
+
+def _abs_to_rel(x):
+    """transformer.py:227-241."""
+    b, h, l, _ = x.size()
+    x = F.pad(x, [0, l - 1, 0, 0, 0, 0, 0, 0])
+    x_flat = x.view([b, h, l ** 2 + l * (l - 1)])
+    x_flat = F.pad(x_flat, [l, 0, 0, 0, 0, 0])
+    return x_flat.view([b, h, l, 2 * l])[:, :, :, 1:]
+
+
+def rel_mha(sd, p, x, attn_mask, num_heads, window):
+    """RelativePositionMultiHeadAttention.forward/attention, transformer.py:106-163."""
+    q = conv1d(sd, p + "conv_q", x)
+    k = conv1d(sd, p + "conv_k", x)
+    v = conv1d(sd, p + "conv_v", x)
+    b, d, t = k.shape
+    kc = d // num_heads
+    q = q.view(b, num_heads, kc, t).transpose(2, 3)
+    k = k.view(b, num_heads, kc, t).transpose(2, 3)
+    v = v.view(b, num_heads, kc, t).transpose(2, 3)
+    scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(kc)
+    if window is not None:
+        ek = _get_relative_embeddings(sd[p + "emb_rel_k"], t, window)
+        rel_logits = torch.matmul(q, ek.unsqueeze(0).transpose(-2, -1))
+        scores = scores + _rel_to_abs(rel_logits) / math.sqrt(kc)
+    scores = scores.masked_fill(attn_mask == 0, -1e4)
+    p_attn = F.softmax(scores, dim=-1)
+    out = torch.matmul(p_attn, v)
+    if window is not None:
+        rw = _abs_to_rel(p_attn)
+        ev = _get_relative_embeddings(sd[p + "emb_rel_v"], t, window)
+        out = out + torch.matmul(rw, ev.unsqueeze(0))
+    out = out.transpose(2, 3).contiguous().view(b, d, t)
+    return conv1d(sd, p + "conv_o", out)
+
+
+def ffn(sd, p, x, x_mask, kernel_size):
+    """FeedForwardNetwork.forward, transformer.py:290-295 with _same_padding :306-313."""
+    pl, pr = (kernel_size - 1) // 2, kernel_size // 2
+    pad = (lambda t: t) if kernel_size == 1 else (lambda t: F.pad(t, [pl, pr]))
+    x = conv1d(sd, p + "conv_1", pad(x * x_mask))
+    x = torch.relu(x)
+    x = conv1d(sd, p + "conv_2", pad(x * x_mask))
+    return x * x_mask
+
+
+def rel_pos_transformer(sd, p, x, x_mask, num_layers, num_heads, kernel_size, window, ln_type):
+    """RelativePositionTransformer.forward, transformer.py:409-432."""
+    ln = layer_norm2 if ln_type == "2" else layer_norm1
+    attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+    for i in range(num_layers):
+        x = x * x_mask
+        y = rel_mha(sd, p + "attn_layers.%d." % i, x, attn_mask, num_heads, window)
+        x = ln(sd, p + "norm_layers_1.%d" % i, x + y)
+        y = ffn(sd, p + "ffn_layers.%d." % i, x, x_mask, kernel_size)
+        if (i + 1) == num_layers and (p + "proj.weight") in sd:
+            x = conv1d(sd, p + "proj", x)
+        x = ln(sd, p + "norm_layers_2.%d" % i, x + y)
+    return x * x_mask
+
+
+def text_encoder(sd, p, tokens, x_lengths, cfg):
+    """TextEncoder.forward, vits/networks.py:79-100."""
+    hidden = cfg["hidden_channels"]
+    x = F.embedding(tokens, sd[p + "emb.weight"]) * math.sqrt(hidden)
+    x = torch.transpose(x, 1, -1)
+    x_mask = torch.unsqueeze(sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
+    x = rel_pos_transformer(sd, p + "encoder.", x * x_mask, x_mask, cfg["num_layers_text_encoder"],
+                            cfg["num_heads_text_encoder"], cfg["kernel_size_text_encoder"], 4, "2")
+    stats = conv1d(sd, p + "proj", x) * x_mask
+    m, logs = torch.split(stats, hidden, dim=1)
+    return x, m, logs, x_mask
+
+
+# ----------------------------------------------------------------------------------------------
+# stochastic duration predictor — vits/stochastic_duration_predictor.py, vits/transforms.py
+# ----------------------------------------------------------------------------------------------
+def dds_conv(sd, p, x, x_mask, kernel_size, num_layers, g=None):
+    """DilatedDepthSeparableConv.forward, stochastic_duration_predictor.py:46-63."""
+    if g is not None:
+        x = x + g
+    c = x.shape[1]
+    for i in range(num_layers):
+        d = kernel_size ** i
+        y = conv1d(sd, p + "convs_sep.%d" % i, x * x_mask, dilation=d, padding=(kernel_size * d - d) // 2, groups=c)
+        y = layer_norm2(sd, p + "norms_1.%d" % i, y)
+        y = F.gelu(y)
+        y = conv1d(sd, p + "convs_1x1.%d" % i, y)
+        y = layer_norm2(sd, p + "norms_2.%d" % i, y)
+        y = F.gelu(y)
+        x = x + y
+    return x * x_mask
+
+
+def rq_spline_inverse(inputs, uw, uh, ud, tail_bound=5.0, min_bin_width=1e-3, min_bin_height=1e-3,
+                      min_derivative=1e-3):
+    """unconstrained_rational_quadratic_spline(inverse=True, tails='linear') + rational_quadratic_spline,
+    vits/transforms.py:50-184.  Vectorised with `where` instead of boolean-mask scatter; elementwise
+    arithmetic and its order follow the reference exactly."""
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)           # transforms.py:62
+    ud = F.pad(ud, pad=(1, 1))
+    constant = np.log(np.exp(1 - min_derivative) - 1)                     # transforms.py:70
+    ud[..., 0] = constant
+    ud[..., -1] = constant
+    num_bins = uw.shape[-1]
+    left = bottom = -tail_bound
+    right = top = tail_bound
+    x_in = torch.where(inside, inputs, torch.zeros_like(inputs))         # dummy in-domain value outside
+
+    widths = F.softmax(uw, dim=-1)                                        # transforms.py:122-129
+    widths = min_bin_width + (1 - min_bin_width * num_bins) * widths
+    cumwidths = torch.cumsum(widths, dim=-1)
+    cumwidths = F.pad(cumwidths, pad=(1, 0), mode="constant", value=0.0)
+    cumwidths = (right - left) * cumwidths + left
+    cumwidths[..., 0] = left
+    cumwidths[..., -1] = right
+    widths = cumwidths[..., 1:] - cumwidths[..., :-1]
+    derivatives = min_derivative + F.softplus(ud)                         # transforms.py:131
+    heights = F.softmax(uh, dim=-1)                                       # transforms.py:133-140
+    heights = min_bin_height + (1 - min_bin_height * num_bins) * heights
+    cumheights = torch.cumsum(heights, dim=-1)
+    cumheights = F.pad(cumheights, pad=(1, 0), mode="constant", value=0.0)
+    cumheights = (top - bottom) * cumheights + bottom
+    cumheights[..., 0] = bottom
+    cumheights[..., -1] = top
+    heights = cumheights[..., 1:] - cumheights[..., :-1]
+
+    locs = cumheights.clone()                                             # searchsorted, transforms.py:45-47
+    locs[..., -1] += 1e-6
+    bin_idx = (torch.sum(x_in[..., None] >= locs, dim=-1) - 1)[..., None]
+
+    input_cumwidths = cumwidths.gather(-1, bin_idx)[..., 0]
+    input_bin_widths = widths.gather(-1, bin_idx)[..., 0]
+    input_cumheights = cumheights.gather(-1, bin_idx)[..., 0]
+    delta = heights / widths
+    input_delta = delta.gather(-1, bin_idx)[..., 0]
+    input_derivatives = derivatives.gather(-1, bin_idx)[..., 0]
+    input_derivatives_plus_one = derivatives[..., 1:].gather(-1, bin_idx)[..., 0]
+    input_heights = heights.gather(-1, bin_idx)[..., 0]
+
+    a = (x_in - input_cumheights) * (input_derivatives + input_derivatives_plus_one - 2 * input_delta) \
+        + input_heights * (input_delta - input_derivatives)             # transforms.py:159-165
+    b = input_heights * input_derivatives - (x_in - input_cumheights) * (
+        input_derivatives + input_derivatives_plus_one - 2 * input_delta)
+    c = -input_delta * (x_in - input_cumheights)
+    discriminant = b.pow(2) - 4 * a * c
+    root = (2 * c) / (-b - torch.sqrt(discriminant))
+    outputs = root * input_bin_widths + input_cumwidths
+    return torch.where(inside, outputs, inputs)
+
+
+def conv_flow_reverse(sd, p, x, x_mask, g, hidden, kernel_size, num_layers, num_bins=10, tail_bound=5.0):
+    """ConvFlow.forward(reverse=True), stochastic_duration_predictor.py:120-147 (in_channels=2)."""
+    x0, x1 = x[:, :1], x[:, 1:]
+    h = conv1d(sd, p + "pre", x0)
+    h = dds_conv(sd, p + "convs.", h, x_mask, kernel_size, num_layers, g=g)
+    h = conv1d(sd, p + "proj", h) * x_mask
+    b, c, t = x0.shape
+    h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)
+    uw = h[..., :num_bins] / math.sqrt(hidden)
+    uh = h[..., num_bins:2 * num_bins] / math.sqrt(hidden)
+    ud = h[..., 2 * num_bins:]
+    x1 = rq_spline_inverse(x1, uw, uh, ud, tail_bound=tail_bound)
+    return torch.cat([x0, x1], 1) * x_mask
+
+
+def sdp_reverse(sd, p, x, x_mask, noise, noise_scale=1.0, hidden=192, kernel_size=3, num_flows=4, g=None):
+    """StochasticDurationPredictor.forward(reverse=True), stochastic_duration_predictor.py:230-239,283-294.
+
+    `noise` [B,2,T] replaces the internal torch.randn (:287) so both sides see identical draws."""
+    x = conv1d(sd, p + "pre", x)
+    if g is not None:
+        x = x + conv1d(sd, p + "cond", g)
+    x = dds_conv(sd, p + "convs.", x, x_mask, kernel_size, 3)
+    x = conv1d(sd, p + "proj", x) * x_mask
+    order = list(reversed(range(num_flows + 1)))      # flows[4],[3],[2],[1],[0]
+    order = order[:-2] + [order[-1]]                  # "remove a useless vflow" (:285-286)
+    z = noise * noise_scale
+    for i in order:
+        z = torch.flip(z, [1])
+        if i == 0:  # ElementwiseAffine reverse (:82-83)
+            z = (z - sd[p + "flows.0.translation"]) * torch.exp(-sd[p + "flows.0.log_scale"]) * x_mask
+        else:
+            z = conv_flow_reverse(sd, p + "flows.%d." % i, z, x_mask, x, hidden, kernel_size, 3)
+    return z[:, :1]
+
+
+def duration_predictor(sd, p, x, x_mask, g=None):
+    """glow_tts/duration_predictor.py:46-69 (conv -> relu -> LayerNorm(1e-4), twice, then 1x1)."""
+    if g is not None:
+        x = x + conv1d(sd, p + "cond", g)
+    k = weight(sd, p + "conv_1").shape[-1]
+    x = conv1d(sd, p + "conv_1", x * x_mask, padding=k // 2)
+    x = layer_norm1(sd, p + "norm_1", torch.relu(x))
+    x = conv1d(sd, p + "conv_2", x * x_mask, padding=k // 2)
+    x = layer_norm1(sd, p + "norm_2", torch.relu(x))
+    x = conv1d(sd, p + "proj", x * x_mask)
+    return x * x_mask
+
+
+# ----------------------------------------------------------------------------------------------
+# VITS inference glue — TTS/tts/models/vits.py:1088-1173
+# ----------------------------------------------------------------------------------------------
+VITS_DEFAULTS = dict(  # VitsArgs, vits.py:544-600
+    num_chars=100, hidden_channels=192, hidden_channels_ffn_text_encoder=768, num_heads_text_encoder=2,
+    num_layers_text_encoder=6, kernel_size_text_encoder=3, kernel_size_flow=5, dilation_rate_flow=1,
+    num_layers_flow=4, resblock_type_decoder="1", resblock_kernel_sizes_decoder=[3, 7, 11],
+    resblock_dilation_sizes_decoder=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], upsample_rates_decoder=[8, 8, 2, 2],
+    upsample_initial_channel_decoder=512, upsample_kernel_sizes_decoder=[16, 16, 4, 4], use_sdp=True,
+    inference_noise_scale=0.667, length_scale=1.0, inference_noise_scale_dp=1.0, max_inference_len=None,
+)
+
+
+def vits_decoder_cfg(args):
+    return dict(resblock_type=args["resblock_type_decoder"],
+                resblock_dilation_sizes=args["resblock_dilation_sizes_decoder"],
+                resblock_kernel_sizes=args["resblock_kernel_sizes_decoder"],
+                upsample_kernel_sizes=args["upsample_kernel_sizes_decoder"],
+                upsample_factors=args["upsample_rates_decoder"], inference_padding=0)
+
+
+def vits_inference(sd, tokens, x_lengths=None, args=None, noise_dp=None, noise_z=None, durations=None,
+                   stop_after=None):
+    """Vits.inference, vits.py:1088-1173 (single speaker: g=None, lang_emb=None).
+
+    noise_dp [B,2,T_text] / noise_z [B,C,T_dec] replace the internal randn draws
+    (stochastic_duration_predictor.py:287, vits.py:1155); when None they are drawn with torch.randn in
+    the reference's order.  `durations` [B,1,T_text] overrides w_ceil (parity runs inject the other
+    side's integer durations — SURVEY §7 "ceil() cliff")."""
+    a = dict(VITS_DEFAULTS)
+    a.update(args or {})
+    if x_lengths is None:
+        x_lengths = torch.tensor(tokens.shape[1:2])                         # vits.py:1082-1086
+    x, m_p, logs_p, x_mask = text_encoder(sd, "text_encoder.", tokens, x_lengths, a)
+    out = {"x": x, "m_p_text": m_p, "logs_p_text": logs_p, "x_mask": x_mask}
+    if durations is None:
+        if a["use_sdp"]:
+            if noise_dp is None:
+                noise_dp = torch.randn(x.size(0), 2, x.size(2))
+            logw = sdp_reverse(sd, "duration_predictor.", x, x_mask, noise_dp, a["inference_noise_scale_dp"],
+                               hidden=192)
+        else:
+            logw = duration_predictor(sd, "duration_predictor.", x, x_mask)
+        out["logw"] = logw
+        w = torch.exp(logw) * x_mask * a["length_scale"]                    # vits.py:1140
+        w_ceil = torch.ceil(w)
+    else:
+        w_ceil = durations
+    y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()        # vits.py:1146
+    y_mask = sequence_mask(y_lengths, None).to(x_mask.dtype).unsqueeze(1)
+    attn_mask = x_mask * y_mask.transpose(1, 2)
+    attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1).transpose(1, 2))
+    m_p = torch.matmul(attn.transpose(1, 2), m_p.transpose(1, 2)).transpose(1, 2)
+    logs_p = torch.matmul(attn.transpose(1, 2), logs_p.transpose(1, 2)).transpose(1, 2)
+    if noise_z is None:
+        noise_z = torch.randn_like(m_p)
+    z_p = m_p + noise_z * torch.exp(logs_p) * a["inference_noise_scale"]    # vits.py:1155
+    out.update(durations=w_ceil, y_mask=y_mask, alignments=attn, m_p=m_p, logs_p=logs_p, z_p=z_p,
+               y_lengths=y_lengths)
+    if stop_after == "prior":
+        return out
+    flow_cfg = dict(hidden=a["hidden_channels"], kernel_size=a["kernel_size_flow"],
+                    dilation_rate=a["dilation_rate_flow"], num_layers=a["num_layers_flow"])
+    z = residual_coupling_blocks_reverse(sd, "flow.", z_p, y_mask, flow_cfg)
+    out["z"] = z
+    if stop_after == "flow":
+        return out
+    o = hifigan_forward(sd, "waveform_decoder.", (z * y_mask)[:, :, : a["max_inference_len"]], vits_decoder_cfg(a))
+    out["model_outputs"] = o
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Glow-TTS — TTS/tts/layers/glow_tts/{encoder,decoder,glow}.py, TTS/tts/models/glow_tts.py
+# ----------------------------------------------------------------------------------------------
+GLOW_DEFAULTS = dict(  # GlowTTSConfig, glow_tts_config.py:101-152
+    num_chars=130, hidden_channels_enc=192, hidden_channels_dec=192, hidden_channels_dp=256, out_channels=80,
+    num_flow_blocks_dec=12, kernel_size_dec=5, dilation_rate=1, num_block_layers=4, num_splits=4, num_squeeze=2,
+    sigmoid_scale=False, mean_only=True, use_encoder_prenet=True, inference_noise_scale=0.0, length_scale=1.0,
+    encoder_params=dict(kernel_size=3, num_layers=6, num_heads=2, hidden_channels_ffn=768,
+                        rel_attn_window_size=None, layer_norm_type="1"),
+)
+
+
+def glow_prenet(sd, p, x, x_mask, num_layers=3, kernel_size=5):
+    """ResidualConv1dLayerNormBlock.forward, glow_tts/glow.py:55-67."""
+    x_res = x
+    for i in range(num_layers):
+        x = conv1d(sd, p + "conv_layers.%d" % i, x * x_mask, padding=kernel_size // 2)
+        x = layer_norm1(sd, p + "norm_layers.%d" % i, x * x_mask)
+        x = F.relu(x)
+    x = x_res + conv1d(sd, p + "proj", x)
+    return x * x_mask
+
+
+def glow_encoder(sd, p, tokens, x_lengths, a):
+    """Encoder.forward (rel_pos_transformer type), glow_tts/encoder.py:143-179."""
+    hidden = a["hidden_channels_enc"]
+    ep = a["encoder_params"]
+    x = F.embedding(tokens, sd[p + "emb.weight"]) * math.sqrt(hidden)
+    x = torch.transpose(x, 1, -1)
+    x_mask = torch.unsqueeze(sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
+    if a["use_encoder_prenet"]:
+        x = glow_prenet(sd, p + "prenet.", x, x_mask)
+    x = rel_pos_transformer(sd, p + "encoder.", x, x_mask, ep["num_layers"], ep["num_heads"], ep["kernel_size"],
+                            ep.get("rel_attn_window_size"), ep.get("layer_norm_type", "1"))
+    x_m = conv1d(sd, p + "proj_m", x) * x_mask
+    if not a["mean_only"]:
+        x_logs = conv1d(sd, p + "proj_s", x) * x_mask
+    else:
+        x_logs = torch.zeros_like(x_m)
+    logw = duration_predictor(sd, p + "duration_predictor.", x, x_mask)
+    return x_m, x_logs, logw, x_mask
+
+
+def glow_squeeze(x, x_mask, n=2):
+    """glow_tts/decoder.py:8-28."""
+    b, c, t = x.size()
+    t = (t // n) * n
+    x = x[:, :, :t]
+    x_sqz = x.view(b, c, t // n, n).permute(0, 3, 1, 2).contiguous().view(b, c * n, t // n)
+    x_mask = x_mask[:, :, n - 1::n]
+    return x_sqz * x_mask, x_mask
+
+
+def glow_unsqueeze(x, x_mask, n=2):
+    """glow_tts/decoder.py:31-47."""
+    b, c, t = x.size()
+    x_unsqz = x.view(b, n, c // n, t).permute(0, 2, 3, 1).contiguous().view(b, c // n, t * n)
+    x_mask = x_mask.unsqueeze(-1).repeat(1, 1, 1, n).view(b, 1, t * n)
+    return x_unsqz * x_mask, x_mask
+
+
+def glow_decoder_reverse(sd, p, x, x_mask, a):
+    """Decoder.forward(reverse=True), glow_tts/decoder.py:113-137 with ActNorm (normalization.py:98-101),
+    InvConvNear (glow.py:107-137) and CouplingBlock (glow.py:200-229) in reverse."""
+    ns, nsq = a["num_splits"], a["num_squeeze"]
+    if nsq > 1:
+        x, x_mask = glow_squeeze(x, x_mask, nsq)
+    cin = x.shape[1]
+    for blk in reversed(range(a["num_flow_blocks_dec"])):
+        pa, pi, pc = (p + "flows.%d." % (3 * blk + j) for j in range(3))
+        # CouplingBlock reverse
+        x0, x1 = x[:, : cin // 2], x[:, cin // 2:]
+        h = conv1d(sd, pc + "start", x0) * x_mask
+        h = wn_forward(sd, pc + "wn.", h, x_mask, a["hidden_channels_dec"], a["kernel_size_dec"],
+                       a["dilation_rate"], a["num_block_layers"])
+        out = conv1d(sd, pc + "end", h)
+        t_, s_ = out[:, : cin // 2], out[:, cin // 2:]
+        if a["sigmoid_scale"]:
+            s_ = torch.log(1e-6 + torch.sigmoid(s_ + 2))
+        x = torch.cat([x0, (x1 - t_) * torch.exp(-s_) * x_mask], 1)
+        # InvConvNear reverse
+        b, c, t = x.size()
+        w = sd[pi + "weight_inv"] if (pi + "weight_inv") in sd else torch.inverse(sd[pi + "weight"].float())
+        xx = x.view(b, 2, c // ns, ns // 2, t).permute(0, 1, 3, 2, 4).contiguous().view(b, ns, c // ns, t)
+        z = F.conv2d(xx, w.view(ns, ns, 1, 1))
+        x = z.view(b, 2, ns // 2, c // ns, t).permute(0, 1, 3, 2, 4).contiguous().view(b, c, t) * x_mask
+        # ActNorm reverse
+        x = (x - sd[pa + "bias"]) * torch.exp(-sd[pa + "logs"]) * x_mask
+    if nsq > 1:
+        x, x_mask = glow_unsqueeze(x, x_mask, nsq)
+    return x
+
+
+def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None):
+    """GlowTTS.inference, glow_tts.py:341-374 (single speaker)."""
+    a = dict(GLOW_DEFAULTS)
+    a.update(args or {})
+    o_mean, o_log_scale, o_dur_log, x_mask = glow_encoder(sd, "encoder.", tokens, x_lengths, a)
+    w = (torch.exp(o_dur_log) - 1) * x_mask * a["length_scale"]
+    w_ceil = torch.clamp_min(torch.ceil(w), 1)
+    y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+    y_mask = torch.unsqueeze(sequence_mask(y_lengths, None), 1).to(x_mask.dtype)
+    attn_mask = torch.unsqueeze(x_mask, -1) * torch.unsqueeze(y_mask, 2)
+    attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
+    y_mean = torch.matmul(attn.squeeze(1).transpose(1, 2), o_mean.transpose(1, 2)).transpose(1, 2)
+    y_log_scale = torch.matmul(attn.squeeze(1).transpose(1, 2), o_log_scale.transpose(1, 2)).transpose(1, 2)
+    if noise is None:
+        noise = torch.randn_like(y_mean)
+    z = (y_mean + torch.exp(y_log_scale) * noise * a["inference_noise_scale"]) * y_mask
+    y = glow_decoder_reverse(sd, "decoder.", z, y_mask, a)
+    return {"model_outputs": y.transpose(1, 2), "alignments": attn.squeeze(1).permute(0, 2, 1),
+            "durations_log": o_dur_log.transpose(1, 2), "y_mean": y_mean.transpose(1, 2), "durations": w_ceil,
+            "y_lengths": y_lengths}
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded weight factory (no network => no released checkpoints; SURVEY §8c "Weights")
+# ----------------------------------------------------------------------------------------------
+def _conv(sd, name, cout, cin, k, gen, wn=False, bias=True, std=None, transposed=False):
+    fan_in = cin * k
+    std = std if std is not None else 1.0 / math.sqrt(fan_in)
+    shape = (cin, cout, k) if transposed else (cout, cin, k)
+    v = torch.randn(shape, generator=gen) * std
+    if wn:
+        n0 = shape[0]
+        g = v.reshape(n0, -1).norm(dim=1).reshape(n0, 1, 1) * (0.8 + 0.4 * torch.rand(n0, 1, 1, generator=gen))
+        sd[name + ".parametrizations.weight.original0"] = g
+        sd[name + ".parametrizations.weight.original1"] = v
+    else:
+        sd[name + ".weight"] = v
+    if bias:
+        sd[name + ".bias"] = torch.randn(cout, generator=gen) * 0.02
+
+
+def make_hifigan_state(cfg, in_channels, seed=1234, prefix="", weight_norm=True, pre_wn=True, post_wn=True,
+                       post_bias=True, out_channels=1):
+    """Random HifiganGenerator state_dict in the reference's key layout (hifigan_generator.py:199-234)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+    c0 = cfg["upsample_initial_channel"]
+    _conv(sd, prefix + "conv_pre", c0, in_channels, 7, gen, wn=weight_norm and pre_wn)
+    ch = c0
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(cfg["upsample_factors"], cfg["upsample_kernel_sizes"])):
+        _conv(sd, prefix + "ups.%d" % i, ch // 2, ch, k, gen, wn=weight_norm, transposed=True,
+              std=1.0 / math.sqrt(ch * k / u))
+        ch //= 2
+        for j, (rk, rd) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
+            rp = prefix + "resblocks.%d." % (i * nk + j)
+            for m in range(len(rd)):
+                if str(cfg["resblock_type"]) == "1":
+                    _conv(sd, rp + "convs1.%d" % m, ch, ch, rk, gen, wn=weight_norm, std=0.7 / math.sqrt(ch * rk))
+                    _conv(sd, rp + "convs2.%d" % m, ch, ch, rk, gen, wn=weight_norm, std=0.7 / math.sqrt(ch * rk))
+                else:
+                    _conv(sd, rp + "convs.%d" % m, ch, ch, rk, gen, wn=weight_norm, std=0.7 / math.sqrt(ch * rk))
+    _conv(sd, prefix + "conv_post", out_channels, ch, 7, gen, wn=weight_norm and post_wn, bias=post_bias)
+    return sd

@@ -1,0 +1,76 @@
+"""Golden cases: each function runs either the REAL reference modules (`impl="ref"`, container only)
+or the oracle restatement (`impl="oracle"`) on identical seeded weights + inputs and returns the
+tensors that are compared."""
+import torch
+
+from oracle import tts_oracle as O
+from oracle import weights as W
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def hifigan_small(impl, rb="1"):
+    cfg = dict(W.HIFIGAN_V1, upsample_initial_channel=64, resblock_type=rb)
+    if rb == "2":
+        cfg["resblock_dilation_sizes"] = [[1, 3], [1, 3], [1, 3]]
+    sd = O.make_hifigan_state(cfg, 80, seed=11)
+    x = torch.randn(2, 80, 23, generator=_g(0))
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        with torch.no_grad():
+            o = RM.hifigan(sd, cfg, 80).inference(x)
+    else:
+        o = O.hifigan_inference(sd, "", x, cfg)
+    return {"wav": o}
+
+
+VITS_SMALL = dict(upsample_initial_channel_decoder=64)
+
+
+def vits_small(impl, use_sdp=True):
+    args = dict(VITS_SMALL, use_sdp=use_sdp)
+    sd = W.make_vits_state(args, seed=1234)
+    x = torch.randint(0, 100, (3, 37), generator=_g(0))
+    xl = torch.tensor([37, 30, 21])
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        out = RM.RefVits(sd, args).inference(x, xl, seed=7)
+    else:
+        torch.manual_seed(7)
+        out = O.vits_inference(sd, x, xl, args)
+    keys = ["x", "logw", "durations", "m_p", "logs_p", "z_p", "z", "model_outputs"]
+    return {k: out[k] for k in keys}
+
+
+GLOW_SMALL = dict(inference_noise_scale=0.33, num_flow_blocks_dec=4)
+
+
+def glow_small(impl, window=None, ln="1"):
+    args = dict(GLOW_SMALL)
+    args["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], rel_attn_window_size=window, layer_norm_type=ln,
+                                  num_layers=3)
+    sd = W.make_glow_state(args, seed=4321)
+    x = torch.randint(0, 130, (2, 29), generator=_g(1))
+    xl = torch.tensor([29, 20])
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        out = RM.RefGlow(sd, args).inference(x, xl, seed=3)
+    else:
+        torch.manual_seed(3)
+        out = O.glow_tts_inference(sd, x, xl, args)
+    return {k: out[k] for k in ["model_outputs", "durations", "durations_log", "y_mean"]}
+
+
+CASES = {
+    "hifigan_small_rb1": lambda impl: hifigan_small(impl, "1"),
+    "hifigan_small_rb2": lambda impl: hifigan_small(impl, "2"),
+    "vits_small_sdp": lambda impl: vits_small(impl, True),
+    "vits_small_dp": lambda impl: vits_small(impl, False),
+    "glow_small": lambda impl: glow_small(impl),
+    "glow_small_relwin": lambda impl: glow_small(impl, 4, "2"),
+}

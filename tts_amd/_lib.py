@@ -34,6 +34,11 @@ def lib():
                 "libtts_amd.so is missing (%s): build it with `python -m tts_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
             )
+        # torch ships its own libamdhip64.so.7; load it FIRST so that libtts_amd.so (NEEDED
+        # libamdhip64.so.7) binds to the same HIP runtime instance by SONAME — streams and device
+        # pointers are shared with torch.  (Two HIP runtimes in one process see no device.)
+        import torch  # noqa: F401
+
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ttsamd_last_error.restype = ctypes.c_char_p
         _lib.ttsamd_arch.restype = ctypes.c_char_p
