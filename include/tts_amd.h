@@ -65,6 +65,73 @@ int ttsamd_maximum_path(void *paths, const float *values_in, const float *mask, 
 int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, int t_x, int t_y,
                         void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Conv1d / ConvTranspose1d as implicit GEMM on the fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact
+ * fp32 == an fmaf chain, at the fp32 vector peak rate) with fused prologue/epilogue.
+ * replaces (torch ops behind): torch.nn.Conv1d / ConvTranspose1d + F.leaky_relu + residual adds in
+ *   TTS/vocoder/models/hifigan_generator.py:83-98 (ResBlock1), :150-155 (ResBlock2), :236-265
+ *   (HifiganGenerator.forward); TTS/tts/layers/generic/wavenet.py:92-116 (WN.forward, incl. the
+ *   TorchScript fused_add_tanh_sigmoid_multiply :6-13); TTS/tts/layers/vits/networks.py:138-166
+ *   (ResidualCouplingBlock); TTS/tts/layers/glow_tts/transformer.py:106-114,290-295 (q/k/v/o + FFN).
+ * ---------------------------------------------------------------------------------------- */
+#define TTSAMD_ACT_NONE 0
+#define TTSAMD_ACT_LRELU 1 /* input side: leaky_relu(x, in_slope) */
+#define TTSAMD_ACT_RELU 1  /* output side */
+#define TTSAMD_ACT_TANH 2  /* output side */
+
+#define TTSAMD_CONV_NORMAL 0
+/* WN gate: packed row tile 2a = tanh channels [32a,32a+32), tile 2a+1 = sigmoid channels; writes
+ * tanh(.)*sigmoid(.) to out channel 32a+i (wavenet.py:6-13). c_out = number of packed rows (2H). */
+#define TTSAMD_CONV_GATE 1
+/* ConvTranspose1d (kernel 2u, stride u, pad u/2) in polyphase form: packed row m = co*u + r holds
+ * the 2-tap filter of phase r; column q is written to y[b, co, q*u + r - shuffle_pad]. */
+#define TTSAMD_CONV_SHUFFLE 2
+/* affine coupling, mean only (networks.py:164): y = (res - (conv+bias)*mask) * mask */
+#define TTSAMD_CONV_COUPLE 3
+
+typedef struct ttsamd_conv1d_args {
+    const float *x;        /* x[b,ci,t] = x[b*x_bstride + ci*x_rstride + t], t in [0,t_in) */
+    int64_t x_bstride, x_rstride;
+    int32_t c_in, t_in;
+    const float *w_packed; /* from ttsamd_conv1d_pack_weights */
+    const float *bias;     /* [c_out] in packed-row order, or NULL */
+    int32_t c_out, kernel, dilation, pad_left;
+    float *y;              /* y[b,co,t] = y[b*y_bstride + co*y_rstride + t] */
+    int64_t y_bstride, y_rstride;
+    int32_t t_out;         /* number of output columns computed (conv domain) */
+    int32_t batch;
+    int32_t in_act;        /* TTSAMD_ACT_NONE | TTSAMD_ACT_LRELU, applied once per staged element */
+    float in_slope;
+    const float *in_mask;  /* [batch, t_in] multiplied into x before the activation, or NULL */
+    int32_t mode;          /* TTSAMD_CONV_* */
+    int32_t out_act;       /* v = act(acc + bias) */
+    const float *res;      /* v += res[b,co,t]   (or NULL) */
+    int64_t res_bstride, res_rstride;
+    const float *accum;    /* v = accum[b,co,t] + v (or NULL) */
+    int64_t accum_bstride, accum_rstride;
+    const float *out_mask; /* [batch, t_out]: v *= mask (or NULL) */
+    float out_div;         /* v = v / out_div when != 0 (true division: z_sum / num_kernels) */
+    int32_t shuffle_u, shuffle_pad, shuffle_t_out; /* TTSAMD_CONV_SHUFFLE only */
+} ttsamd_conv1d_args;
+
+int ttsamd_conv1d(const ttsamd_conv1d_args *args /* host */, void *stream);
+
+/* Number of floats of the packed image of a [c_out, c_in, kernel] weight. */
+size_t ttsamd_conv1d_packed_floats(int c_out, int c_in, int kernel);
+/* HOST-side repack (load time): w [c_out, c_in, kernel] row-major (host) -> MFMA fragment order
+ * dst (host) = [ceil(c_out/32)][k-step groups][64 lanes][4]; zero padded. */
+int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, int kernel);
+/* 1 if (kernel, dilation) has a tuned instantiation. */
+int ttsamd_conv1d_supported(int kernel, int dilation);
+
+/* ------------------------------------------------------------------------------------------
+ * Small streaming kernels (HBM-bound; coalesced, one pass)
+ * ---------------------------------------------------------------------------------------- */
+/* y[b,c,:] = F.pad(x[b,c,:], (pad,pad), "replicate")  — HifiganGenerator.inference,
+ * TTS/vocoder/models/hifigan_generator.py:281.  x [rows, t], y [rows, t + 2*pad]. */
+int ttsamd_replicate_pad(float *y, const float *x, int64_t rows, int t, int pad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""GPU parity: fused MFMA Conv1d / polyphase ConvTranspose1d vs torch fp32 CPU ops (floating point:
+tolerance = 1e-5 relative RMS, i.e. fp32 reordering noise; north_star bar is 1e-4 absolute RMS)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tts_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+CASES = [  # (B, Cin, Cout, K, D, T)
+    (2, 32, 32, 3, 1, 700), (2, 32, 32, 7, 5, 1000), (1, 64, 64, 11, 3, 600), (2, 128, 128, 7, 1, 300),
+    (1, 256, 256, 11, 5, 150), (2, 80, 512, 7, 1, 47), (2, 192, 384, 5, 1, 77), (3, 192, 96, 1, 1, 33),
+    (2, 96, 192, 1, 1, 130), (2, 768, 192, 3, 1, 257), (1, 32, 1, 7, 1, 5000), (2, 192, 29, 1, 1, 50),
+    (2, 3, 20, 3, 9, 40), (1, 17, 40, 5, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv1d_matches_torch(gpu, case):
+    B, Cin, Cout, K, D, T = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / np.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g)
+    want = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=(K - 1) * D // 2, dilation=D)
+    pc = ops.PackedConv(w, b, gpu, dilation=D)
+    y = torch.full((B, Cout, T), float("nan"), device=gpu)
+    ops.conv1d(pc, x.to(gpu), y, in_act=ops.ACT_LRELU, in_slope=0.1)
+    assert _rel(y, want) < TOL
+
+
+def test_conv1d_epilogue_res_accum_mask_div(gpu):
+    g = torch.Generator().manual_seed(1)
+    B, C, T, K = 2, 64, 333, 7
+    x, res, acc = (torch.randn(B, C, T, generator=g) for _ in range(3))
+    mask = (torch.arange(T)[None, :] < torch.tensor([333, 200])[:, None]).float()
+    w = torch.randn(C, C, K, generator=g) / np.sqrt(C * K)
+    b = torch.randn(C, generator=g)
+    want = (acc + (F.conv1d(x * mask[:, None], w, b, padding=3) + res)) * mask[:, None] / 3.0
+    pc = ops.PackedConv(w, b, gpu)
+    y = torch.empty(B, C, T, device=gpu)
+    ops.conv1d(pc, x.to(gpu), y, in_mask=mask.to(gpu), res=res.to(gpu), accum=acc.to(gpu), out_mask=mask.to(gpu),
+               out_div=3.0)
+    assert _rel(y, want) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 64, 32, 8, 50), (1, 128, 64, 2, 301), (2, 32, 16, 2, 64), (1, 512, 256, 8, 20)])
+def test_conv_transpose_polyphase(gpu, case):
+    B, Cin, Cout, u, T = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cin, Cout, 2 * u, generator=g) / np.sqrt(Cin * 2)
+    b = torch.randn(Cout, generator=g)
+    want = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=u // 2)
+    wp, bp = ops.convt_polyphase_weight(w, b, u)
+    pc = ops.PackedConv(wp, bp, gpu, pad_left=1)
+    y = torch.full((B, Cout, T * u), float("nan"), device=gpu)
+    ops.conv1d(pc, x.to(gpu), y, in_act=ops.ACT_LRELU, in_slope=0.1, mode=ops.CONV_SHUFFLE, shuffle_u=u,
+               shuffle_pad=u // 2)
+    assert want.shape == y.shape
+    assert _rel(y, want) < TOL
+
+
+def test_gate_and_couple_modes(gpu):
+    g = torch.Generator().manual_seed(3)
+    B, H, T = 2, 192, 90
+    x = torch.randn(B, H, T, generator=g)
+    w = torch.randn(2 * H, H, 5, generator=g) / np.sqrt(H * 5)
+    b = torch.randn(2 * H, generator=g) * 0.1
+    xin = F.conv1d(x, w, b, padding=2)
+    want = torch.tanh(xin[:, :H]) * torch.sigmoid(xin[:, H:])
+    wg, bg = ops.gate_permute(w, b, H)
+    y = torch.empty(B, H, T, device=gpu)
+    ops.conv1d(ops.PackedConv(wg, bg, gpu), x.to(gpu), y, mode=ops.CONV_GATE)
+    assert _rel(y, want) < TOL
+    # mean-only coupling: x1 = (x1 - post(h)*mask) * mask, in place on the upper half of z
+    z = torch.randn(B, H, T, generator=g)
+    mask = (torch.arange(T)[None, :] < torch.tensor([90, 61])[:, None]).float()
+    wpost = torch.randn(H // 2, H, 1, generator=g) / np.sqrt(H)
+    bpost = torch.randn(H // 2, generator=g) * 0.1
+    m = F.conv1d(x, wpost, bpost) * mask[:, None]
+    want_z = z.clone()
+    want_z[:, H // 2:] = (z[:, H // 2:] - m) * mask[:, None]
+    zg = z.to(gpu)
+    ops.conv1d(ops.PackedConv(wpost, bpost, gpu), x.to(gpu), zg, mode=ops.CONV_COUPLE, res=zg, out_mask=mask.to(gpu),
+               y_row_offset=H // 2, res_row_offset=H // 2)
+    assert _rel(zg, want_z) < TOL
+
+
+def test_replicate_pad(gpu):
+    x = torch.randn(3, 5, 17)
+    y = torch.empty(3, 5, 27, device=gpu)
+    ops.replicate_pad(x.to(gpu), y, 5)
+    assert torch.equal(y.cpu(), F.pad(x, (5, 5), mode="replicate"))

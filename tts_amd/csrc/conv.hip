@@ -1,0 +1,78 @@
+// Conv1d dispatcher + host-side weight packing (see conv_kernel.h for the kernel design).
+#include "conv_kernel.h"
+
+#include <cstring>
+
+using namespace ttsamd;
+
+extern "C" int ttsamd_conv1d_supported(int kernel, int dilation)
+{
+    switch (kernel) {
+        case 1: case 2: case 5: return dilation == 1;
+        case 3: case 7: case 11: return dilation == 1 || dilation == 3 || dilation == 5 || (kernel == 3 && dilation == 9);
+        default: return 0;
+    }
+}
+
+extern "C" size_t ttsamd_conv1d_packed_floats(int c_out, int c_in, int kernel)
+{
+    if (c_out <= 0 || c_in <= 0 || kernel <= 0) return 0;
+    const size_t mtiles = (size_t)(c_out + 31) / 32;
+    const size_t nchunks = (size_t)(c_in + kConvCK - 1) / kConvCK;
+    const size_t gpc = (size_t)(kConvCK / 2) * kernel / 4;
+    return mtiles * nchunks * gpc * 256 + 256;  // + one zero group of prefetch slack
+}
+
+extern "C" int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, int kernel)
+{
+    TTSAMD_CHECK_ARG(dst && w && c_out > 0 && c_in > 0 && kernel > 0, "conv1d_pack_weights: bad args");
+    TTSAMD_CHECK_ARG(((kConvCK / 2) * kernel) % 4 == 0, "conv1d_pack_weights: kernel size %d unsupported", kernel);
+    const size_t n = ttsamd_conv1d_packed_floats(c_out, c_in, kernel);
+    memset(dst, 0, n * sizeof(float));
+    const int mtiles = (c_out + 31) / 32;
+    const int nchunks = (c_in + kConvCK - 1) / kConvCK;
+    const int gpc = (kConvCK / 2) * kernel / 4;
+    const long ksg = (long)nchunks * gpc;
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int c = 0; c < nchunks; ++c)
+            for (int p = 0; p < kConvCK / 2; ++p)
+                for (int tap = 0; tap < kernel; ++tap) {
+                    const int ksl = p * kernel + tap;
+                    const long g = (long)c * gpc + ksl / 4;
+                    const int s = ksl % 4;
+                    for (int l = 0; l < 64; ++l) {
+                        const int row = mt * 32 + (l & 31);
+                        const int ci = c * kConvCK + 2 * p + (l >> 5);
+                        if (row < c_out && ci < c_in)
+                            dst[((mt * ksg + g) * 64 + l) * 4 + s] = w[((long)row * c_in + ci) * kernel + tap];
+                    }
+                }
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
+{
+    TTSAMD_CHECK_ARG(args, "conv1d: NULL args");
+    const ttsamd_conv1d_args &a = *args;
+    TTSAMD_CHECK_ARG(a.x && a.w_packed && a.y, "conv1d: NULL tensor");
+    TTSAMD_CHECK_ARG(a.c_in > 0 && a.c_out > 0 && a.batch >= 0 && a.t_in >= 0 && a.t_out >= 0, "conv1d: bad shape");
+    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_COUPLE || a.res, "conv1d: COUPLE needs res");
+    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_SHUFFLE || a.shuffle_u > 0, "conv1d: SHUFFLE needs shuffle_u");
+    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_GATE || (a.c_out % 64) == 0, "conv1d: GATE needs c_out %% 64 == 0");
+    if (a.batch == 0 || a.t_out == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(a.batch <= 65535, "conv1d: batch > 65535");
+    if (!ttsamd_conv1d_supported(a.kernel, a.dilation)) {
+        set_error("conv1d: (kernel=%d, dilation=%d) has no instantiation", a.kernel, a.dilation);
+        return TTSAMD_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    switch (a.kernel) {
+        case 1: return conv1d_launch_k1(a, st);
+        case 2: return conv1d_launch_k2(a, st);
+        case 3: return conv1d_launch_k3(a, st);
+        case 5: return conv1d_launch_k5(a, st);
+        case 7: return conv1d_launch_k7(a, st);
+        case 11: return conv1d_launch_k11(a, st);
+    }
+    return TTSAMD_ERR_UNSUPPORTED;
+}

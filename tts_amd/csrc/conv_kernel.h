@@ -1,0 +1,265 @@
+// Conv1d as implicit GEMM on the fp32-input MFMA of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+//   y[b,co,t] = epilogue( bias[co] + sum_{ci,k} W[co,ci,k] * act(x[b,ci,t + k*D - pad_left]) )
+//
+// GEMM view: M = c_out rows, N = time, reduction = (ci, tap).  One MFMA consumes two reduction
+// indices: lanes 0-31 carry channel 2p, lanes 32-63 channel 2p+1, same tap (kernel sizes are odd, so
+// channels are paired, not taps).
+//   * A (weights): pre-packed at load time in exact fragment order [m-tile][k-step group][lane][4],
+//     so every wave fetches its fragments with one fully coalesced 16-byte-per-lane load per four
+//     k-steps straight from L2 (a c_out-tile's weights are re-used by every time tile; measured
+//     need ~2-4 B/clk/CU, far below L2 bandwidth) — no LDS round trip, software-prefetched one
+//     group ahead.
+//   * B (activations): a [16 channels][BN + halo] tile is staged once per channel chunk through
+//     registers into LDS (double buffered, one barrier per chunk); leaky-ReLU / input masking are
+//     applied ONCE per staged element, not per tap.  B fragments are `ds_read_b32` with a single
+//     base VGPR + compile-time immediates (K, D are template parameters): lanes read 32 consecutive
+//     floats per half-wave => bank-conflict free.
+//   * D: 32x32 fp32 accumulators stay in registers for the whole reduction; the epilogue fuses
+//     bias, activation, residual add, MRF accumulation, masking, the WaveNet tanh*sigmoid gate,
+//     the mean-only affine coupling and the polyphase "pixel shuffle" of ConvTranspose1d.
+// fp32 MFMA is bit-for-bit an fmaf chain (one rounding per product), i.e. the same arithmetic
+// class as the reference's fp32 CPU conv; only the summation order differs.
+#pragma once
+#include "common.h"
+
+namespace ttsamd {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kConvCK = 16;  // input channels per LDS chunk (8 channel pairs)
+
+struct ConvTileCfg {
+    int mi, ni, wm, wn;
+};
+
+template <int K, int D, int MI, int NI, int WM, int WN>
+struct ConvGeom {
+    static constexpr int kThreads = 64 * WM * WN;
+    static constexpr int kBM = 32 * MI * WM;
+    static constexpr int kBN = 32 * NI * WN;
+    static constexpr int kHalo = (K - 1) * D;
+    static constexpr int kXW = kBN + kHalo;                 // staged columns per channel
+    static constexpr int kStageElems = kConvCK * kXW;
+    static constexpr int kNStage = (kStageElems + kThreads - 1) / kThreads;
+    static constexpr int kGroupsPerChunk = (kConvCK / 2) * K / 4;  // k-step groups (of 4) per chunk
+    static constexpr size_t kLdsBytes = (size_t)2 * kStageElems * sizeof(float);
+};
+
+__device__ __forceinline__ float conv_in_act(float v, int act, float slope)
+{
+    return (act == TTSAMD_ACT_LRELU) ? (v > 0.f ? v : v * slope) : v;
+}
+
+template <int K, int D, int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_conv1d_args a)
+{
+    using G = ConvGeom<K, D, MI, NI, WM, WN>;
+    static_assert(((kConvCK / 2) * K) % 4 == 0, "k-steps per chunk must be a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][CK][XW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int h = lane >> 5;   // which channel of the pair / which row group of D
+    const int j = lane & 31;   // column inside a 32-wide N tile
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * G::kBN;
+    const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
+    const long ksg_total = (long)nchunks * G::kGroupsPerChunk;  // groups per m-tile
+
+    const float *xb = a.x + (long)b * a.x_bstride;
+    const float *mrow = a.in_mask ? a.in_mask + (long)b * a.t_in : nullptr;
+
+    // ---- staging helpers -------------------------------------------------------------------
+    float st[G::kNStage];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) {
+            const int e = tid + i * G::kThreads;
+            const int row = e / G::kXW;
+            const int col = e - row * G::kXW;
+            const int ci = chunk * kConvCK + row;
+            const int gt = t0 - a.pad_left + col;
+            float v = 0.f;
+            if (e < G::kStageElems && ci < a.c_in && gt >= 0 && gt < a.t_in) {
+                v = xb[(long)ci * a.x_rstride + gt];
+                if (mrow) v *= mrow[gt];
+            }
+            st[i] = v;
+        }
+    };
+    auto stage_store = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) {
+            const int e = tid + i * G::kThreads;
+            if (e < G::kStageElems) buf[e] = conv_in_act(st[i], a.in_act, a.in_slope);
+        }
+    };
+
+    // ---- accumulators ----------------------------------------------------------------------
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // A fragment stream of this wave: m-tile (blockIdx.y*WM + wm)*MI + mi
+    const float4 *wp[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+        wp[mi] = reinterpret_cast<const float4 *>(a.w_packed) + (mtile * ksg_total) * 64 + lane;
+    }
+    float4 a_cur[MI], a_nxt[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a_cur[mi] = wp[mi][0];
+
+    stage_load(0);
+    stage_store(xs);
+    __syncthreads();
+
+    const int bcol = h * G::kXW + wn * (32 * NI) + j;  // base LDS index of this lane's B reads
+    for (int c = 0; c < nchunks; ++c) {
+        const float *cur = xs + (c & 1) * G::kStageElems;
+        if (c + 1 < nchunks) stage_load(c + 1);
+        const float *bbase = cur + bcol;
+#pragma unroll
+        for (int gl = 0; gl < G::kGroupsPerChunk; ++gl) {
+            const long g = (long)c * G::kGroupsPerChunk + gl;
+            // prefetch the next group's fragments (the packed image has one zero group of slack)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a_nxt[mi] = wp[mi][(g + 1) * 64];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int ks = gl * 4 + s;       // compile-time after unrolling
+                const int p = ks / K;
+                const int tap = ks - p * K;
+                float bf[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bf[ni] = bbase[(2 * p) * G::kXW + ni * 32 + tap * D];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float av = (s == 0) ? a_cur[mi].x : (s == 1) ? a_cur[mi].y : (s == 2) ? a_cur[mi].z : a_cur[mi].w;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a_cur[mi] = a_nxt[mi];
+        }
+        if (c + 1 < nchunks) stage_store(xs + ((c + 1) & 1) * G::kStageElems);
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------
+    const float *omask = a.out_mask ? a.out_mask + (long)b * a.t_out : nullptr;
+    if (a.mode == TTSAMD_CONV_GATE) {
+        if constexpr (MI == 2) {
+            const long pair = (long)blockIdx.y * WM + wm;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const long prow = pair * 64 + i;  // packed row of the tanh half
+                    if (prow + 32 < a.c_out && t < a.t_out) {
+                        float vt = acc[0][ni][r], vs = acc[1][ni][r];
+                        if (a.bias) { vt += a.bias[prow]; vs += a.bias[prow + 32]; }
+                        const float g = tanhf(vt) * (1.f / (1.f + expf(-vs)));
+                        a.y[(long)b * a.y_bstride + (pair * 32 + i) * a.y_rstride + t] = g;
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= a.c_out || t >= a.t_out) continue;
+                float v = acc[mi][ni][r];
+                if (a.bias) v += a.bias[row];
+                if (a.out_act == TTSAMD_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (a.out_act == TTSAMD_ACT_TANH) v = tanhf(v);
+                if (a.mode == TTSAMD_CONV_SHUFFLE) {
+                    const int co = (int)(row / a.shuffle_u);
+                    const int rr = (int)(row - (long)co * a.shuffle_u);
+                    const int n = t * a.shuffle_u + rr - a.shuffle_pad;
+                    if (n >= 0 && n < a.shuffle_t_out)
+                        a.y[(long)b * a.y_bstride + (long)co * a.y_rstride + n] = v;
+                    continue;
+                }
+                if (a.mode == TTSAMD_CONV_COUPLE) {
+                    const float m = omask ? omask[t] : 1.f;
+                    v = v * m;
+                    v = (a.res[(long)b * a.res_bstride + row * a.res_rstride + t] - v) * m;
+                    a.y[(long)b * a.y_bstride + row * a.y_rstride + t] = v;
+                    continue;
+                }
+                if (a.res) v += a.res[(long)b * a.res_bstride + row * a.res_rstride + t];
+                if (a.accum) v = a.accum[(long)b * a.accum_bstride + row * a.accum_rstride + t] + v;
+                if (omask) v *= omask[t];
+                if (a.out_div != 0.f) v = v / a.out_div;
+                a.y[(long)b * a.y_bstride + row * a.y_rstride + t] = v;
+            }
+        }
+    }
+}
+
+template <int K, int D, int MI, int NI, int WM, int WN>
+int conv1d_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
+{
+    using G = ConvGeom<K, D, MI, NI, WM, WN>;
+    auto kern = conv1d_mfma_kernel<K, D, MI, NI, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLdsBytes));
+        attr_set = true;
+    }
+    const int mtiles = (a.c_out + 31) / 32;
+    const int mblocks = (mtiles + MI * WM - 1) / (MI * WM);
+    const int nblocks = (a.t_out + G::kBN - 1) / G::kBN;
+    hipLaunchKernelGGL(kern, dim3(nblocks, mblocks, a.batch), dim3(G::kThreads), G::kLdsBytes, st, a);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+// Tile choice by packed row count: 128x128 (4 waves, 2x2 of 64x64), 64x256, 32x512.
+template <int K, int D>
+int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
+{
+    const int mtiles = (a.c_out + 31) / 32;
+    if (a.mode == TTSAMD_CONV_GATE) {
+        if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2>(a, st);
+        return conv1d_launch_cfg<K, D, 2, 2, 1, 4>(a, st);
+    }
+    if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2>(a, st);
+    if (mtiles % 2 == 0) return conv1d_launch_cfg<K, D, 2, 2, 1, 4>(a, st);
+    return conv1d_launch_cfg<K, D, 1, 4, 1, 4>(a, st);
+}
+
+// one translation unit per kernel size (conv_k*.hip) so hipcc compiles them in parallel
+int conv1d_launch_k1(const ttsamd_conv1d_args &a, hipStream_t st);
+int conv1d_launch_k2(const ttsamd_conv1d_args &a, hipStream_t st);
+int conv1d_launch_k3(const ttsamd_conv1d_args &a, hipStream_t st);
+int conv1d_launch_k5(const ttsamd_conv1d_args &a, hipStream_t st);
+int conv1d_launch_k7(const ttsamd_conv1d_args &a, hipStream_t st);
+int conv1d_launch_k11(const ttsamd_conv1d_args &a, hipStream_t st);
+
+}  // namespace ttsamd

