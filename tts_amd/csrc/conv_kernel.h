@@ -73,9 +73,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
     const float *xb = a.x + (long)b * a.x_bstride;
     const float *mrow = a.in_mask ? a.in_mask + (long)b * a.t_in : nullptr;
 
-    // ---- staging helpers -------------------------------------------------------------------
+    // ---- staging helpers (branch-free: clamped always-valid address + select) --------------
     float st[G::kNStage];
     auto stage_load = [&](int chunk) {
+        const bool has_mask = (mrow != nullptr);  // wave-uniform
 #pragma unroll
         for (int i = 0; i < G::kNStage; ++i) {
             const int e = tid + i * G::kThreads;
@@ -83,12 +84,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
             const int col = e - row * G::kXW;
             const int ci = chunk * kConvCK + row;
             const int gt = t0 - a.pad_left + col;
-            float v = 0.f;
-            if (e < G::kStageElems && ci < a.c_in && gt >= 0 && gt < a.t_in) {
-                v = xb[(long)ci * a.x_rstride + gt];
-                if (mrow) v *= mrow[gt];
-            }
-            st[i] = v;
+            const bool ok = (e < G::kStageElems) && (ci < a.c_in) && (gt >= 0) && (gt < a.t_in);
+            const long off = ok ? ((long)ci * a.x_rstride + gt) : 0;
+            float v = xb[off];
+            if (has_mask) v *= mrow[ok ? gt : 0];
+            st[i] = ok ? v : 0.f;
         }
     };
     auto stage_store = [&](float *buf) {
@@ -128,28 +128,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
         const float *cur = xs + (c & 1) * G::kStageElems;
         if (c + 1 < nchunks) stage_load(c + 1);
         const float *bbase = cur + bcol;
+        constexpr int kSteps = G::kGroupsPerChunk * 4;
+        // B fragments are register double-buffered one k-step ahead of the MFMAs that use them.
+        float bf[2][NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[0][ni] = bbase[ni * 32];
 #pragma unroll
         for (int gl = 0; gl < G::kGroupsPerChunk; ++gl) {
             const long g = (long)c * G::kGroupsPerChunk + gl;
-            // prefetch the next group's fragments (the packed image has one zero group of slack)
+            // prefetch the next group's A fragments (the packed image has one zero group of slack)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a_nxt[mi] = wp[mi][(g + 1) * 64];
+            // pin the prefetch a full group (4 k-steps of MFMAs) ahead of its first use; hipcc
+            // otherwise sinks the loads down to their consumer and exposes the L2 latency.
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int ks = gl * 4 + s;       // compile-time after unrolling
-                const int p = ks / K;
-                const int tap = ks - p * K;
-                float bf[NI];
+                if (ks + 1 < kSteps) {
+                    const int p1 = (ks + 1) / K;
+                    const int tap1 = (ks + 1) - p1 * K;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bf[ni] = bbase[(2 * p) * G::kXW + ni * 32 + tap * D];
+                    for (int ni = 0; ni < NI; ++ni)
+                        bf[(ks + 1) & 1][ni] = bbase[(2 * p1) * G::kXW + ni * 32 + tap1 * D];
+                }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const float av = (s == 0) ? a_cur[mi].x : (s == 1) ? a_cur[mi].y : (s == 2) ? a_cur[mi].z : a_cur[mi].w;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[ks & 1][ni], acc[mi][ni], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -240,7 +248,7 @@ int conv1d_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
     return TTSAMD_OK;
 }
 
-// Tile choice by packed row count: 128x128 (4 waves, 2x2 of 64x64), 64x256, 32x512.
+// Tile choice by packed row count: 128x128 (4 waves, 2x2 of 64x64), 64x256, 32x256.
 template <int K, int D>
 int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
 {
@@ -251,7 +259,7 @@ int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
     }
     if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2>(a, st);
     if (mtiles % 2 == 0) return conv1d_launch_cfg<K, D, 2, 2, 1, 4>(a, st);
-    return conv1d_launch_cfg<K, D, 1, 4, 1, 4>(a, st);
+    return conv1d_launch_cfg<K, D, 1, 2, 1, 4>(a, st);
 }
 
 // one translation unit per kernel size (conv_k*.hip) so hipcc compiles them in parallel
