@@ -79,6 +79,7 @@ int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, 
 #define TTSAMD_ACT_LRELU 1 /* input side: leaky_relu(x, in_slope) */
 #define TTSAMD_ACT_RELU 1  /* output side */
 #define TTSAMD_ACT_TANH 2  /* output side */
+#define TTSAMD_ACT_GELU 3  /* norm kernel only: exact erf GELU (F.gelu default) */
 
 #define TTSAMD_CONV_NORMAL 0
 /* WN gate: packed row tile 2a = tanh channels [32a,32a+32), tile 2a+1 = sigmoid channels; writes
@@ -89,6 +90,12 @@ int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, 
 #define TTSAMD_CONV_SHUFFLE 2
 /* affine coupling, mean only (networks.py:164): y = (res - (conv+bias)*mask) * mask */
 #define TTSAMD_CONV_COUPLE 3
+/* WN res/skip 1x1 conv (wavenet.py:109-114): rows < split_row: y[row] = (res[row] + v) * out_mask;
+ * rows >= split_row: y2[row-split_row] = accum[row-split_row] + v (accum may be NULL: first layer). */
+#define TTSAMD_CONV_RES_SKIP 4
+/* Glow affine coupling (glow.py:216-224): packed row tile pairs like GATE: tile 2a = t rows, 2a+1 = s rows;
+ * y[32a+i] = (res[32a+i] - t) * exp(-s) * out_mask.  c_out = packed rows (2 * coupled channels). */
+#define TTSAMD_CONV_COUPLE_AFFINE 5
 
 typedef struct ttsamd_conv1d_args {
     const float *x;        /* x[b,ci,t] = x[b*x_bstride + ci*x_rstride + t], t in [0,t_in) */
@@ -113,6 +120,10 @@ typedef struct ttsamd_conv1d_args {
     const float *out_mask; /* [batch, t_out]: v *= mask (or NULL) */
     float out_div;         /* v = v / out_div when != 0 (true division: z_sum / num_kernels) */
     int32_t shuffle_u, shuffle_pad, shuffle_t_out; /* TTSAMD_CONV_SHUFFLE only */
+    float *y2;             /* TTSAMD_CONV_RES_SKIP: second output (skip accumulator) */
+    int64_t y2_bstride, y2_rstride;
+    int32_t split_row;
+    const float *row_bias; /* [batch, c_out] per-(b,row) additive term (speaker conditioning), or NULL */
 } ttsamd_conv1d_args;
 
 int ttsamd_conv1d(const ttsamd_conv1d_args *args /* host */, void *stream);
@@ -124,6 +135,114 @@ size_t ttsamd_conv1d_packed_floats(int c_out, int c_in, int kernel);
 int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, int kernel);
 /* 1 if (kernel, dilation) has a tuned instantiation. */
 int ttsamd_conv1d_supported(int kernel, int dilation);
+
+/* ------------------------------------------------------------------------------------------
+ * Channel LayerNorm on [B, C, T] (normalise over C for every (b, t)), with the fusions the text
+ * encoder / duration predictors need.
+ * replaces: TTS/tts/layers/generic/normalization.py:5-28 (LayerNorm, eps 1e-4) and :31-53
+ *   (LayerNorm2, eps 1e-5); the depthwise conv + norm + GELU chain of DilatedDepthSeparableConv
+ *   (TTS/tts/layers/vits/stochastic_duration_predictor.py:46-63); the residual adds around the
+ *   norms in TTS/tts/layers/glow_tts/transformer.py:419-431.
+ *   u[c,t]  = dw ? dw_bias[c] + sum_k dw_w[c,k] * (x*in_mask)[c, t + (k-(K-1)/2)*dil] : x[c,t]
+ *   u      += pre_res[c,t]                                   (if pre_res)
+ *   v       = (u - mean_c(u)) * rsqrt(var_c(u) + eps) * gamma[c] + beta[c]   (biased variance)
+ *   v       = act(v)   (NONE | RELU | GELU(erf))
+ *   v       = post_res[c,t] + v                              (if post_res)
+ *   y[c,t]  = v * out_mask[t]                                (if out_mask)
+ * Limit: C <= 512. */
+typedef struct ttsamd_norm_args {
+    const float *x;
+    int64_t x_bstride, x_rstride;
+    int32_t c, t, batch;
+    const float *gamma, *beta; /* [c] */
+    float eps;
+    const float *dw_w, *dw_bias; /* [c, dw_kernel], [c] or NULL */
+    int32_t dw_kernel, dw_dilation;
+    const float *in_mask; /* [batch, t], used by the depthwise prologue */
+    const float *pre_res;
+    int64_t pre_bstride, pre_rstride;
+    int32_t act;
+    const float *post_res;
+    int64_t post_bstride, post_rstride;
+    const float *out_mask; /* [batch, t] */
+    float *y;
+    int64_t y_bstride, y_rstride;
+} ttsamd_norm_args;
+int ttsamd_channel_norm(const ttsamd_norm_args *args /* host */, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Relative-position multi-head attention core (everything between conv_q/k/v and conv_o).
+ * replaces: RelativePositionMultiHeadAttention.attention, TTS/tts/layers/glow_tts/transformer.py:118-163
+ *   incl. _get_relative_embeddings / _relative_position_to_absolute_position /
+ *   _absolute_position_to_relative_position (:196-241).
+ *   q,k,v: [B, H*dk, T] (row stride t, batch stride qkv_bstride — they may live in one fused
+ *   [B, 3*H*dk, T] projection buffer); mask [B, T] (x_mask; attn_mask[i][j] = mask[i]*mask[j],
+ *   masked scores = -1e4, transformer.py:147); emb_rel_k / emb_rel_v [2*window+1, dk] shared by
+ *   all heads (heads_share=True) or NULL when rel_attn_window_size is None (window ignored).
+ *   out [B, H*dk, T] contiguous.  QK^T and P.V run on the fp32-input MFMA (exact fp32 products).
+ * Limits: dk % 32 == 0, dk <= 128, T <= 1024 (TTSAMD_ERR_UNSUPPORTED beyond). */
+int ttsamd_rel_attention(float *out, const float *q, const float *k, const float *v, int64_t qkv_bstride,
+                         const float *mask, const float *emb_rel_k, const float *emb_rel_v, int window,
+                         int batch, int heads, int dk, int t, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Text-side small kernels (HBM/latency-bound; one coalesced pass each)
+ * ---------------------------------------------------------------------------------------- */
+/* y[b,c,t] = emb[tokens[b,t], c] * scale * mask[b,t]     (TextEncoder.forward, networks.py:87-96;
+ * glow_tts/encoder.py:156-160).  tokens int64 [B,T], emb [V,C], mask [B,T] or NULL. */
+int ttsamd_embed(float *y, const int64_t *tokens, const float *emb, const float *mask, float scale,
+                 int batch, int c, int t, int vocab, void *stream);
+
+/* mask[b,t] = t < lengths[b] ? 1 : 0   (sequence_mask, TTS/tts/utils/helpers.py:43-57). lengths int64 [B]. */
+int ttsamd_sequence_mask(float *mask, const int64_t *lengths, int batch, int t, void *stream);
+
+/* ConvFlow head (stochastic_duration_predictor.py:121-122 + DDSConv's `x = x + g`, :55-56):
+ *   h[b,c,t] = w[c] * z[b, z_ch, t] + bias[c] + g[b,c,t]      (pre = Conv1d(1, C, 1)) */
+int ttsamd_convflow_pre(float *h, const float *z, int z_ch, const float *w, const float *bias, const float *g,
+                        int batch, int c, int t, void *stream);
+
+/* ConvFlow tail, reverse direction (stochastic_duration_predictor.py:126-147 +
+ * TTS/tts/layers/vits/transforms.py:12-202, inverse=True, tails="linear", tail_bound):
+ *   params h [B, 3*bins-1, T] (proj output, already masked), z_in [B,2,T];
+ *   the flow sees zf = flip(z_in, channel) (stochastic_duration_predictor.py:289): x0 = z_in[:,1], x1 = z_in[:,0];
+ *   z_out[:,0] = x0 * mask,  z_out[:,1] = rq_spline_inverse(x1; h / sqrt(filter) ...) * mask. */
+int ttsamd_convflow_spline_reverse(float *z_out, const float *z_in, const float *h, const float *mask,
+                                   int batch, int t, int num_bins, float filter_channels, float tail_bound,
+                                   void *stream);
+
+/* ElementwiseAffine reverse after a channel flip (stochastic_duration_predictor.py:82-83,289):
+ *   z_out[b,c,t] = (z_in[b,1-c,t] - m[c]) * exp(-logs[c]) * mask[b,t],  c in {0,1}. */
+int ttsamd_sdp_affine_reverse(float *z_out, const float *z_in, const float *m, const float *logs,
+                              const float *mask, int batch, int t, void *stream);
+
+/* Durations from log-durations.
+ * VITS (vits.py:1140-1146):   w = exp(logw) * mask * length_scale;  w_ceil = ceil(w)
+ * Glow (glow_tts.py:350-352): w = (exp(logw) - 1) * mask * length_scale;  w_ceil = max(ceil(w), 1)   [glow != 0]
+ *   durations [B,T] float (= w_ceil), cum [B,T] int32 inclusive cumsum, y_lengths int64 [B] = max(sum, 1).
+ * `durations_in` (may be NULL) overrides w_ceil (logw ignored). */
+int ttsamd_durations(float *durations, int32_t *cum, int64_t *y_lengths, const float *logw,
+                     const float *durations_in, const float *mask, float length_scale, int glow, int batch,
+                     int t, void *stream);
+
+/* generate_path (helpers.py:154-169): attn[b,x,y] = (cum[b,x-1] <= y < cum[b,x]) * x_mask[b,x] * (y < y_lengths[b]). */
+int ttsamd_generate_path(float *attn, const int32_t *cum, const float *x_mask, const int64_t *y_lengths,
+                         int batch, int t_x, int t_y, void *stream);
+
+/* Prior expansion: the two attn matmuls + the noise draw as one gather
+ * (vits.py:1152-1155; glow_tts.py:137-148,361):
+ *   x = token owning frame y (from cum);  valid = x_mask[b,x] && y < y_lengths[b]
+ *   m_p[b,c,y] = valid ? m[b,c,x] : 0;  logs_p likewise (logs may be NULL = zeros: Glow mean_only)
+ *   z_p[b,c,y] = (m_p + noise[b,c,y] * exp(logs_p) * noise_scale) * (mask_out ? y_mask : 1)
+ *   y_mask[b,y] = y < y_lengths[b].   m_p / logs_p outputs may be NULL; z_p2 (may be NULL) gets a second copy. */
+int ttsamd_expand_prior(float *z_p, float *z_p2, float *m_p, float *logs_p, float *y_mask, const float *m,
+                        const float *logs, int64_t stats_bstride, const float *noise, const int32_t *cum,
+                        const float *x_mask, const int64_t *y_lengths, float noise_scale, int mask_out, int batch,
+                        int c, int t_x, int t_y, void *stream);
+/* m / logs are read as m[b*stats_bstride + c*t_x + x] (they are usually the two halves of one [B,2C,T_x]
+ * projection buffer). */
+
+/* y[i] = x[i] * s  (noise * noise_scale, stochastic_duration_predictor.py:287). */
+int ttsamd_scale(float *y, const float *x, float s, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small streaming kernels (HBM-bound; coalesced, one pass)

@@ -1,0 +1,122 @@
+"""GPU parity: tts_amd.Vits (HIP) vs the CPU oracle restatement of Vits.inference (oracle/tts_oracle.py, pinned to
+the reference modules) and vs the committed golden fixtures generated from the REAL reference modules
+(tests/golden/make_golden.py).
+
+Staging (SURVEY §7 "ceil() cliff"): integer durations must match exactly; a 1-ulp difference in logw next to an
+integer would shift every later sample, so on a (rare, reported) mismatch the comparison is re-run with the
+oracle's durations injected.  Waveform tolerance: 1e-4 absolute RMS (north_star) and 1e-5 relative RMS."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tts_oracle as O
+from oracle import weights as W
+from tts_amd.vits import Vits
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _errs(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    rms = float((a - b).pow(2).mean().sqrt())
+    return rms, rms / float(b.pow(2).mean().sqrt() + 1e-30)
+
+
+def _model(args, sd, gpu):
+    m = Vits({"model_args": args})
+    m.load_state_dict(sd)
+    return m.to(gpu)
+
+
+def _compare(out, want, B):
+    assert torch.equal(out["durations"].cpu(), want["durations"]), "integer durations differ"
+    for k in ("m_p", "logs_p", "z_p", "z"):
+        rms, rel = _errs(out[k], want[k])
+        assert rel < 1e-5, (k, rms, rel)
+    assert torch.equal(out["alignments"].cpu(), want["alignments"])
+    assert torch.equal(out["y_mask"].cpu(), want["y_mask"])
+    rms, rel = _errs(out["model_outputs"], want["model_outputs"])
+    assert out["model_outputs"].shape == want["model_outputs"].shape
+    assert rms < 1e-4 and rel < 1e-5, ("model_outputs", rms, rel)
+
+
+@pytest.mark.parametrize("use_sdp", [True, False])
+def test_vits_inference_matches_oracle(gpu, use_sdp):
+    torch.set_num_threads(8)
+    args = dict(upsample_initial_channel_decoder=64, use_sdp=use_sdp)
+    sd = W.make_vits_state(args, seed=77)
+    g = torch.Generator().manual_seed(0)
+    B, T = 3, 41
+    x = torch.randint(0, 100, (B, T), generator=g)
+    xl = torch.tensor([41, 29, 12])
+    noise_dp = torch.randn(B, 2, T, generator=g)
+    ref0 = O.vits_inference(sd, x, xl, args, noise_dp=noise_dp, stop_after="prior",
+                            noise_z=torch.zeros(B, 192, 1))  # durations only
+    t_dec = int(ref0["y_lengths"].max())
+    noise_z = torch.randn(B, 192, t_dec, generator=g)
+    want = O.vits_inference(sd, x, xl, args, noise_dp=noise_dp, noise_z=noise_z)
+    m = _model(args, sd, gpu)
+    aux = {"x_lengths": xl.to(gpu), "noise_dp": noise_dp.to(gpu), "noise_z": noise_z.to(gpu), "return_extras": True}
+    try:
+        out = m.inference(x.to(gpu), aux)
+        same = torch.equal(out["durations"].cpu(), want["durations"])
+    except AssertionError:
+        same = False
+    lw = _errs(m.inference(x.to(gpu), dict(aux, noise_z=None))["logw"], want["logw"])
+    assert lw[1] < 1e-5, ("logw", lw)
+    if not same:  # ceil() cliff: report, then compare with the oracle's integer durations injected
+        print("NOTE: duration flip between two fp32 implementations; injecting oracle durations")
+        out = m.inference(x.to(gpu), dict(aux, durations=want["durations"].to(gpu)))
+    _compare(out, want, B)
+    assert set(["model_outputs", "alignments", "durations", "z", "z_p", "m_p", "logs_p", "y_mask"]) <= set(out)
+    assert out["model_outputs"].shape == (B, 1, t_dec * 256)                    # tests/tts_tests/test_vits.py:283-290
+
+
+@pytest.mark.parametrize("name,use_sdp", [("vits_small_sdp", True), ("vits_small_dp", False)])
+def test_vits_matches_reference_golden(gpu, name, use_sdp):
+    """Fixture made by the real reference modules (tests/golden/cases.py:vits_small): same seeds -> same draws."""
+    from tests.golden import cases
+
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    args = dict(cases.VITS_SMALL, use_sdp=use_sdp)
+    sd = W.make_vits_state(args, seed=1234)
+    x = torch.randint(0, 100, (3, 37), generator=torch.Generator().manual_seed(0))
+    xl = torch.tensor([37, 30, 21])
+    t_dec = gold["z_p"].shape[2]
+    torch.manual_seed(7)                        # the reference draws randn(B,2,T) (SDP only) then randn_like(m_p)
+    noise_dp = torch.randn(3, 2, 37) if use_sdp else None
+    # randn_like(m_p) fills in m_p's MEMORY order; m_p is a transposed matmul result, i.e. laid out [B, T, C]
+    noise_z = torch.randn(3, t_dec, 192).transpose(1, 2)
+    m = _model(args, sd, gpu)
+    aux = {"x_lengths": xl.to(gpu), "noise_dp": None if noise_dp is None else noise_dp.to(gpu),
+           "noise_z": noise_z.to(gpu), "return_extras": True}
+    dur = torch.from_numpy(gold["durations"])
+    try:
+        out = m.inference(x.to(gpu), aux)
+        same = torch.equal(out["durations"].cpu(), dur)
+    except AssertionError:
+        same = False
+    if not same:
+        print("NOTE: duration flip vs golden; injecting golden durations")
+        out = m.inference(x.to(gpu), dict(aux, durations=dur.to(gpu)))
+    for k in ("m_p", "logs_p", "z_p", "z"):
+        rms, rel = _errs(out[k], torch.from_numpy(gold[k]))
+        assert rel < 1e-5, (k, rms, rel)
+    rms, rel = _errs(out["model_outputs"], torch.from_numpy(gold["model_outputs"]))
+    assert rms < 1e-4 and rel < 1e-5, (rms, rel)
+
+
+def test_vits_default_size_single_utterance(gpu):
+    """Full VitsArgs defaults (512-channel decoder), B=1 without x_lengths (the Synthesizer call pattern)."""
+    torch.set_num_threads(8)
+    sd = W.make_vits_state({}, seed=5)
+    x = torch.randint(0, 100, (1, 17), generator=torch.Generator().manual_seed(3))
+    dur = (2 + (torch.arange(17) % 3)).float().view(1, 1, 17)
+    noise_z = torch.randn(1, 192, int(dur.sum()), generator=torch.Generator().manual_seed(4))
+    want = O.vits_inference(sd, x, None, {}, noise_z=noise_z, durations=dur)
+    m = _model({}, sd, gpu)
+    out = m.inference(x.to(gpu), {"durations": dur.to(gpu), "noise_z": noise_z.to(gpu)})
+    _compare(out, want, 1)

@@ -169,21 +169,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
 
     // ---- epilogue --------------------------------------------------------------------------
     const float *omask = a.out_mask ? a.out_mask + (long)b * a.t_out : nullptr;
-    if (a.mode == TTSAMD_CONV_GATE) {
+    const float *rbias = a.row_bias ? a.row_bias + (long)b * a.c_out : nullptr;
+    if (a.mode == TTSAMD_CONV_GATE || a.mode == TTSAMD_CONV_COUPLE_AFFINE) {
         if constexpr (MI == 2) {
             const long pair = (long)blockIdx.y * WM + wm;
+            const bool gate = (a.mode == TTSAMD_CONV_GATE);
+            const int nvalid = gate ? a.c_out / 2 : a.split_row;  // output channels
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int t = t0 + wn * (32 * NI) + ni * 32 + j;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const long prow = pair * 64 + i;  // packed row of the tanh half
-                    if (prow + 32 < a.c_out && t < a.t_out) {
-                        float vt = acc[0][ni][r], vs = acc[1][ni][r];
-                        if (a.bias) { vt += a.bias[prow]; vs += a.bias[prow + 32]; }
-                        const float g = tanhf(vt) * (1.f / (1.f + expf(-vs)));
-                        a.y[(long)b * a.y_bstride + (pair * 32 + i) * a.y_rstride + t] = g;
+                    const long prow = pair * 64 + i;  // packed row of the first (tanh / t) half
+                    const long oc = pair * 32 + i;    // output channel
+                    if (prow + 32 < a.c_out && oc < nvalid && t < a.t_out) {
+                        float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
+                        if (a.bias) { v0 += a.bias[prow]; v1 += a.bias[prow + 32]; }
+                        if (rbias) { v0 += rbias[prow]; v1 += rbias[prow + 32]; }
+                        float o;
+                        if (gate) {
+                            o = tanhf(v0) * (1.f / (1.f + expf(-v1)));
+                        } else {
+                            const float m = omask ? omask[t] : 1.f;
+                            o = (a.res[(long)b * a.res_bstride + oc * a.res_rstride + t] - v0) * expf(-v1) * m;
+                        }
+                        a.y[(long)b * a.y_bstride + oc * a.y_rstride + t] = o;
                     }
                 }
             }
@@ -202,6 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
                 if (row >= a.c_out || t >= a.t_out) continue;
                 float v = acc[mi][ni][r];
                 if (a.bias) v += a.bias[row];
+                if (rbias) v += rbias[row];
                 if (a.out_act == TTSAMD_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (a.out_act == TTSAMD_ACT_TANH) v = tanhf(v);
                 if (a.mode == TTSAMD_CONV_SHUFFLE) {
@@ -217,6 +229,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
                     v = v * m;
                     v = (a.res[(long)b * a.res_bstride + row * a.res_rstride + t] - v) * m;
                     a.y[(long)b * a.y_bstride + row * a.y_rstride + t] = v;
+                    continue;
+                }
+                if (a.mode == TTSAMD_CONV_RES_SKIP) {
+                    if (row < a.split_row) {
+                        v = a.res[(long)b * a.res_bstride + row * a.res_rstride + t] + v;
+                        if (omask) v *= omask[t];
+                        a.y[(long)b * a.y_bstride + row * a.y_rstride + t] = v;
+                    } else {
+                        const long r2 = row - a.split_row;
+                        if (a.accum) v = a.accum[(long)b * a.accum_bstride + r2 * a.accum_rstride + t] + v;
+                        a.y2[(long)b * a.y2_bstride + r2 * a.y2_rstride + t] = v;
+                    }
                     continue;
                 }
                 if (a.res) v += a.res[(long)b * a.res_bstride + row * a.res_rstride + t];
@@ -253,7 +277,7 @@ template <int K, int D>
 int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     const int mtiles = (a.c_out + 31) / 32;
-    if (a.mode == TTSAMD_CONV_GATE) {
+    if (a.mode == TTSAMD_CONV_GATE || a.mode == TTSAMD_CONV_COUPLE_AFFINE) {
         if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2>(a, st);
         return conv1d_launch_cfg<K, D, 2, 2, 1, 4>(a, st);
     }

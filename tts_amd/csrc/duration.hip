@@ -1,0 +1,381 @@
+// Text-side small kernels of the VITS / Glow-TTS inference path: embedding, sequence masks, the
+// stochastic duration predictor's flow tails (rational-quadratic spline inverse), durations ->
+// cumulative frame offsets, generate_path and the prior expansion (declarations + reference
+// citations: include/tts_amd.h).  All HBM/latency-bound: lanes run along time (the contiguous axis
+// of the channels-first layout), one pass over each tensor, no reshaping into GEMMs.
+#include "common.h"
+
+namespace ttsamd {
+
+constexpr int kTxtThreads = 256;
+
+// ---- embedding ------------------------------------------------------------------------------
+__global__ void embed_kernel(float *__restrict__ y, const long *__restrict__ tokens, const float *__restrict__ emb,
+                             const float *__restrict__ mask, float scale, int C, int T, int V)
+{
+    const int b = blockIdx.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    long tok = tokens[(long)b * T + t];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    const float m = mask ? mask[(long)b * T + t] : 1.f;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        float v = emb[tok * C + c] * scale;
+        if (mask) v *= m;
+        y[((long)b * C + c) * T + t] = v;
+    }
+}
+
+__global__ void sequence_mask_kernel(float *__restrict__ mask, const long *__restrict__ lengths, int T)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) mask[(long)b * T + t] = (t < lengths[b]) ? 1.f : 0.f;
+}
+
+// ---- ConvFlow head --------------------------------------------------------------------------
+__global__ void convflow_pre_kernel(float *__restrict__ h, const float *__restrict__ z, int z_ch,
+                                    const float *__restrict__ w, const float *__restrict__ bias,
+                                    const float *__restrict__ g, int C, int T)
+{
+    const int b = blockIdx.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float x0 = z[((long)b * 2 + z_ch) * T + t];
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        const long o = ((long)b * C + c) * T + t;
+        float v = w[c] * x0;
+        if (bias) v += bias[c];
+        if (g) v += g[o];
+        h[o] = v;
+    }
+}
+
+// ---- rational-quadratic spline, inverse direction, linear tails --------------------------------
+// Follows vits/transforms.py:50-184 operation by operation (fp32, no contraction).
+constexpr int kMaxBins = 16;
+constexpr float kMinBinWidth = 1e-3f, kMinBinHeight = 1e-3f, kMinDerivative = 1e-3f;
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// knots[0..nb] from unnormalised params (softmax -> min width -> cumsum -> affine to [-B, B])
+__device__ __forceinline__ void spline_knots(float *knots, float *sizes, const float *u, int nb, float min_size,
+                                             float lo, float hi)
+{
+    float mx = u[0];
+    for (int k = 1; k < nb; ++k) mx = fmaxf(mx, u[k]);
+    float e[kMaxBins];
+    float sum = 0.f;
+    for (int k = 0; k < nb; ++k) {
+        e[k] = expf(u[k] - mx);
+        sum += e[k];
+    }
+    const float keep = (float)(1.0 - (double)min_size * nb);  // python double, then fp32 multiply
+    float cum = 0.f;
+    knots[0] = lo;
+    for (int k = 0; k < nb; ++k) {
+        const float wk = min_size + keep * (e[k] / sum);
+        cum += wk;
+        knots[k + 1] = (hi - lo) * cum + lo;
+    }
+    knots[nb] = hi;
+    for (int k = 0; k < nb; ++k) sizes[k] = knots[k + 1] - knots[k];
+}
+
+__global__ void convflow_spline_reverse_kernel(float *__restrict__ z_out, const float *__restrict__ z_in,
+                                               const float *__restrict__ h, const float *__restrict__ mask,
+                                               int T, int nb, float sqrt_filter, float tail)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float m = mask ? mask[(long)b * T + t] : 1.f;
+    const float x0 = z_in[((long)b * 2 + 1) * T + t];
+    const float x1 = z_in[((long)b * 2 + 0) * T + t];
+    float outv = x1;
+    if (x1 >= -tail && x1 <= tail) {
+        const float *hp = h + (long)b * (3 * nb - 1) * T + t;
+        float uw[kMaxBins], uh[kMaxBins], cw[kMaxBins + 1], ch[kMaxBins + 1], wd[kMaxBins], ht[kMaxBins];
+        for (int k = 0; k < nb; ++k) {
+            uw[k] = hp[(long)k * T] / sqrt_filter;
+            uh[k] = hp[(long)(nb + k) * T] / sqrt_filter;
+        }
+        spline_knots(cw, wd, uw, nb, kMinBinWidth, -tail, tail);
+        spline_knots(ch, ht, uh, nb, kMinBinHeight, -tail, tail);
+        // searchsorted(cumheights, x): count of knots <= x (last knot + 1e-6), minus one
+        int bin = -1;
+        for (int k = 0; k <= nb; ++k) {
+            const float loc = (k == nb) ? ch[k] + 1e-6f : ch[k];
+            bin += (x1 >= loc) ? 1 : 0;
+        }
+        bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
+        const float edge = (float)log(exp(1.0 - (double)kMinDerivative) - 1.0);
+        const float ud0 = (bin == 0) ? edge : hp[(long)(2 * nb + bin - 1) * T];
+        const float ud1 = (bin == nb - 1) ? edge : hp[(long)(2 * nb + bin) * T];
+        const float d0 = kMinDerivative + softplus_f(ud0);
+        const float d1 = kMinDerivative + softplus_f(ud1);
+        const float in_cw = cw[bin], in_w = wd[bin], in_ch = ch[bin], in_h = ht[bin];
+        const float delta = in_h / in_w;
+        const float dx = x1 - in_ch;
+        const float s = d0 + d1 - 2.f * delta;
+        const float qa = dx * s + in_h * (delta - d0);
+        const float qb = in_h * d0 - dx * s;
+        const float qc = -delta * dx;
+        const float disc = qb * qb - 4.f * qa * qc;
+        const float root = (2.f * qc) / (-qb - sqrtf(disc));
+        outv = root * in_w + in_cw;
+    }
+    z_out[((long)b * 2 + 0) * T + t] = x0 * m;
+    z_out[((long)b * 2 + 1) * T + t] = outv * m;
+}
+
+__global__ void sdp_affine_reverse_kernel(float *__restrict__ z_out, const float *__restrict__ z_in,
+                                          const float *__restrict__ mm, const float *__restrict__ logs,
+                                          const float *__restrict__ mask, int T)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float m = mask ? mask[(long)b * T + t] : 1.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float zf = z_in[((long)b * 2 + (1 - c)) * T + t];
+        z_out[((long)b * 2 + c) * T + t] = (zf - mm[c]) * expf(-logs[c]) * m;
+    }
+}
+
+// ---- durations -> cumulative frame offsets -----------------------------------------------------
+__global__ __launch_bounds__(kTxtThreads) void durations_kernel(float *__restrict__ dur, int *__restrict__ cum,
+                                                                long *__restrict__ y_lengths,
+                                                                const float *__restrict__ logw,
+                                                                const float *__restrict__ dur_in,
+                                                                const float *__restrict__ mask, float length_scale,
+                                                                int glow, int T)
+{
+    __shared__ int part[kTxtThreads];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int per = (T + kTxtThreads - 1) / kTxtThreads;
+    const int lo = tid * per;
+    const int hi = min(T, lo + per);
+    int local = 0;
+    for (int t = lo; t < hi; ++t) {
+        const long o = (long)b * T + t;
+        float wc;
+        if (dur_in) {
+            wc = dur_in[o];
+        } else {
+            const float m = mask ? mask[o] : 1.f;
+            float w = expf(logw[o]);
+            if (glow) w = w - 1.f;
+            w = w * m * length_scale;
+            wc = ceilf(w);
+            if (glow) wc = fmaxf(wc, 1.f);
+        }
+        dur[o] = wc;
+        const float cl = fminf(fmaxf(wc, 0.f), 1048576.f);  // keep the int offsets finite for inf/NaN inputs
+        local += (int)cl;
+    }
+    part[tid] = local;
+    __syncthreads();
+    // inclusive scan over the 256 partials (Hillis-Steele; tiny)
+    for (int off = 1; off < kTxtThreads; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = (tid > 0) ? part[tid - 1] : 0;
+    for (int t = lo; t < hi; ++t) {
+        const long o = (long)b * T + t;
+        const float cl = fminf(fmaxf(dur[o], 0.f), 1048576.f);
+        run += (int)cl;
+        cum[o] = run;
+    }
+    if (tid == kTxtThreads - 1) {
+        const int tot = part[kTxtThreads - 1];
+        y_lengths[b] = tot < 1 ? 1 : tot;
+    }
+}
+
+__global__ void generate_path_kernel(float *__restrict__ attn, const int *__restrict__ cum,
+                                     const float *__restrict__ x_mask, const long *__restrict__ y_lengths, int Tx,
+                                     int Ty)
+{
+    const int b = blockIdx.z;
+    const int x = blockIdx.y;
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= Ty) return;
+    const int hi = cum[(long)b * Tx + x];
+    const int lo = x > 0 ? cum[(long)b * Tx + x - 1] : 0;
+    const float xm = x_mask ? x_mask[(long)b * Tx + x] : 1.f;
+    const float on = (y >= lo && y < hi && y < y_lengths[b]) ? xm : 0.f;
+    attn[((long)b * Tx + x) * Ty + y] = on;
+}
+
+__global__ __launch_bounds__(256) void expand_prior_kernel(
+    float *__restrict__ z_p, float *__restrict__ z_p2, float *__restrict__ m_p, float *__restrict__ logs_p,
+    float *__restrict__ y_mask, const float *__restrict__ m, const float *__restrict__ logs, long stats_bstride,
+    const float *__restrict__ noise, const int *__restrict__ cum, const float *__restrict__ x_mask,
+    const long *__restrict__ y_lengths, float noise_scale, int mask_out, int C, int Tx, int Ty)
+{
+    const int b = blockIdx.y;
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    const int grp = threadIdx.y;
+    if (y >= Ty) return;
+    const int *cb = cum + (long)b * Tx;
+    // first x with cum[x] > y
+    int lo = 0, hi = Tx;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cb[mid] > y) hi = mid; else lo = mid + 1;
+    }
+    const int x = lo;
+    const bool in_len = y < y_lengths[b];
+    const bool valid = in_len && x < Tx && (!x_mask || x_mask[(long)b * Tx + x] != 0.f);
+    const float ym = in_len ? 1.f : 0.f;
+    if (grp == 0 && y_mask) y_mask[(long)b * Ty + y] = ym;
+    for (int c = grp; c < C; c += 4) {
+        const long src = (long)b * stats_bstride + (long)c * Tx + x;
+        const long dst = ((long)b * C + c) * Ty + y;
+        const float mv = valid ? m[src] : 0.f;
+        const float lv = (valid && logs) ? logs[src] : 0.f;
+        float z = mv;
+        if (noise) z = mv + noise[dst] * expf(lv) * noise_scale;
+        if (mask_out) z *= ym;
+        if (m_p) m_p[dst] = mv;
+        if (logs_p) logs_p[dst] = lv;
+        z_p[dst] = z;
+        if (z_p2) z_p2[dst] = z;
+    }
+}
+
+__global__ void scale_kernel(float *__restrict__ y, const float *__restrict__ x, float s, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
+}
+
+}  // namespace ttsamd
+using namespace ttsamd;
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int ttsamd_embed(float *y, const int64_t *tokens, const float *emb, const float *mask, float scale,
+                            int batch, int c, int t, int vocab, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && tokens && emb && batch >= 0 && c > 0 && t >= 0 && vocab > 0, "embed: bad args");
+    if (batch == 0 || t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "embed: batch > 65535");
+    hipLaunchKernelGGL(embed_kernel, dim3(cdiv(t, 64), min(c, 16), batch), dim3(64), 0, as_stream(stream), y,
+                       reinterpret_cast<const long *>(tokens), emb, mask, scale, c, t, vocab);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_sequence_mask(float *mask, const int64_t *lengths, int batch, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(mask && lengths && batch >= 0 && t >= 0, "sequence_mask: bad args");
+    if (batch == 0 || t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "sequence_mask: batch > 65535");
+    hipLaunchKernelGGL(sequence_mask_kernel, dim3(cdiv(t, kTxtThreads), batch), dim3(kTxtThreads), 0,
+                       as_stream(stream), mask, reinterpret_cast<const long *>(lengths), t);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_convflow_pre(float *h, const float *z, int z_ch, const float *w, const float *bias,
+                                   const float *g, int batch, int c, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(h && z && w && (z_ch == 0 || z_ch == 1) && batch >= 0 && c > 0 && t >= 0, "convflow_pre: bad args");
+    if (batch == 0 || t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "convflow_pre: batch > 65535");
+    hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(t, 64), min(c, 16), batch), dim3(64), 0, as_stream(stream), h, z,
+                       z_ch, w, bias, g, c, t);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_convflow_spline_reverse(float *z_out, const float *z_in, const float *h, const float *mask,
+                                              int batch, int t, int num_bins, float filter_channels,
+                                              float tail_bound, void *stream)
+{
+    TTSAMD_CHECK_ARG(z_out && z_in && h && batch >= 0 && t >= 0 && filter_channels > 0 && tail_bound > 0,
+                     "convflow_spline_reverse: bad args");
+    TTSAMD_CHECK_ARG(z_out != z_in, "convflow_spline_reverse: in-place not allowed (channel flip)");
+    if (num_bins < 2 || num_bins > kMaxBins) {
+        set_error("convflow_spline_reverse: num_bins=%d outside [2,%d]", num_bins, kMaxBins);
+        return TTSAMD_ERR_UNSUPPORTED;
+    }
+    if (batch == 0 || t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "convflow_spline_reverse: batch > 65535");
+    hipLaunchKernelGGL(convflow_spline_reverse_kernel, dim3(cdiv(t, 64), batch), dim3(64), 0, as_stream(stream), z_out,
+                       z_in, h, mask, t, num_bins, sqrtf(filter_channels), tail_bound);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_sdp_affine_reverse(float *z_out, const float *z_in, const float *m, const float *logs,
+                                         const float *mask, int batch, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(z_out && z_in && m && logs && batch >= 0 && t >= 0, "sdp_affine_reverse: bad args");
+    TTSAMD_CHECK_ARG(z_out != z_in, "sdp_affine_reverse: in-place not allowed (channel flip)");
+    if (batch == 0 || t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "sdp_affine_reverse: batch > 65535");
+    hipLaunchKernelGGL(sdp_affine_reverse_kernel, dim3(cdiv(t, kTxtThreads), batch), dim3(kTxtThreads), 0,
+                       as_stream(stream), z_out, z_in, m, logs, mask, t);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_durations(float *durations, int32_t *cum, int64_t *y_lengths, const float *logw,
+                                const float *durations_in, const float *mask, float length_scale, int glow,
+                                int batch, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(durations && cum && y_lengths && (logw || durations_in) && batch >= 0 && t > 0,
+                     "durations: bad args");
+    if (batch == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(durations_kernel, dim3(batch), dim3(kTxtThreads), 0, as_stream(stream), durations, cum,
+                       reinterpret_cast<long *>(y_lengths), logw, durations_in, mask, length_scale, glow, t);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_generate_path(float *attn, const int32_t *cum, const float *x_mask, const int64_t *y_lengths,
+                                    int batch, int t_x, int t_y, void *stream)
+{
+    TTSAMD_CHECK_ARG(attn && cum && y_lengths && batch >= 0 && t_x >= 0 && t_y >= 0, "generate_path: bad args");
+    if (batch == 0 || t_x == 0 || t_y == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535 && t_x <= 65535, "generate_path: batch / t_x > 65535");
+    hipLaunchKernelGGL(generate_path_kernel, dim3(cdiv(t_y, kTxtThreads), t_x, batch), dim3(kTxtThreads), 0,
+                       as_stream(stream), attn, cum, x_mask, reinterpret_cast<const long *>(y_lengths), t_x, t_y);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_expand_prior(float *z_p, float *z_p2, float *m_p, float *logs_p, float *y_mask, const float *m,
+                                   const float *logs, int64_t stats_bstride, const float *noise, const int32_t *cum,
+                                   const float *x_mask, const int64_t *y_lengths, float noise_scale, int mask_out,
+                                   int batch, int c, int t_x, int t_y, void *stream)
+{
+    TTSAMD_CHECK_ARG(z_p && m && cum && y_lengths && batch >= 0 && c > 0 && t_x > 0 && t_y >= 0,
+                     "expand_prior: bad args");
+    if (batch == 0 || t_y == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "expand_prior: batch > 65535");
+    hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(t_y, 64), batch), dim3(64, 4), 0, as_stream(stream), z_p, z_p2,
+                       m_p, logs_p, y_mask, m, logs, (long)stats_bstride, noise, cum, x_mask,
+                       reinterpret_cast<const long *>(y_lengths),
+                       noise_scale, mask_out, c, t_x, t_y);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_scale(float *y, const float *x, float s, int64_t n, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && x && n >= 0, "scale: bad args");
+    if (n == 0) return TTSAMD_OK;
+    const long blocks = (n + kTxtThreads - 1) / kTxtThreads;
+    hipLaunchKernelGGL(scale_kernel, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(kTxtThreads), 0, as_stream(stream),
+                       y, x, s, (long)n);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}

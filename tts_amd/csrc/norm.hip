@@ -1,0 +1,117 @@
+// Channel LayerNorm on channels-first [B, C, T] tensors with fused depthwise-conv prologue,
+// residual adds, activation and masking (see include/tts_amd.h: ttsamd_channel_norm).
+//
+// Replaces generic/normalization.py:5-53 (LayerNorm / LayerNorm2) and the per-layer chain of
+// DilatedDepthSeparableConv (vits/stochastic_duration_predictor.py:46-63).
+//
+// HBM/latency-bound.  Layout decision: the normalised axis (C) is the STRIDED one, so lanes run along
+// time (coalesced 256-byte row segments per wavefront) and each workgroup is 64 time columns x 4 channel
+// groups; a thread keeps its C/4 channel values in registers between the statistics passes (the tensor
+// is read exactly once), partial sums meet in LDS in a fixed order (deterministic).
+#include "common.h"
+
+namespace ttsamd {
+
+template <int NC, int kNormGroups>  // channels per thread, channel groups per block (C <= NC * kNormGroups)
+__global__ __launch_bounds__(64 * kNormGroups) void channel_norm_kernel(const ttsamd_norm_args a)
+{
+    __shared__ float red[kNormGroups][64];
+    const int lane = threadIdx.x;       // time lane
+    const int grp = threadIdx.y;        // channel group: channels grp, grp+4, ...
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + lane;
+    const bool tv = t < a.t;
+    const float *xb = a.x + (long)b * a.x_bstride;
+    const float *im = a.in_mask ? a.in_mask + (long)b * a.t : nullptr;
+
+    float v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = grp + i * kNormGroups;
+        float u = 0.f;
+        if (tv && c < a.c) {
+            if (a.dw_w) {
+                u = a.dw_bias ? a.dw_bias[c] : 0.f;
+                const int half = (a.dw_kernel - 1) / 2;
+                for (int k = 0; k < a.dw_kernel; ++k) {
+                    const int tt = t + (k - half) * a.dw_dilation;
+                    if (tt >= 0 && tt < a.t) {
+                        float xv = xb[(long)c * a.x_rstride + tt];
+                        if (im) xv *= im[tt];
+                        u += a.dw_w[c * a.dw_kernel + k] * xv;
+                    }
+                }
+            } else {
+                u = xb[(long)c * a.x_rstride + t];
+            }
+            if (a.pre_res) u += a.pre_res[(long)b * a.pre_bstride + (long)c * a.pre_rstride + t];
+            s += u;
+        }
+        v[i] = u;
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    float tot = red[0][lane];
+#pragma unroll
+    for (int g2 = 1; g2 < kNormGroups; ++g2) tot += red[g2][lane];
+    const float mean = tot / (float)a.c;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = grp + i * kNormGroups;
+        if (tv && c < a.c) {
+            const float d = v[i] - mean;
+            q += d * d;
+        }
+    }
+    red[grp][lane] = q;
+    __syncthreads();
+    float tot2 = red[0][lane];
+#pragma unroll
+    for (int g2 = 1; g2 < kNormGroups; ++g2) tot2 += red[g2][lane];
+    const float var = tot2 / (float)a.c;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    const float om = (a.out_mask && tv) ? a.out_mask[(long)b * a.t + t] : 1.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = grp + i * kNormGroups;
+        if (tv && c < a.c) {
+            float o = (v[i] - mean) * rstd * a.gamma[c] + a.beta[c];
+            if (a.act == TTSAMD_ACT_RELU) o = fmaxf(o, 0.f);
+            else if (a.act == TTSAMD_ACT_GELU) o = o * 0.5f * (1.0f + erff(o * 0.70710678118654752440f));
+            if (a.post_res) o = a.post_res[(long)b * a.post_bstride + (long)c * a.post_rstride + t] + o;
+            if (a.out_mask) o *= om;
+            a.y[(long)b * a.y_bstride + (long)c * a.y_rstride + t] = o;
+        }
+    }
+}
+
+}  // namespace ttsamd
+using namespace ttsamd;
+
+extern "C" int ttsamd_channel_norm(const ttsamd_norm_args *args, void *stream)
+{
+    TTSAMD_CHECK_ARG(args, "channel_norm: NULL args");
+    const ttsamd_norm_args &a = *args;
+    TTSAMD_CHECK_ARG(a.x && a.y && a.gamma && a.beta, "channel_norm: NULL tensor");
+    TTSAMD_CHECK_ARG(a.c > 0 && a.t >= 0 && a.batch >= 0, "channel_norm: bad shape");
+    TTSAMD_CHECK_ARG(!a.dw_w || (a.dw_kernel > 0 && (a.dw_kernel & 1) && a.dw_dilation > 0),
+                     "channel_norm: depthwise prologue needs an odd kernel and dilation > 0");
+    TTSAMD_CHECK_ARG(a.act == TTSAMD_ACT_NONE || a.act == TTSAMD_ACT_RELU || a.act == TTSAMD_ACT_GELU,
+                     "channel_norm: bad act %d", a.act);
+    if (a.c > 512) {
+        set_error("channel_norm: C=%d > 512 unsupported", a.c);
+        return TTSAMD_ERR_UNSUPPORTED;
+    }
+    if (a.batch == 0 || a.t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(a.batch <= 65535, "channel_norm: batch > 65535");
+    const dim3 grid((a.t + 63) / 64, a.batch);
+    hipStream_t st = as_stream(stream);
+    if (a.c <= 192) hipLaunchKernelGGL((channel_norm_kernel<48, 4>), grid, dim3(64, 4), 0, st, a);
+    else if (a.c <= 256) hipLaunchKernelGGL((channel_norm_kernel<64, 4>), grid, dim3(64, 4), 0, st, a);
+    else hipLaunchKernelGGL((channel_norm_kernel<64, 8>), grid, dim3(64, 8), 0, st, a);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}

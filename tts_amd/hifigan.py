@@ -105,7 +105,8 @@ class HifiganGenerator:
 
     # ---- forward (hifigan_generator.py:236-265) ----------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, g=None):
+    def forward(self, x, g=None, in_mask=None):
+        """`in_mask` [B,T] (optional) multiplies x inside conv_pre's load: VITS feeds `z * y_mask` (vits.py:1161)."""
         if self._packed is None:
             raise _lib.TtsAmdError("HifiganGenerator: no weights loaded / not moved to the GPU")
         _lib.require_gpu(x, "x")
@@ -117,13 +118,13 @@ class HifiganGenerator:
         ch = self.upsample_initial_channel
         o = new(ch, T)
         if g is not None and "cond_layer" in P:
-            # o = conv_pre(x) + cond_layer(g): g is [B, C, 1] -> broadcast over time via a 1x1 conv on expanded g
+            # o = conv_pre(x) + cond_layer(g): g is [B, C, 1]; its 1x1 conv is a per-(b, channel) offset that
+            # rides in conv_pre's epilogue (hifigan_generator.py:250-251)
             gc = new(ch, 1)
             ops.conv1d(P["cond_layer"], g.contiguous().float(), gc)
-            ops.conv1d(P["conv_pre"], x, o)
-            o.add_(gc)  # TODO(hip): fold the per-(b,c) conditioning offset into conv_pre's bias
+            ops.conv1d(P["conv_pre"], x, o, in_mask=in_mask, row_bias=gc.reshape(B, ch))
         else:
-            ops.conv1d(P["conv_pre"], x, o)
+            ops.conv1d(P["conv_pre"], x, o, in_mask=in_mask)
         nk = self.num_kernels
         for i, u in enumerate(self.upsample_factors):
             ch //= 2

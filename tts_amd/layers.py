@@ -1,0 +1,303 @@
+"""Host-side layer drivers of the VITS / Glow-TTS acoustic models over the HIP kernels.
+
+Each class mirrors one reference `nn.Module` (same parameter names read from a reference-layout
+`state_dict`, same forward semantics) but owns no arithmetic: `__init__` folds/re-orders/packs the
+weights once (load-time glue), `__call__` is a fixed sequence of kernel launches through the C ABI
+(tts_amd.ops).  torch tensors are device buffers only.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import (ACT_GELU, ACT_NONE, ACT_RELU, CONV_COUPLE, CONV_COUPLE_AFFINE, CONV_GATE, CONV_RES_SKIP,
+                  PackedConv, fold_weight_norm)
+
+
+def _dev(t, device):
+    return t.detach().to(device, torch.float32).contiguous()
+
+
+def _new(like, c=None, t=None):
+    B, C, T = like.shape
+    return torch.empty((B, C if c is None else c, T if t is None else t), dtype=torch.float32, device=like.device)
+
+
+class _Norm:
+    """gamma/beta of LayerNorm ([1,C,1], eps 1e-4, normalization.py:5-28) or LayerNorm2 ([C], eps 1e-5, :31-53)."""
+
+    def __init__(self, sd, name, device, eps):
+        self.gamma = _dev(sd[name + ".gamma"].reshape(-1), device)
+        self.beta = _dev(sd[name + ".beta"].reshape(-1), device)
+        self.eps = eps
+
+
+# ------------------------------------------------------------------------------------------------
+# relative-position transformer — TTS/tts/layers/glow_tts/transformer.py:322-432
+# ------------------------------------------------------------------------------------------------
+class RelativePositionTransformer:
+    def __init__(self, sd, p, device, num_layers, num_heads, kernel_size, rel_attn_window_size, layer_norm_type):
+        self.num_layers, self.num_heads, self.window = num_layers, num_heads, rel_attn_window_size
+        eps = 1e-5 if str(layer_norm_type) == "2" else 1e-4
+        self.layers = []
+        for i in range(num_layers):
+            a = p + "attn_layers.%d." % i
+            L = {}
+            wq, wk, wv = (fold_weight_norm(sd, a + n) for n in ("conv_q", "conv_k", "conv_v"))
+            bq, bk, bv = (sd[a + n + ".bias"] for n in ("conv_q", "conv_k", "conv_v"))
+            # one fused projection launch: rows q | k | v  (transformer.py:106-110)
+            L["qkv"] = PackedConv(torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0), device)
+            L["o"] = PackedConv(fold_weight_norm(sd, a + "conv_o"), sd[a + "conv_o.bias"], device)
+            if rel_attn_window_size is not None:
+                L["emb_k"] = _dev(sd[a + "emb_rel_k"][0], device)   # heads_share=True: [1, 2w+1, dk]
+                L["emb_v"] = _dev(sd[a + "emb_rel_v"][0], device)
+            L["n1"] = _Norm(sd, p + "norm_layers_1.%d" % i, device, eps)
+            f = p + "ffn_layers.%d." % i
+            L["f1"] = PackedConv(fold_weight_norm(sd, f + "conv_1"), sd[f + "conv_1.bias"], device,
+                                 pad_left=(kernel_size - 1) // 2)
+            L["f2"] = PackedConv(fold_weight_norm(sd, f + "conv_2"), sd[f + "conv_2.bias"], device,
+                                 pad_left=(kernel_size - 1) // 2)
+            L["n2"] = _Norm(sd, p + "norm_layers_2.%d" % i, device, eps)
+            self.layers.append(L)
+        self.proj = None
+        if (p + "proj.weight") in sd:  # only when out_channels != hidden (transformer.py:398-399,426-427)
+            self.proj = PackedConv(sd[p + "proj.weight"], sd.get(p + "proj.bias"), device)
+        if kernel_size % 2 == 0:
+            raise ops._lib.TtsAmdError("FFN kernel_size must be odd for the HIP conv path")
+
+    def __call__(self, x, mask):
+        """x [B,H,T] already multiplied by mask, mask [B,T] -> [B,H_out,T] (masked).  transformer.py:409-432.
+        Padded columns are zeroed after every norm (the reference zeroes them at the next layer's entry
+        and at the end; valid columns are identical)."""
+        B, H, T = x.shape
+        for i, L in enumerate(self.layers):
+            qkv = _new(x, 3 * H)
+            ops.conv1d(L["qkv"], x, qkv)
+            att = _new(x)
+            ops.rel_attention(qkv, att, mask, self.num_heads, L.get("emb_k"), L.get("emb_v"), self.window or 0)
+            xy = _new(x)
+            ops.conv1d(L["o"], att, xy, res=x)                                  # x + attn(x)
+            x1 = ops.channel_norm(xy, _new(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, out_mask=mask)
+            hid = _new(x, L["f1"].c_out)
+            ops.conv1d(L["f1"], x1, hid, out_act=ACT_RELU, out_mask=mask)       # relu(conv_1(x*mask)) * mask
+            last = (i + 1) == self.num_layers
+            if last and self.proj is not None:
+                xo = _new(x, self.proj.c_out)
+                ops.conv1d(self.proj, x1, xo)
+                y = _new(xo)
+                ops.conv1d(L["f2"], hid, y, out_mask=mask)
+                x = ops.channel_norm(y, _new(xo), L["n2"].gamma, L["n2"].beta, L["n2"].eps, pre_res=xo, out_mask=mask)
+            else:
+                y = _new(x)
+                ops.conv1d(L["f2"], hid, y, res=x1, out_mask=mask)              # x + ffn(x) (x1 is masked)
+                x = ops.channel_norm(y, _new(x), L["n2"].gamma, L["n2"].beta, L["n2"].eps, out_mask=mask)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------
+# VITS text encoder — TTS/tts/layers/vits/networks.py:29-100
+# ------------------------------------------------------------------------------------------------
+class TextEncoder:
+    def __init__(self, sd, p, device, hidden, num_layers, num_heads, kernel_size):
+        self.hidden = hidden
+        self.emb = _dev(sd[p + "emb.weight"], device)
+        self.encoder = RelativePositionTransformer(sd, p + "encoder.", device, num_layers, num_heads, kernel_size, 4, "2")
+        self.proj = PackedConv(sd[p + "proj.weight"], sd[p + "proj.bias"], device)
+
+    def __call__(self, tokens, x_mask):
+        """tokens int64 [B,T], x_mask [B,T] -> x [B,H,T], stats [B,2H,T] (m | logs), networks.py:79-100."""
+        B, T = tokens.shape
+        x = torch.empty((B, self.hidden, T), dtype=torch.float32, device=tokens.device)
+        ops.embed(tokens, self.emb, x_mask, math.sqrt(self.hidden), x)
+        x = self.encoder(x, x_mask)
+        stats = _new(x, 2 * self.hidden)
+        ops.conv1d(self.proj, x, stats, out_mask=x_mask)
+        return x, stats
+
+
+# ------------------------------------------------------------------------------------------------
+# DilatedDepthSeparableConv — TTS/tts/layers/vits/stochastic_duration_predictor.py:11-63
+# ------------------------------------------------------------------------------------------------
+class DDSConv:
+    def __init__(self, sd, p, device, channels, kernel_size, num_layers):
+        self.layers = []
+        for i in range(num_layers):
+            self.layers.append(dict(
+                dw_w=_dev(sd[p + "convs_sep.%d.weight" % i].reshape(channels, kernel_size), device),
+                dw_b=_dev(sd[p + "convs_sep.%d.bias" % i], device), dil=kernel_size ** i,
+                pw=PackedConv(sd[p + "convs_1x1.%d.weight" % i], sd[p + "convs_1x1.%d.bias" % i], device),
+                n1=_Norm(sd, p + "norms_1.%d" % i, device, 1e-5), n2=_Norm(sd, p + "norms_2.%d" % i, device, 1e-5)))
+
+    def __call__(self, x, mask):
+        """x [B,C,T] (conditioning already added) -> DDSConv(x) * mask."""
+        n = len(self.layers)
+        for i, L in enumerate(self.layers):
+            y = ops.channel_norm(x, _new(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, dw_w=L["dw_w"], dw_bias=L["dw_b"],
+                                 dw_dilation=L["dil"], in_mask=mask, act=ACT_GELU)
+            y2 = _new(x)
+            ops.conv1d(L["pw"], y, y2)
+            x = ops.channel_norm(y2, _new(x), L["n2"].gamma, L["n2"].beta, L["n2"].eps, act=ACT_GELU, post_res=x,
+                                 out_mask=mask if i == n - 1 else None)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------
+# StochasticDurationPredictor (reverse) — stochastic_duration_predictor.py:150-294
+# ------------------------------------------------------------------------------------------------
+class StochasticDurationPredictor:
+    def __init__(self, sd, p, device, in_channels, hidden, kernel_size, num_flows=4, cond_channels=0):
+        self.hidden, self.num_flows = hidden, num_flows
+        self.pre = PackedConv(sd[p + "pre.weight"], sd[p + "pre.bias"], device)
+        self.convs = DDSConv(sd, p + "convs.", device, hidden, kernel_size, 3)
+        self.proj = PackedConv(sd[p + "proj.weight"], sd[p + "proj.bias"], device)
+        self.cond = None
+        if cond_channels and (p + "cond.weight") in sd:
+            self.cond = PackedConv(sd[p + "cond.weight"], sd[p + "cond.bias"], device)
+        self.ea_m = _dev(sd[p + "flows.0.translation"].reshape(-1), device)
+        self.ea_logs = _dev(sd[p + "flows.0.log_scale"].reshape(-1), device)
+        self.flows = {}
+        for i in range(1, num_flows + 1):
+            q = p + "flows.%d." % i
+            self.flows[i] = dict(
+                pre_w=_dev(sd[q + "pre.weight"].reshape(-1), device), pre_b=_dev(sd[q + "pre.bias"], device),
+                convs=DDSConv(sd, q + "convs.", device, hidden, kernel_size, 3),
+                proj=PackedConv(sd[q + "proj.weight"], sd[q + "proj.bias"], device))
+            self.num_bins = (sd[q + "proj.weight"].shape[0] + 1) // 3
+
+    def __call__(self, x, mask, noise, noise_scale=1.0, g=None):
+        """x [B,C,T] (text-encoder hidden), mask [B,T], noise [B,2,T] -> logw [B,T] view of z[:,0]."""
+        h = _new(x, self.hidden)
+        row_bias = None
+        if g is not None and self.cond is not None:
+            gb = torch.empty((g.shape[0], self.hidden, 1), dtype=torch.float32, device=x.device)
+            ops.conv1d(self.cond, g.contiguous().float(), gb)
+            row_bias = gb.reshape(g.shape[0], self.hidden)
+        ops.conv1d(self.pre, x, h, row_bias=row_bias)
+        h = self.convs(h, mask)
+        cond = _new(h)
+        ops.conv1d(self.proj, h, cond, out_mask=mask)
+        order = list(reversed(range(self.num_flows + 1)))
+        order = order[:-2] + [order[-1]]           # drop the "useless" flow (:285-286)
+        z = ops.scale(noise, noise_scale) if noise_scale != 1.0 else noise.contiguous()
+        for i in order:
+            z_out = torch.empty_like(z)
+            if i == 0:
+                ops.sdp_affine_reverse(z_out, z, self.ea_m, self.ea_logs, mask)
+            else:
+                F_ = self.flows[i]
+                hh = _new(cond)
+                ops.convflow_pre(hh, z, 1, F_["pre_w"], F_["pre_b"], cond)   # pre(x0) + g, x0 = flip(z)[:,0] = z[:,1]
+                hh = F_["convs"](hh, mask)
+                par = _new(hh, F_["proj"].c_out)
+                ops.conv1d(F_["proj"], hh, par, out_mask=mask)
+                ops.convflow_spline_reverse(z_out, z, par, mask, self.num_bins, float(self.hidden), 5.0)
+            z = z_out
+        return z[:, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# DurationPredictor — TTS/tts/layers/glow_tts/duration_predictor.py:7-69
+# ------------------------------------------------------------------------------------------------
+class DurationPredictor:
+    def __init__(self, sd, p, device):
+        self.c1 = PackedConv(sd[p + "conv_1.weight"], sd[p + "conv_1.bias"], device)
+        self.c2 = PackedConv(sd[p + "conv_2.weight"], sd[p + "conv_2.bias"], device)
+        self.n1 = _Norm(sd, p + "norm_1", device, 1e-4)
+        self.n2 = _Norm(sd, p + "norm_2", device, 1e-4)
+        self.proj = PackedConv(sd[p + "proj.weight"], sd[p + "proj.bias"], device)
+
+    def __call__(self, x, mask):
+        """x [B,C,T] -> logw [B,T]   (conv -> relu -> LayerNorm twice, then 1x1; dropout is off in eval)."""
+        h = _new(x, self.c1.c_out)
+        ops.conv1d(self.c1, x, h, in_mask=mask, out_act=ACT_RELU)
+        h = ops.channel_norm(h, _new(h), self.n1.gamma, self.n1.beta, self.n1.eps)
+        h2 = _new(h, self.c2.c_out)
+        ops.conv1d(self.c2, h, h2, in_mask=mask, out_act=ACT_RELU)
+        h2 = ops.channel_norm(h2, _new(h2), self.n2.gamma, self.n2.beta, self.n2.eps)
+        o = _new(h2, 1)
+        ops.conv1d(self.proj, h2, o, in_mask=mask, out_mask=mask)
+        return o[:, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# WaveNet block — TTS/tts/layers/generic/wavenet.py:16-123
+# ------------------------------------------------------------------------------------------------
+class WN:
+    def __init__(self, sd, p, device, hidden, kernel_size, dilation_rate, num_layers, cond_channels=0):
+        self.hidden, self.num_layers = hidden, num_layers
+        self.in_layers, self.rs_layers = [], []
+        for i in range(num_layers):
+            w, b = ops.gate_permute(fold_weight_norm(sd, p + "in_layers.%d" % i), sd[p + "in_layers.%d.bias" % i], hidden)
+            self.in_layers.append(PackedConv(w, b, device, dilation=dilation_rate ** i))
+            self.rs_layers.append(PackedConv(fold_weight_norm(sd, p + "res_skip_layers.%d" % i),
+                                             sd[p + "res_skip_layers.%d.bias" % i], device))
+        self.cond = None
+        if cond_channels and (p + "cond_layer.bias") in sd:
+            self.cond_w = fold_weight_norm(sd, p + "cond_layer")
+            self.cond = PackedConv(self.cond_w, sd[p + "cond_layer.bias"], device)
+            idx = []
+            for a in range(hidden // 32):
+                idx += list(range(32 * a, 32 * a + 32)) + list(range(hidden + 32 * a, hidden + 32 * a + 32))
+            self.gate_idx = torch.tensor(idx, device=device)
+
+    def __call__(self, x, mask, out, g=None, out_kw=None):
+        """x [B,H,T] is updated IN PLACE layer by layer; `out` receives sum of skips * mask.
+        wavenet.py:92-116; the tanh*sigmoid gate (:6-13) lives in the in_layer conv's epilogue."""
+        H = self.hidden
+        gl = None
+        if g is not None and self.cond is not None:
+            gc = torch.empty((g.shape[0], self.cond.c_out, 1), dtype=torch.float32, device=x.device)
+            ops.conv1d(self.cond, g.contiguous().float(), gc)
+            gl = gc.reshape(g.shape[0], self.num_layers, 2 * H)[:, :, self.gate_idx].contiguous()
+        acts = _new(x)
+        for i in range(self.num_layers):
+            ops.conv1d(self.in_layers[i], x, acts, mode=CONV_GATE, row_bias=None if gl is None else gl[:, i].contiguous())
+            if i < self.num_layers - 1:
+                ops.conv1d(self.rs_layers[i], acts, x, mode=CONV_RES_SKIP, res=x, out_mask=mask, y2=out,
+                           accum=out if i > 0 else None, split_row=H)
+            else:
+                ops.conv1d(self.rs_layers[i], acts, out, accum=out if i > 0 else None, out_mask=mask)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# ResidualCouplingBlocks (reverse) — TTS/tts/layers/vits/networks.py:103-232
+# ------------------------------------------------------------------------------------------------
+class ResidualCouplingBlocks:
+    """The channel flip before every flow (networks.py:229-231) is folded into the weights: flows
+    that see a flipped tensor read their conditioning half through input-channel-reversed `pre`
+    weights and write the coupled half through output-row-reversed `post` weights, so the latent
+    stays in place in ONE buffer for the whole stack."""
+
+    def __init__(self, sd, p, device, channels, hidden, kernel_size, dilation_rate, num_layers, num_flows=4,
+                 cond_channels=0):
+        self.half, self.hidden, self.num_flows = channels // 2, hidden, num_flows
+        self.flows = []
+        for i in range(num_flows):
+            q = p + "flows.%d." % i
+            flipped = (num_flows - i) % 2 == 1     # number of flips applied before flow i runs (reverse order)
+            wpre, bpre = sd[q + "pre.weight"].float(), sd[q + "pre.bias"].float()
+            wpost, bpost = sd[q + "post.weight"].float(), sd[q + "post.bias"].float()
+            if wpost.shape[0] != self.half:
+                raise ops._lib.TtsAmdError("only mean_only=True coupling (VITS default) has a HIP path")
+            if flipped:
+                wpre = torch.flip(wpre, [1])
+                wpost, bpost = torch.flip(wpost, [0]), torch.flip(bpost, [0])
+            self.flows.append(dict(flipped=flipped, pre=PackedConv(wpre, bpre, device),
+                                   post=PackedConv(wpost, bpost, device),
+                                   wn=WN(sd, q + "enc.", device, hidden, kernel_size, dilation_rate, num_layers,
+                                         cond_channels)))
+
+    def __call__(self, z, mask, g=None):
+        """z [B,C,T] is transformed IN PLACE (reverse direction) and returned."""
+        half = self.half
+        h = _new(z, self.hidden)
+        out = _new(z, self.hidden)
+        for i in reversed(range(self.num_flows)):
+            F_ = self.flows[i]
+            src, dst = (half, 0) if F_["flipped"] else (0, half)
+            ops.conv1d(F_["pre"], z, h, c_in_offset=src, out_mask=mask)
+            F_["wn"](h, mask, out, g=g)
+            # x1 = (x1 - post(h) * mask) * mask   (mean_only: exp(-log_scale) == 1), in place on the other half
+            ops.conv1d(F_["post"], out, z, mode=CONV_COUPLE, res=z, res_row_offset=dst, y_row_offset=dst, out_mask=mask)
+        return z

@@ -11,8 +11,8 @@ import torch
 from . import _lib
 from ._lib import P, check, lib, stream_ptr
 
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 1, 2
-CONV_NORMAL, CONV_GATE, CONV_SHUFFLE, CONV_COUPLE = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 1, 2, 3
+CONV_NORMAL, CONV_GATE, CONV_SHUFFLE, CONV_COUPLE, CONV_RES_SKIP, CONV_COUPLE_AFFINE = 0, 1, 2, 3, 4, 5
 
 
 class Conv1dArgs(ctypes.Structure):
@@ -32,6 +32,8 @@ class Conv1dArgs(ctypes.Structure):
         ("accum", ctypes.c_void_p), ("accum_bstride", ctypes.c_int64), ("accum_rstride", ctypes.c_int64),
         ("out_mask", ctypes.c_void_p), ("out_div", ctypes.c_float),
         ("shuffle_u", ctypes.c_int32), ("shuffle_pad", ctypes.c_int32), ("shuffle_t_out", ctypes.c_int32),
+        ("y2", ctypes.c_void_p), ("y2_bstride", ctypes.c_int64), ("y2_rstride", ctypes.c_int64),
+        ("split_row", ctypes.c_int32), ("row_bias", ctypes.c_void_p),
     ]
 
 
@@ -64,7 +66,8 @@ class PackedConv:
 
 def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, in_slope=0.0, in_mask=None,
            mode=CONV_NORMAL, out_act=ACT_NONE, res=None, accum=None, out_mask=None, out_div=0.0,
-           y_row_offset=0, res_row_offset=0, accum_row_offset=0, shuffle_u=0, shuffle_pad=0):
+           y_row_offset=0, res_row_offset=0, accum_row_offset=0, shuffle_u=0, shuffle_pad=0, y2=None, split_row=0,
+           row_bias=None):
     """Launch one fused conv.  x [B, Cx, T_in] (uses channels c_in_offset : c_in_offset + c_in),
     y [B, Cy, T_y] written at rows y_row_offset + packed row (or per `mode`)."""
     B, Cx, T_in = x.shape
@@ -90,6 +93,9 @@ def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, 
         a.accum_bstride, a.accum_rstride = accum.shape[1] * accum.shape[2], accum.shape[2]
     a.out_mask, a.out_div = _dp(out_mask), out_div
     a.shuffle_u, a.shuffle_pad, a.shuffle_t_out = shuffle_u, shuffle_pad, T_y
+    if y2 is not None:
+        a.y2, a.y2_bstride, a.y2_rstride = y2.data_ptr(), y2.shape[1] * y2.shape[2], y2.shape[2]
+    a.split_row, a.row_bias = split_row, _dp(row_bias)
     check(lib().ttsamd_conv1d(ctypes.byref(a), stream_ptr()), "conv1d")
     return y
 
@@ -137,4 +143,144 @@ def replicate_pad(x, y, pad):
     rows = x.numel() // x.shape[-1]
     check(lib().ttsamd_replicate_pad(P(y), P(x), ctypes.c_int64(rows), x.shape[-1], pad, stream_ptr()),
           "replicate_pad")
+    return y
+
+
+class NormArgs(ctypes.Structure):
+    """Mirror of `ttsamd_norm_args` (include/tts_amd.h)."""
+
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("x_bstride", ctypes.c_int64), ("x_rstride", ctypes.c_int64),
+        ("c", ctypes.c_int32), ("t", ctypes.c_int32), ("batch", ctypes.c_int32),
+        ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float),
+        ("dw_w", ctypes.c_void_p), ("dw_bias", ctypes.c_void_p),
+        ("dw_kernel", ctypes.c_int32), ("dw_dilation", ctypes.c_int32),
+        ("in_mask", ctypes.c_void_p),
+        ("pre_res", ctypes.c_void_p), ("pre_bstride", ctypes.c_int64), ("pre_rstride", ctypes.c_int64),
+        ("act", ctypes.c_int32),
+        ("post_res", ctypes.c_void_p), ("post_bstride", ctypes.c_int64), ("post_rstride", ctypes.c_int64),
+        ("out_mask", ctypes.c_void_p),
+        ("y", ctypes.c_void_p), ("y_bstride", ctypes.c_int64), ("y_rstride", ctypes.c_int64),
+    ]
+
+
+def channel_norm(x, y, gamma, beta, eps, *, dw_w=None, dw_bias=None, dw_dilation=1, in_mask=None, pre_res=None,
+                 act=ACT_NONE, post_res=None, out_mask=None):
+    """y = [post_res +] act(LN_c([dwconv](x) [+ pre_res])) [* out_mask] on [B, C, T] (include/tts_amd.h)."""
+    B, C, T = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape
+    a = NormArgs()
+    a.x, a.x_bstride, a.x_rstride, a.c, a.t, a.batch = x.data_ptr(), C * T, T, C, T, B
+    a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    if dw_w is not None:
+        a.dw_w, a.dw_bias, a.dw_kernel, a.dw_dilation = dw_w.data_ptr(), _dp(dw_bias), dw_w.shape[-1], dw_dilation
+    a.in_mask = _dp(in_mask)
+    if pre_res is not None:
+        assert pre_res.shape == x.shape and pre_res.is_contiguous()
+        a.pre_res, a.pre_bstride, a.pre_rstride = pre_res.data_ptr(), C * T, T
+    a.act = act
+    if post_res is not None:
+        assert post_res.shape == x.shape and post_res.is_contiguous()
+        a.post_res, a.post_bstride, a.post_rstride = post_res.data_ptr(), C * T, T
+    a.out_mask = _dp(out_mask)
+    a.y, a.y_bstride, a.y_rstride = y.data_ptr(), C * T, T
+    check(lib().ttsamd_channel_norm(ctypes.byref(a), stream_ptr()), "channel_norm")
+    return y
+
+
+def rel_attention(qkv, out, mask, heads, emb_rel_k=None, emb_rel_v=None, window=0):
+    """qkv [B, 3*H*dk, T] (rows: q | k | v) -> out [B, H*dk, T] (include/tts_amd.h: ttsamd_rel_attention)."""
+    B, C3, T = qkv.shape
+    C = C3 // 3
+    dk = C // heads
+    assert qkv.is_contiguous() and out.is_contiguous() and out.shape == (B, C, T)
+    base = qkv.data_ptr()
+    check(lib().ttsamd_rel_attention(P(out), ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * C * T),
+                                     ctypes.c_void_p(base + 8 * C * T), ctypes.c_int64(C3 * T), P(mask),
+                                     P(emb_rel_k), P(emb_rel_v), window, B, heads, dk, T, stream_ptr()),
+          "rel_attention")
+    return out
+
+
+def embed(tokens, emb, mask, scale, y):
+    B, T = tokens.shape
+    V, C = emb.shape
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and y.shape == (B, C, T)
+    check(lib().ttsamd_embed(P(y), P(tokens), P(emb), P(mask), ctypes.c_float(scale), B, C, T, V, stream_ptr()), "embed")
+    return y
+
+
+def sequence_mask(lengths, t):
+    """helpers.py:43-57 on the device; returns float [B, t]."""
+    lengths = lengths.to(torch.int64).contiguous()
+    mask = torch.empty((lengths.shape[0], t), dtype=torch.float32, device=lengths.device)
+    check(lib().ttsamd_sequence_mask(P(mask), P(lengths), lengths.shape[0], t, stream_ptr()), "sequence_mask")
+    return mask
+
+
+def convflow_pre(h, z, z_ch, w, bias, g):
+    B, C, T = h.shape
+    check(lib().ttsamd_convflow_pre(P(h), P(z), z_ch, P(w), P(bias), P(g), B, C, T, stream_ptr()), "convflow_pre")
+    return h
+
+
+def convflow_spline_reverse(z_out, z_in, h, mask, num_bins, filter_channels, tail_bound):
+    B, _, T = z_in.shape
+    assert h.shape == (B, 3 * num_bins - 1, T) and h.is_contiguous()
+    check(lib().ttsamd_convflow_spline_reverse(P(z_out), P(z_in), P(h), P(mask), B, T, num_bins,
+                                               ctypes.c_float(filter_channels), ctypes.c_float(tail_bound),
+                                               stream_ptr()), "convflow_spline_reverse")
+    return z_out
+
+
+def sdp_affine_reverse(z_out, z_in, m, logs, mask):
+    B, _, T = z_in.shape
+    check(lib().ttsamd_sdp_affine_reverse(P(z_out), P(z_in), P(m), P(logs), P(mask), B, T, stream_ptr()),
+          "sdp_affine_reverse")
+    return z_out
+
+
+def durations(logw, mask, length_scale, glow=False, durations_in=None):
+    """-> (w_ceil float [B,T], cum int32 [B,T], y_lengths int64 [B]) (include/tts_amd.h: ttsamd_durations)."""
+    src = logw if logw is not None else durations_in
+    B, T = src.shape[0], src.shape[-1]
+    dev = src.device
+    dur = torch.empty((B, T), dtype=torch.float32, device=dev)
+    cum = torch.empty((B, T), dtype=torch.int32, device=dev)
+    ylen = torch.empty((B,), dtype=torch.int64, device=dev)
+    check(lib().ttsamd_durations(P(dur), P(cum), P(ylen), P(logw), P(durations_in), P(mask),
+                                 ctypes.c_float(length_scale), int(glow), B, T, stream_ptr()), "durations")
+    return dur, cum, ylen
+
+
+def generate_path(cum, x_mask, y_lengths, t_y):
+    """helpers.py:154-169 from cumulative durations; returns float [B, T_x, t_y]."""
+    B, Tx = cum.shape
+    attn = torch.empty((B, Tx, t_y), dtype=torch.float32, device=cum.device)
+    check(lib().ttsamd_generate_path(P(attn), P(cum), P(x_mask), P(y_lengths), B, Tx, t_y, stream_ptr()), "generate_path")
+    return attn
+
+
+def expand_prior(m, logs, noise, cum, x_mask, y_lengths, t_y, noise_scale, mask_out=False, want_stats=True,
+                 second_copy=False):
+    """vits.py:1152-1155 / glow_tts.py:137-148,361 as one gather -> dict(z_p, z_p2, m_p, logs_p, y_mask).
+    m / logs [B,C,T_x] may be channel-slices of one projection buffer (row stride T_x, any batch stride)."""
+    B, C, Tx = m.shape
+    dev = m.device
+    assert m.stride(2) == 1 and m.stride(1) == Tx and (logs is None or logs.stride() == m.stride())
+    new = lambda: torch.empty((B, C, t_y), dtype=torch.float32, device=dev)  # noqa: E731
+    z_p = new()
+    z_p2 = new() if second_copy else None
+    m_p = new() if want_stats else None
+    logs_p = new() if want_stats else None
+    y_mask = torch.empty((B, t_y), dtype=torch.float32, device=dev)
+    check(lib().ttsamd_expand_prior(P(z_p), P(z_p2), P(m_p), P(logs_p), P(y_mask), P(m), P(logs), ctypes.c_int64(m.stride(0)), P(noise), P(cum),
+                                    P(x_mask), P(y_lengths), ctypes.c_float(noise_scale), int(mask_out), B, C, Tx,
+                                    t_y, stream_ptr()), "expand_prior")
+    return {"z_p": z_p, "z_p2": z_p2, "m_p": m_p, "logs_p": logs_p, "y_mask": y_mask}
+
+
+def scale(x, s):
+    y = torch.empty_like(x)
+    check(lib().ttsamd_scale(P(y), P(x.contiguous()), ctypes.c_float(s), ctypes.c_int64(x.numel()), stream_ptr()), "scale")
     return y

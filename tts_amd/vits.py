@@ -1,0 +1,197 @@
+"""VITS on hand-written HIP kernels — drop-in for the inference surface of
+`TTS.tts.models.vits.Vits` (vits.py:544-724 args/wiring, :1088-1173 inference, :1698-1725
+load_checkpoint, :1771-1804 init_from_config).
+
+`Synthesizer`/`synthesis()` only touch: `init_from_config`, `load_checkpoint(config, path, eval=True)`,
+`.cuda()`, `parameters()`, `.tokenizer`, `.ap`, `.speaker_manager`, `.language_manager` and
+`inference(x, aux_input) -> {"model_outputs", "alignments", ...}`; all are here with
+the reference's names and argument meaning.  Training, ONNX export, voice conversion are out of scope.
+"""
+import torch
+
+from . import _lib, layers, ops
+from .hifigan import HifiganGenerator
+
+VITS_ARGS_DEFAULTS = dict(  # VitsArgs, vits.py:544-600
+    num_chars=100, out_channels=513, spec_segment_size=32, hidden_channels=192, hidden_channels_ffn_text_encoder=768,
+    num_heads_text_encoder=2, num_layers_text_encoder=6, kernel_size_text_encoder=3, dropout_p_text_encoder=0.1,
+    dropout_p_duration_predictor=0.5, kernel_size_posterior_encoder=5, dilation_rate_posterior_encoder=1,
+    num_layers_posterior_encoder=16, kernel_size_flow=5, dilation_rate_flow=1, num_layers_flow=4,
+    resblock_type_decoder="1", resblock_kernel_sizes_decoder=[3, 7, 11],
+    resblock_dilation_sizes_decoder=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], upsample_rates_decoder=[8, 8, 2, 2],
+    upsample_initial_channel_decoder=512, upsample_kernel_sizes_decoder=[16, 16, 4, 4], use_sdp=True,
+    noise_scale=1.0, inference_noise_scale=0.667, length_scale=1.0, noise_scale_dp=1.0, inference_noise_scale_dp=1.0,
+    max_inference_len=None, init_discriminator=True, use_speaker_embedding=False, num_speakers=0,
+    use_d_vector_file=False, d_vector_dim=0, speaker_embedding_channels=256, condition_dp_on_speaker=True,
+    use_language_embedding=False, embedded_language_dim=4, num_languages=0, encoder_sample_rate=None,
+    interpolate_z=True,
+)
+
+
+def _get(cfg, name, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+class _Args(dict):
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class Vits:
+    def __init__(self, config=None, ap=None, tokenizer=None, speaker_manager=None, language_manager=None):
+        self.config = config
+        margs = _get(config, "model_args", config)          # VitsConfig.model_args (vits_config.py) or a flat dict
+        self.args = _Args(VITS_ARGS_DEFAULTS)
+        for k in VITS_ARGS_DEFAULTS:
+            v = _get(margs, k, None)
+            if v is not None:
+                self.args[k] = v
+        self.ap, self.tokenizer = ap, tokenizer
+        self.speaker_manager, self.language_manager = speaker_manager, language_manager
+        a = self.args
+        self.length_scale = a.length_scale
+        self.inference_noise_scale = a.inference_noise_scale
+        self.inference_noise_scale_dp = a.inference_noise_scale_dp
+        self.max_inference_len = a.max_inference_len
+        if a.use_language_embedding or a.use_speaker_embedding or a.use_d_vector_file:
+            raise _lib.TtsAmdError("tts_amd.Vits: multi-speaker / multi-lingual conditioning is not built yet "
+                                   "(LJSpeech single-speaker path only)")
+        if a.encoder_sample_rate:
+            raise _lib.TtsAmdError("tts_amd.Vits: encoder_sample_rate / interpolate_z is not built")
+        self.waveform_decoder = HifiganGenerator(
+            a.hidden_channels, 1, a.resblock_type_decoder, a.resblock_dilation_sizes_decoder,
+            a.resblock_kernel_sizes_decoder, a.upsample_kernel_sizes_decoder, a.upsample_initial_channel_decoder,
+            a.upsample_rates_decoder, inference_padding=0, cond_channels=0, conv_pre_weight_norm=False,
+            conv_post_weight_norm=False, conv_post_bias=False)  # vits.py:704-718
+        self.device = torch.device("cpu")
+        self._sd = None
+        self.text_encoder = self.duration_predictor = self.flow = None
+
+    # ---- plug-in surface ---------------------------------------------------------------------------
+    @staticmethod
+    def init_from_config(config, samples=None, verbose=True):  # vits.py:1771-1804 (no dataset-driven managers here)
+        up = _get(_get(config, "model_args", config), "upsample_rates_decoder", VITS_ARGS_DEFAULTS["upsample_rates_decoder"])
+        hop = _get(_get(config, "audio", None), "hop_length", None)
+        if hop is not None:
+            prod = 1
+            for u in up:
+                prod *= u
+            assert prod == hop, " [!] Product of upsample rates must be equal to the hop length - %d vs %d" % (prod, hop)
+        return Vits(config, ap=_get(config, "_ap", None), tokenizer=_get(config, "_tokenizer", None))
+
+    def parameters(self):
+        return iter([self.text_encoder.emb] if self.text_encoder is not None else [])
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self._sd is not None:
+            self._pack()
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        self._sd = {k: v.detach().cpu() for k, v in sd.items()
+                    if not k.startswith(("disc.", "posterior_encoder."))}  # training-only parts (vits.py:1716-1719)
+        if self.device.type == "cuda":
+            self._pack()
+
+    def load_checkpoint(self, config, checkpoint_path, eval=False, strict=True, cache=False):  # noqa: A002
+        """vits.py:1698-1725: `{"model": state_dict}`; weight-norm stays parametrised in the checkpoint and is
+        folded once here (the reference re-normalises on every forward)."""
+        state = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        self.load_state_dict(state["model"], strict=strict)
+
+    def _pack(self):
+        if self.device.type != "cuda":
+            raise _lib.TtsAmdError("tts_amd.Vits runs only on a GPU (no CPU fallback)")
+        a, sd, dev = self.args, self._sd, self.device
+        self.text_encoder = layers.TextEncoder(sd, "text_encoder.", dev, a.hidden_channels, a.num_layers_text_encoder,
+                                               a.num_heads_text_encoder, a.kernel_size_text_encoder)
+        if a.use_sdp:
+            self.duration_predictor = layers.StochasticDurationPredictor(sd, "duration_predictor.", dev, a.hidden_channels,
+                                                                         192, 3, 4)
+        else:
+            self.duration_predictor = layers.DurationPredictor(sd, "duration_predictor.", dev)
+        self.flow = layers.ResidualCouplingBlocks(sd, "flow.", dev, a.hidden_channels, a.hidden_channels, a.kernel_size_flow,
+                                                  a.dilation_rate_flow, a.num_layers_flow)
+        self.waveform_decoder.load_state_dict(sd, prefix="waveform_decoder.")
+        self.waveform_decoder.to(dev)
+
+    def weight_bytes(self):
+        return sum(v.numel() * 4 for v in self._sd.values())
+
+    # ---- inference (vits.py:1088-1173) ---------------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None,  # noqa: B006
+                                      "language_ids": None, "durations": None}):
+        """x int64 [B, T_seq]; aux_input["x_lengths"] [B] for batches.  Extra (optional) aux keys let a caller
+        pin the two random draws: "noise_dp" [B,2,T_seq] (stochastic_duration_predictor.py:287) and
+        "noise_z" [B,C,T_dec] (vits.py:1155); without them they are drawn with torch.randn on the device."""
+        if self.text_encoder is None:
+            raise _lib.TtsAmdError("tts_amd.Vits: no weights loaded / not moved to the GPU")
+        _lib.require_gpu(x, "x")
+        a = self.args
+        dev = x.device
+        x = x.to(torch.int64).contiguous()
+        B, T = x.shape
+        x_lengths = aux_input.get("x_lengths") if aux_input else None
+        if x_lengths is None:
+            x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)       # vits.py:1082-1086
+        x_mask = ops.sequence_mask(x_lengths.to(dev), T)
+        h, stats = self.text_encoder(x, x_mask)
+        H = a.hidden_channels
+        durations = aux_input.get("durations") if aux_input else None
+        logw = None
+        if durations is None:
+            if a.use_sdp:
+                noise_dp = aux_input.get("noise_dp") if aux_input else None
+                if noise_dp is None:
+                    noise_dp = torch.randn(B, 2, T, device=dev, dtype=torch.float32)
+                logw = self.duration_predictor(h, x_mask, noise_dp.to(dev, torch.float32).contiguous(),
+                                               self.inference_noise_scale_dp)
+            else:
+                logw = self.duration_predictor(h, x_mask)
+            w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale))
+        else:
+            d = durations.to(dev, torch.float32).reshape(B, T).contiguous()       # vits.py:1141-1143 (+ batches)
+            w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d)
+        t_dec = int(y_lengths.max().item())                                       # one D2H sync: output extent
+        noise_z = aux_input.get("noise_z") if aux_input else None
+        if noise_z is None:
+            noise_z = torch.randn(B, H, t_dec, device=dev, dtype=torch.float32)
+        noise_z = noise_z.to(dev, torch.float32).contiguous()
+        assert noise_z.shape == (B, H, t_dec), "noise_z must be [B, C, T_dec]"
+        pri = ops.expand_prior(stats[:, :H], stats[:, H:], noise_z, cum, x_mask, y_lengths, t_dec,
+                               float(self.inference_noise_scale), second_copy=True)
+        attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)
+        y_mask = pri["y_mask"]
+        z = self.flow(pri["z_p2"], y_mask)
+        zd = z if self.max_inference_len is None else z[:, :, : self.max_inference_len].contiguous()
+        md = y_mask if self.max_inference_len is None else y_mask[:, : self.max_inference_len].contiguous()
+        o = self.waveform_decoder.forward(zd, in_mask=md)                         # (z * y_mask)[:, :, :max_len]
+        outputs = {
+            "model_outputs": o,
+            "alignments": attn,
+            "durations": w_ceil.unsqueeze(1),
+            "z": z,
+            "z_p": pri["z_p"],
+            "m_p": pri["m_p"],
+            "logs_p": pri["logs_p"],
+            "y_mask": y_mask.unsqueeze(1),
+        }
+        if aux_input and aux_input.get("return_extras"):
+            outputs.update(x=h, logw=None if logw is None else logw.unsqueeze(1), y_lengths=y_lengths)
+        return outputs
+
+    __call__ = inference
