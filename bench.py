@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): audio samples/s + real-time factor of LJSpeech-shaped VITS
+end-to-end inference (text ids -> waveform, 22.05 kHz) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one full `Vits.inference` pass (text encoder, stochastic duration predictor, prior expansion incl.
+both random draws, 4 coupling flows, HiFiGAN waveform decoder) over a batch of 32 synthetic utterances of
+128 characters (257 token ids with blanks).  Token ids are resident in HBM when the
+timed region starts; random-init weights of the exact `VitsArgs` default architecture (no network => no
+released checkpoint).  Output length is pinned with the synthetic duration pattern 2+(t mod 3) (770 frames =
+197 120 samples per utterance) so the workload is identical run to run — the duration predictor still runs
+inside the timed region, nothing is skipped.
+
+N GPUs = N independent replicas (one process per GPU), each with its own 32-utterance shard (weak scaling);
+the only collective is the one-time weight broadcast from rank 0 (RCCL), outside the timed region.
+
+Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" + "cpu_baseline", see README/DESIGN.md).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SAMPLE_RATE = 22050
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def synthetic_batch(batch, n_chars, seed, device):
+    """128-char utterances -> 2*128+1 ids with the blank id interleaved (add_blank=True, vits_config.py:146;
+    tokenizer.py:126-134): blank (id 0 here) at even positions, uniform random character ids at odd ones."""
+    g = torch.Generator().manual_seed(seed)
+    T = 2 * n_chars + 1
+    x = torch.zeros(batch, T, dtype=torch.int64)
+    x[:, 1::2] = torch.randint(1, 100, (batch, n_chars), generator=g)
+    dur = (2 + (torch.arange(T) % 3)).float().repeat(batch, 1)
+    return x.to(device), torch.full((batch,), T, dtype=torch.int64, device=device), dur.to(device)
+
+
+def cpu_baseline(sd, n_chars, seconds_budget=20.0):
+    """The CPU oracle (oracle/tts_oracle.py: torch fp32 restatement of the reference's modules, pinned to them)
+    on this box's host cores, reference call pattern: one utterance at a time (synthesizer.py:384)."""
+    from oracle import tts_oracle as O
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    x, xl, dur = synthetic_batch(1, n_chars, 0, "cpu")
+    noise_dp = torch.randn(1, 2, x.shape[1])
+    with torch.no_grad():
+        t0 = time.time()
+        out = O.vits_inference(sd, x, xl, {}, noise_dp=noise_dp, durations=dur.view(1, 1, -1))  # warm-up
+        warm = time.time() - t0
+        n, t_used, samples = 0, 0.0, 0
+        while n < 1 or (t_used + warm < seconds_budget and n < 8):
+            t0 = time.time()
+            # the oracle skips the DP when durations are injected; time it separately so no work is skipped
+            O.vits_inference(sd, x, xl, {}, noise_dp=noise_dp, stop_after="prior")
+            out = O.vits_inference(sd, x, xl, {}, noise_dp=noise_dp, durations=dur.view(1, 1, -1))
+            t_used += time.time() - t0
+            samples += out["model_outputs"].shape[-1]
+            n += 1
+    return {"value": samples / t_used, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d x 1 utterance of %d chars (%d samples each), B=1 sentence loop as the reference does; "
+                      "torch fp32 CPU ops, %d threads of %d host cores; rtf_x=%.1f"
+                      % (n, n_chars, out["model_outputs"].shape[-1], threads, cores, samples / t_used / SAMPLE_RATE)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--chars", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from tts_amd import synthetic as W         # seeded synthetic checkpoint (no network => no released weights)
+    from tts_amd import ops, parallel
+    from tts_amd.vits import Vits
+
+    # rank 0 builds the weights, everyone else receives them in one RCCL broadcast
+    sd = W.make_vits_state({}, seed=1234) if rank == 0 else None
+    t0 = time.time()
+    sd = parallel.broadcast_state_dict(sd, src=0, device=dev)
+    bcast_s = time.time() - t0
+    model = Vits({"model_args": {}})
+    model.load_state_dict(sd)
+    model.to(dev)
+
+    x, xl, dur = synthetic_batch(args.batch, args.chars, seed=rank, device=dev)
+    aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True}
+
+    def step():
+        return model.inference(x, aux)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    # live roofline measurement: HIP events around every launch of the dominant kernel instantiation
+    # (ResBlock k=11 d=1 256->256 convs, conv1d_mfma_kernel<11,1,2,2,2,2>) and around all conv launches of the
+    # waveform decoder in aggregate, on the stream they are launched on, during the timed region.
+    def select(pc, a):
+        if pc.kernel == 11 and pc.dilation == 1 and pc.c_out == 256 and pc.c_in == 256:
+            return "dominant"
+        # every other waveform-decoder / flow conv; the tiny text-side launches are left untouched
+        return "other_conv" if 2.0 * pc.c_out * pc.c_in * pc.kernel * a.t_out * a.batch >= 1e9 else None
+
+    timer = ops.ConvTimer(select)
+    if not os.environ.get("TTSAMD_BENCH_NO_TIMER"):
+        ops.set_conv_timer(timer)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.set_conv_timer(None)
+
+    samples_per_step = int(out["y_mask"].sum().item()) * 256        # valid output samples of this rank's shard
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ss = torch.tensor([float(samples_per_step)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+    elapsed_max, total_samples_per_step = float(tt.item()), float(ss.item())
+
+    if rank == 0:
+        res = timer.results()
+        dom = res.get("dominant", dict(launches=0, flops=0.0, bytes=0.0, ms=1.0))
+        allc = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)
+        for r in res.values():
+            for k in allc:
+                allc[k] += r[k]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["launches"] else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        value = total_samples_per_step * args.steps / elapsed_max
+        line = {
+            "metric": "audio samples/sec (LJSpeech VITS -> HiFiGAN decoder, 22.05 kHz, end-to-end inference)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf_x": value / SAMPLE_RATE, "rtf_x_per_gpu": value / SAMPLE_RATE / world,
+            "config": {"workload": "configs[1]: LJSpeech VITS end-to-end, batch=%d random %d-char utterances per GPU "
+                                   "(257 ids, 770 frames, 197120 samples each), 22.05 kHz" % (args.batch, args.chars),
+                       "utterances_per_gpu": args.batch, "chars": args.chars, "parallelism": "replicas x%d" % world,
+                       "weights": "random-init VitsArgs defaults (29.1 M params), broadcast from rank 0 in %.3f s" % bcast_s},
+            "roofline": {
+                "bound": "mfma", "kernel": "ttsamd::conv1d_mfma_kernel<11,1,2,2,2,2> (ResBlock1 k=11 d=1, 256->256)",
+                "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                "launches_timed": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
+                "algorithmic_gbps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["launches"] else 0.0,
+                "all_conv_launches": {"launches": allc["launches"],
+                                      "tflops": allc["flops"] / (allc["ms"] * 1e-3) / 1e12 if allc["ms"] else 0.0,
+                                      "algorithmic_gbps": allc["bytes"] / (allc["ms"] * 1e-3) / 1e9 if allc["ms"] else 0.0,
+                                      "ms_per_step": allc["ms"] / args.steps},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, args.chars)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

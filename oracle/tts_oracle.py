@@ -596,44 +596,7 @@ def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None):
 
 
 # ----------------------------------------------------------------------------------------------
-# seeded weight factory (no network => no released checkpoints; SURVEY §8c "Weights")
+# seeded weight factory: lives in the product package (bench.py needs synthetic checkpoints too and may not
+# import oracle/); re-exported here for the tests.
 # ----------------------------------------------------------------------------------------------
-def _conv(sd, name, cout, cin, k, gen, wn=False, bias=True, std=None, transposed=False):
-    fan_in = cin * k
-    std = std if std is not None else 1.0 / math.sqrt(fan_in)
-    shape = (cin, cout, k) if transposed else (cout, cin, k)
-    v = torch.randn(shape, generator=gen) * std
-    if wn:
-        n0 = shape[0]
-        g = v.reshape(n0, -1).norm(dim=1).reshape(n0, 1, 1) * (0.8 + 0.4 * torch.rand(n0, 1, 1, generator=gen))
-        sd[name + ".parametrizations.weight.original0"] = g
-        sd[name + ".parametrizations.weight.original1"] = v
-    else:
-        sd[name + ".weight"] = v
-    if bias:
-        sd[name + ".bias"] = torch.randn(cout, generator=gen) * 0.02
-
-
-def make_hifigan_state(cfg, in_channels, seed=1234, prefix="", weight_norm=True, pre_wn=True, post_wn=True,
-                       post_bias=True, out_channels=1):
-    """Random HifiganGenerator state_dict in the reference's key layout (hifigan_generator.py:199-234)."""
-    gen = torch.Generator().manual_seed(seed)
-    sd = {}
-    c0 = cfg["upsample_initial_channel"]
-    _conv(sd, prefix + "conv_pre", c0, in_channels, 7, gen, wn=weight_norm and pre_wn)
-    ch = c0
-    nk = len(cfg["resblock_kernel_sizes"])
-    for i, (u, k) in enumerate(zip(cfg["upsample_factors"], cfg["upsample_kernel_sizes"])):
-        _conv(sd, prefix + "ups.%d" % i, ch // 2, ch, k, gen, wn=weight_norm, transposed=True,
-              std=1.0 / math.sqrt(ch * k / u))
-        ch //= 2
-        for j, (rk, rd) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
-            rp = prefix + "resblocks.%d." % (i * nk + j)
-            for m in range(len(rd)):
-                if str(cfg["resblock_type"]) == "1":
-                    _conv(sd, rp + "convs1.%d" % m, ch, ch, rk, gen, wn=weight_norm, std=0.7 / math.sqrt(ch * rk))
-                    _conv(sd, rp + "convs2.%d" % m, ch, ch, rk, gen, wn=weight_norm, std=0.7 / math.sqrt(ch * rk))
-                else:
-                    _conv(sd, rp + "convs.%d" % m, ch, ch, rk, gen, wn=weight_norm, std=0.7 / math.sqrt(ch * rk))
-    _conv(sd, prefix + "conv_post", out_channels, ch, 7, gen, wn=weight_norm and post_wn, bias=post_bias)
-    return sd
+from tts_amd.synthetic import make_hifigan_state  # noqa: E402,F401

@@ -1,181 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY — seeded random `state_dict`s in the reference's parameter layout.
-
-No network => no released checkpoints (SURVEY §8c "Weights"): oracle and engine share these seeded
-weights.  The key names / shapes are those of the reference modules' `state_dict()` (verified by
-tests/test_oracle_pin.py against the real modules when /root/reference is present).  Layers the
-reference zero-initialises (networks.py:135-136, stochastic_duration_predictor.py:117-118,
-glow.py:52-53,195-196) get small random values, otherwise every coupling layer is the identity
-and parity would be vacuous.
-"""
-import math
-
-import torch
-
-from .tts_oracle import GLOW_DEFAULTS, VITS_DEFAULTS, make_hifigan_state
-
-
-class _F:
-    def __init__(self, seed):
-        self.gen = torch.Generator().manual_seed(seed)
-        self.sd = {}
-
-    def randn(self, *shape, std=1.0):
-        return torch.randn(*shape, generator=self.gen) * std
-
-    def conv(self, name, cout, cin, k, wn=False, bias=True, std=None, gain=1.0):
-        std = std if std is not None else gain / math.sqrt(cin * k)
-        v = self.randn(cout, cin, k, std=std)
-        if wn:
-            g = v.reshape(cout, -1).norm(dim=1).reshape(cout, 1, 1)
-            g = g * (0.8 + 0.4 * torch.rand(cout, 1, 1, generator=self.gen))
-            self.sd[name + ".parametrizations.weight.original0"] = g
-            self.sd[name + ".parametrizations.weight.original1"] = v
-        else:
-            self.sd[name + ".weight"] = v
-        if bias:
-            self.sd[name + ".bias"] = self.randn(cout, std=0.05)
-
-    def norm(self, name, c, shape3=False, gamma=1.0):
-        shp = (1, c, 1) if shape3 else (c,)
-        self.sd[name + ".gamma"] = gamma * (1.0 + 0.1 * self.randn(*shp))
-        self.sd[name + ".beta"] = 0.05 * self.randn(*shp)
-
-
-def _transformer(f, p, hidden, ffn_ch, layers, heads, k, window, ln3, gamma=1.0, out_channels=None):
-    out_channels = out_channels or hidden
-    for i in range(layers):
-        a = p + "attn_layers.%d." % i
-        if window is not None:
-            f.sd[a + "emb_rel_k"] = f.randn(1, 2 * window + 1, hidden // heads, std=(hidden // heads) ** -0.5)
-            f.sd[a + "emb_rel_v"] = f.randn(1, 2 * window + 1, hidden // heads, std=(hidden // heads) ** -0.5)
-        for n in ("conv_q", "conv_k", "conv_v", "conv_o"):
-            f.conv(a + n, hidden, hidden, 1)
-        f.norm(p + "norm_layers_1.%d" % i, hidden, ln3, gamma)
-        last = (i + 1) == layers
-        f.conv(p + "ffn_layers.%d.conv_1" % i, ffn_ch, hidden, k)
-        f.conv(p + "ffn_layers.%d.conv_2" % i, out_channels if last else hidden, ffn_ch, k)
-        f.norm(p + "norm_layers_2.%d" % i, out_channels if last else hidden, ln3, gamma)
-    if out_channels != hidden:
-        f.conv(p + "proj", out_channels, hidden, 1)
-
-
-def _dds(f, p, c, k, layers):
-    for i in range(layers):
-        f.sd[p + "convs_sep.%d.weight" % i] = f.randn(c, 1, k, std=1 / math.sqrt(k))
-        f.sd[p + "convs_sep.%d.bias" % i] = f.randn(c, std=0.05)
-    for i in range(layers):
-        f.conv(p + "convs_1x1.%d" % i, c, c, 1)
-    for i in range(layers):
-        f.norm(p + "norms_1.%d" % i, c)
-    for i in range(layers):
-        f.norm(p + "norms_2.%d" % i, c)
-
-
-def _flows(f, p, hidden, k, nflows):
-    f.sd[p + "0.translation"] = 0.1 * f.randn(2, 1)
-    f.sd[p + "0.log_scale"] = 0.1 * f.randn(2, 1)
-    for i in range(1, nflows + 1):
-        q = p + "%d." % i
-        f.conv(q + "pre", hidden, 1, 1)
-        _dds(f, q + "convs.", hidden, k, 3)
-        f.conv(q + "proj", 29, hidden, 1, std=0.5 / math.sqrt(hidden))  # zero-init in the reference
-
-
-def _wn(f, p, hidden, k, layers, in_channels=None):
-    in_channels = in_channels or hidden
-    for i in range(layers):
-        f.conv(p + "in_layers.%d" % i, 2 * hidden, in_channels if i == 0 else hidden, k, wn=True)
-        f.conv(p + "res_skip_layers.%d" % i, 2 * hidden if i < layers - 1 else hidden, hidden, 1, wn=True, gain=0.5)
-
-
-def make_vits_state(args=None, seed=1234, with_decoder=True):
-    """Reference-layout state_dict for the inference-relevant sub-modules of `Vits`
-    (text_encoder., duration_predictor., flow., waveform_decoder.; vits.py:653-718)."""
-    a = dict(VITS_DEFAULTS)
-    a.update(args or {})
-    h = a["hidden_channels"]
-    f = _F(seed)
-    p = "text_encoder."
-    f.sd[p + "emb.weight"] = f.randn(a["num_chars"], h, std=h ** -0.5)
-    _transformer(f, p + "encoder.", h, a["hidden_channels_ffn_text_encoder"], a["num_layers_text_encoder"],
-                 a["num_heads_text_encoder"], a["kernel_size_text_encoder"], 4, False)
-    f.conv(p + "proj", 2 * h, h, 1, gain=0.5)
-    p = "duration_predictor."
-    if a["use_sdp"]:
-        f.conv(p + "pre", 192, h, 1)
-        _dds(f, p + "convs.", 192, 3, 3)
-        f.conv(p + "proj", 192, 192, 1)
-        _flows(f, p + "flows.", 192, 3, 4)
-        f.conv(p + "post_pre", 192, 1, 1)
-        _dds(f, p + "post_convs.", 192, 3, 3)
-        f.conv(p + "post_proj", 192, 192, 1)
-        _flows(f, p + "post_flows.", 192, 3, 4)
-    else:
-        f.conv(p + "conv_1", 256, h, 3)
-        f.norm(p + "norm_1", 256, True, 0.1)
-        f.conv(p + "conv_2", 256, 256, 3)
-        f.norm(p + "norm_2", 256, True, 0.1)
-        f.conv(p + "proj", 1, 256, 1)
-    for i in range(4):
-        q = "flow.flows.%d." % i
-        f.conv(q + "pre", h, h // 2, 1)
-        _wn(f, q + "enc.", h, a["kernel_size_flow"], a["num_layers_flow"])
-        f.conv(q + "post", h // 2, h, 1, gain=0.5)  # zero-init in the reference
-    sd = f.sd
-    if with_decoder:
-        cfg = dict(resblock_type=a["resblock_type_decoder"], resblock_dilation_sizes=a["resblock_dilation_sizes_decoder"],
-                   resblock_kernel_sizes=a["resblock_kernel_sizes_decoder"],
-                   upsample_kernel_sizes=a["upsample_kernel_sizes_decoder"],
-                   upsample_initial_channel=a["upsample_initial_channel_decoder"],
-                   upsample_factors=a["upsample_rates_decoder"])
-        sd.update(make_hifigan_state(cfg, h, seed=seed + 1, prefix="waveform_decoder.", pre_wn=False, post_wn=False,
-                                     post_bias=False))
-    return sd
-
-
-def make_glow_state(args=None, seed=4321):
-    """Reference-layout state_dict for `GlowTTS` (encoder., decoder.; glow_tts.py:80-105) after
-    `store_inverse()` is NOT applied (weight-norm still parametrised, like a training checkpoint)."""
-    a = dict(GLOW_DEFAULTS)
-    a.update(args or {})
-    ep = a["encoder_params"]
-    h = a["hidden_channels_enc"]
-    f = _F(seed)
-    p = "encoder."
-    f.sd[p + "emb.weight"] = f.randn(a["num_chars"], h, std=h ** -0.5)
-    if a["use_encoder_prenet"]:
-        for i in range(3):
-            f.conv(p + "prenet.conv_layers.%d" % i, h, h, 5)
-            f.norm(p + "prenet.norm_layers.%d" % i, h, True, 0.5)
-        f.conv(p + "prenet.proj", h, h, 1, gain=0.5)  # zero-init in the reference
-    ln3 = ep.get("layer_norm_type", "1") == "1"
-    _transformer(f, p + "encoder.", h, ep["hidden_channels_ffn"], ep["num_layers"], ep["num_heads"], ep["kernel_size"],
-                 ep.get("rel_attn_window_size"), ln3, gamma=0.5 if ln3 else 1.0)
-    f.conv(p + "proj_m", a["out_channels"], h, 1)
-    if not a["mean_only"]:
-        f.conv(p + "proj_s", a["out_channels"], h, 1, gain=0.3)
-    q = p + "duration_predictor."
-    f.conv(q + "conv_1", a["hidden_channels_dp"], h, 3)
-    f.norm(q + "norm_1", a["hidden_channels_dp"], True, 0.5)
-    f.conv(q + "conv_2", a["hidden_channels_dp"], a["hidden_channels_dp"], 3)
-    f.norm(q + "norm_2", a["hidden_channels_dp"], True, 0.5)
-    f.conv(q + "proj", 1, a["hidden_channels_dp"], 1)
-    c = a["out_channels"] * a["num_squeeze"]
-    hd = a["hidden_channels_dec"]
-    for b in range(a["num_flow_blocks_dec"]):
-        f.sd["decoder.flows.%d.logs" % (3 * b)] = 0.1 * f.randn(1, c, 1)
-        f.sd["decoder.flows.%d.bias" % (3 * b)] = 0.1 * f.randn(1, c, 1)
-        w = torch.linalg.qr(f.randn(a["num_splits"], a["num_splits"]), "complete")[0]
-        f.sd["decoder.flows.%d.weight" % (3 * b + 1)] = w + 0.05 * f.randn(a["num_splits"], a["num_splits"])
-        q = "decoder.flows.%d." % (3 * b + 2)
-        f.conv(q + "start", hd, c // 2, 1, wn=True)
-        f.conv(q + "end", c, hd, 1, gain=0.3)  # zero-init in the reference
-        _wn(f, q + "wn.", hd, a["kernel_size_dec"], a["num_block_layers"])
-    return f.sd
-
-
-HIFIGAN_V1 = dict(  # TTS/vocoder/configs/hifigan_config.py:95-104
-    resblock_type="1", resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], resblock_kernel_sizes=[3, 7, 11],
-    upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512, upsample_factors=[8, 8, 2, 2],
-    inference_padding=5)
-HIFIGAN_V2 = dict(HIFIGAN_V1, upsample_initial_channel=128)  # HiFi-GAN paper V2
+"""TEST INFRASTRUCTURE ONLY — re-export of the seeded synthetic-checkpoint factory (tts_amd/synthetic.py) under
+the name the tests use."""
+from tts_amd.synthetic import (HIFIGAN_V1, HIFIGAN_V2, _F, _dds, _flows, _transformer, _wn,  # noqa: F401
+                               make_glow_state, make_hifigan_state, make_vits_state)

@@ -1,24 +1,41 @@
-"""Summarise a rocprofv3 --kernel-trace results.db (rocpd sqlite) into a per-kernel table."""
+"""Condense rocprofv3 CSV output (kernel stats / PMC counter collection) into the small text summaries that are
+committed under profiles/.   usage: prof_summary.py stats <trace_kernel_stats.csv> | pmc <pmc_counter_collection.csv>"""
+import csv
 import re
-import sqlite3
 import sys
+from collections import defaultdict
 
 
-def main(path, top=40):
-    c = sqlite3.connect(path)
-    rows = c.execute(
-        "select name, count(*), sum(duration), avg(duration), min(duration), grid_x, grid_y, grid_z, workgroup_x, "
-        "max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels group by name, grid_x, grid_y, grid_z "
-        "order by sum(duration) desc").fetchall()
-    tot = sum(r[2] for r in rows)
-    print("total kernel time %.3f ms over %d dispatches" % (tot / 1e6, sum(r[1] for r in rows)))
-    print("%-52s %5s %10s %10s %10s %-18s %4s %9s %7s %6s" % ("kernel", "n", "total_ms", "avg_us", "min_us", "grid(wg)", "wg", "vgpr+agpr", "lds", "%"))
+def short(name):
+    name = re.sub(r"void ttsamd::conv1d_mfma_kernel<(.*?)>.*", r"conv1d_mfma_kernel<\1>", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*", "", name)[:70]
+
+
+def stats(path, top=45):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print("# rocprofv3 --kernel-trace --stats : %d kernels, %.3f ms total GPU time" % (len(rows), tot / 1e6))
+    print("%-72s %6s %11s %11s %11s %7s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "pct"))
     for r in rows[:top]:
-        nm = re.sub(r"ttsamd::conv1d_mfma_kernel<(.*?)>.*", r"conv<\1>", r[0])
-        nm = re.sub(r"\(.*", "", nm)[:52]
-        grid = "%dx%dx%d" % (r[5] // max(r[8], 1), r[6], r[7])
-        print("%-52s %5d %10.3f %10.1f %10.1f %-18s %4d %5d+%-3d %7d %6.1f" % (nm, r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, grid, r[8], r[9], r[10], r[11], 100.0 * r[2] / tot))
+        print("%-72s %6s %11.3f %11.1f %11.1f %7.2f" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                      float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3,
+                                                      float(r["Percentage"])))
+
+
+def pmc(path, top=30):
+    agg = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+    names = sorted({c for k in agg for c in agg[k]})
+    print("# rocprofv3 --pmc %s : per-kernel counter sums (dispatch count in brackets)" % " ".join(names))
+    order = sorted(agg, key=lambda k: -max(agg[k].values()))
+    for k in order[:top]:
+        print("%-72s " % k + "  ".join("%s=%.6g[%d]" % (c, agg[k][c], cnt[k][c]) for c in names))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])

@@ -88,8 +88,9 @@ def test_vits_matches_reference_golden(gpu, name, use_sdp):
     t_dec = gold["z_p"].shape[2]
     torch.manual_seed(7)                        # the reference draws randn(B,2,T) (SDP only) then randn_like(m_p)
     noise_dp = torch.randn(3, 2, 37) if use_sdp else None
-    # randn_like(m_p) fills in m_p's MEMORY order; m_p is a transposed matmul result, i.e. laid out [B, T, C]
-    noise_z = torch.randn(3, t_dec, 192).transpose(1, 2)
+    # randn_like(m_p): m_p is a transposed matmul result (strides of [B, T, C]); the CPU generator's fill path
+    # depends on the layout, so draw into a tensor with exactly those strides
+    noise_z = torch.randn_like(torch.empty(3, t_dec, 192).transpose(1, 2))
     m = _model(args, sd, gpu)
     aux = {"x_lengths": xl.to(gpu), "noise_dp": None if noise_dp is None else noise_dp.to(gpu),
            "noise_z": noise_z.to(gpu), "return_extras": True}

@@ -51,7 +51,7 @@ __device__ __forceinline__ float conv_in_act(float v, int act, float slope)
     return (act == TTSAMD_ACT_LRELU) ? (v > 0.f ? v : v * slope) : v;
 }
 
-template <int K, int D, int MI, int NI, int WM, int WN>
+template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_conv1d_args a)
 {
     using G = ConvGeom<K, D, MI, NI, WM, WN>;
@@ -168,96 +168,109 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
     }
 
     // ---- epilogue --------------------------------------------------------------------------
-    const float *omask = a.out_mask ? a.out_mask + (long)b * a.t_out : nullptr;
-    const float *rbias = a.row_bias ? a.row_bias + (long)b * a.c_out : nullptr;
-    if (a.mode == TTSAMD_CONV_GATE || a.mode == TTSAMD_CONV_COUPLE_AFFINE) {
-        if constexpr (MI == 2) {
-            const long pair = (long)blockIdx.y * WM + wm;
-            const bool gate = (a.mode == TTSAMD_CONV_GATE);
-            const int nvalid = gate ? a.c_out / 2 : a.split_row;  // output channels
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int t = t0 + wn * (32 * NI) + ni * 32 + j;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const long prow = pair * 64 + i;  // packed row of the first (tanh / t) half
-                    const long oc = pair * 32 + i;    // output channel
-                    if (prow + 32 < a.c_out && oc < nvalid && t < a.t_out) {
-                        float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
-                        if (a.bias) { v0 += a.bias[prow]; v1 += a.bias[prow + 32]; }
-                        if (rbias) { v0 += rbias[prow]; v1 += rbias[prow + 32]; }
-                        float o;
-                        if (gate) {
-                            o = tanhf(v0) * (1.f / (1.f + expf(-v1)));
-                        } else {
-                            const float m = omask ? omask[t] : 1.f;
-                            o = (a.res[(long)b * a.res_bstride + oc * a.res_rstride + t] - v0) * expf(-v1) * m;
-                        }
-                        a.y[(long)b * a.y_bstride + oc * a.y_rstride + t] = o;
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+    // MODE is a template parameter (each fusion gets its own lean kernel), and the epilogue-only
+    // arguments are read from the kernarg segment HERE, behind an opaque barrier, so that they do
+    // not sit in SGPRs (or spill) across the MFMA main loop.
+    const ttsamd_conv1d_args __attribute__((address_space(4))) *ep =
+        (const ttsamd_conv1d_args __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ep) : : "memory");
+    float *const y = ep->y;
+    const long y_bs = ep->y_bstride, y_rs = ep->y_rstride;
+    const int c_out = ep->c_out, t_out = ep->t_out;
+    const float *bias = ep->bias;
+    const float *rbias = ep->row_bias ? ep->row_bias + (long)b * c_out : nullptr;
+    const float *omask = ep->out_mask ? ep->out_mask + (long)b * t_out : nullptr;
+    const float *res = ep->res ? ep->res + (long)b * ep->res_bstride : nullptr;
+    const long res_rs = ep->res_rstride;
+
+    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE) {
+        static_assert(MI == 2, "paired-row epilogues need MI == 2");
+        const long pair = (long)blockIdx.y * WM + wm;
+        constexpr bool gate = (MODE == TTSAMD_CONV_GATE);
+        const int nvalid = gate ? c_out / 2 : ep->split_row;  // output channels
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int t = t0 + wn * (32 * NI) + ni * 32 + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= a.c_out || t >= a.t_out) continue;
-                float v = acc[mi][ni][r];
-                if (a.bias) v += a.bias[row];
-                if (rbias) v += rbias[row];
-                if (a.out_act == TTSAMD_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (a.out_act == TTSAMD_ACT_TANH) v = tanhf(v);
-                if (a.mode == TTSAMD_CONV_SHUFFLE) {
-                    const int co = (int)(row / a.shuffle_u);
-                    const int rr = (int)(row - (long)co * a.shuffle_u);
-                    const int n = t * a.shuffle_u + rr - a.shuffle_pad;
-                    if (n >= 0 && n < a.shuffle_t_out)
-                        a.y[(long)b * a.y_bstride + (long)co * a.y_rstride + n] = v;
-                    continue;
-                }
-                if (a.mode == TTSAMD_CONV_COUPLE) {
-                    const float m = omask ? omask[t] : 1.f;
-                    v = v * m;
-                    v = (a.res[(long)b * a.res_bstride + row * a.res_rstride + t] - v) * m;
-                    a.y[(long)b * a.y_bstride + row * a.y_rstride + t] = v;
-                    continue;
-                }
-                if (a.mode == TTSAMD_CONV_RES_SKIP) {
-                    if (row < a.split_row) {
-                        v = a.res[(long)b * a.res_bstride + row * a.res_rstride + t] + v;
-                        if (omask) v *= omask[t];
-                        a.y[(long)b * a.y_bstride + row * a.y_rstride + t] = v;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const long prow = pair * 64 + i;  // packed row of the first (tanh / t) half
+                const long oc = pair * 32 + i;    // output channel
+                if (prow + 32 < c_out && oc < nvalid && t < t_out) {
+                    float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
+                    if (bias) { v0 += bias[prow]; v1 += bias[prow + 32]; }
+                    if (rbias) { v0 += rbias[prow]; v1 += rbias[prow + 32]; }
+                    float o;
+                    if constexpr (gate) {
+                        o = tanhf(v0) * (1.f / (1.f + expf(-v1)));
                     } else {
-                        const long r2 = row - a.split_row;
-                        if (a.accum) v = a.accum[(long)b * a.accum_bstride + r2 * a.accum_rstride + t] + v;
-                        a.y2[(long)b * a.y2_bstride + r2 * a.y2_rstride + t] = v;
+                        const float m = omask ? omask[t] : 1.f;
+                        o = (res[oc * res_rs + t] - v0) * expf(-v1) * m;
                     }
-                    continue;
+                    y[(long)b * y_bs + oc * y_rs + t] = o;
                 }
-                if (a.res) v += a.res[(long)b * a.res_bstride + row * a.res_rstride + t];
-                if (a.accum) v = a.accum[(long)b * a.accum_bstride + row * a.accum_rstride + t] + v;
-                if (omask) v *= omask[t];
-                if (a.out_div != 0.f) v = v / a.out_div;
-                a.y[(long)b * a.y_bstride + row * a.y_rstride + t] = v;
+            }
+        }
+    } else {
+        const int out_act = ep->out_act;
+        const float out_div = ep->out_div;
+        const float *accum = ep->accum ? ep->accum + (long)b * ep->accum_bstride : nullptr;
+        const long accum_rs = ep->accum_rstride;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row >= c_out || t >= t_out) continue;
+                    float v = acc[mi][ni][r];
+                    if (bias) v += bias[row];
+                    if (rbias) v += rbias[row];
+                    if constexpr (MODE == TTSAMD_CONV_SHUFFLE) {
+                        const int u = ep->shuffle_u;
+                        const int co = (int)(row / u);
+                        const int rr = (int)(row - (long)co * u);
+                        const int n = t * u + rr - ep->shuffle_pad;
+                        if (n >= 0 && n < ep->shuffle_t_out) y[(long)b * y_bs + (long)co * y_rs + n] = v;
+                    } else if constexpr (MODE == TTSAMD_CONV_COUPLE) {
+                        const float m = omask ? omask[t] : 1.f;
+                        v = v * m;
+                        v = (res[row * res_rs + t] - v) * m;
+                        y[(long)b * y_bs + row * y_rs + t] = v;
+                    } else if constexpr (MODE == TTSAMD_CONV_RES_SKIP) {
+                        const int split = ep->split_row;
+                        if (row < split) {
+                            v = res[row * res_rs + t] + v;
+                            if (omask) v *= omask[t];
+                            y[(long)b * y_bs + row * y_rs + t] = v;
+                        } else {
+                            const long r2 = row - split;
+                            if (accum) v = accum[r2 * accum_rs + t] + v;
+                            ep->y2[(long)b * ep->y2_bstride + r2 * ep->y2_rstride + t] = v;
+                        }
+                    } else {
+                        if (out_act == TTSAMD_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (out_act == TTSAMD_ACT_TANH) v = tanhf(v);
+                        if (res) v += res[row * res_rs + t];
+                        if (accum) v = accum[row * accum_rs + t] + v;
+                        if (omask) v *= omask[t];
+                        if (out_div != 0.f) v = v / out_div;
+                        y[(long)b * y_bs + row * y_rs + t] = v;
+                    }
+                }
             }
         }
     }
 }
 
-template <int K, int D, int MI, int NI, int WM, int WN>
+template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
 int conv1d_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     using G = ConvGeom<K, D, MI, NI, WM, WN>;
-    auto kern = conv1d_mfma_kernel<K, D, MI, NI, WM, WN>;
+    auto kern = conv1d_mfma_kernel<K, D, MI, NI, WM, WN, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -273,17 +286,49 @@ int conv1d_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
 }
 
 // Tile choice by packed row count: 128x128 (4 waves, 2x2 of 64x64), 64x256, 32x256.
+template <int K, int D, int MODE>
+int conv1d_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
+{
+    const int mtiles = (a.c_out + 31) / 32;
+    if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
+    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE) {
+        return conv1d_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
+    } else {
+        if (mtiles % 2 == 0) return conv1d_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
+        return conv1d_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
+    }
+}
+
+inline int conv1d_mode_unsupported(const ttsamd_conv1d_args &a)
+{
+    set_error("conv1d: mode %d has no instantiation for kernel=%d dilation=%d", a.mode, a.kernel, a.dilation);
+    return TTSAMD_ERR_UNSUPPORTED;
+}
+
+// Fused epilogues exist where the models use them: GATE on the WaveNet in_layers (k=3/5, d=1), SHUFFLE on the
+// polyphase transposed conv (k=2), COUPLE / RES_SKIP / COUPLE_AFFINE on 1x1 convs.
 template <int K, int D>
 int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
 {
-    const int mtiles = (a.c_out + 31) / 32;
-    if (a.mode == TTSAMD_CONV_GATE || a.mode == TTSAMD_CONV_COUPLE_AFFINE) {
-        if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2>(a, st);
-        return conv1d_launch_cfg<K, D, 2, 2, 1, 4>(a, st);
+    switch (a.mode) {
+        case TTSAMD_CONV_NORMAL: return conv1d_launch_tiles<K, D, TTSAMD_CONV_NORMAL>(a, st);
+        case TTSAMD_CONV_GATE:
+            if constexpr ((K == 3 || K == 5) && D == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_GATE>(a, st);
+            break;
+        case TTSAMD_CONV_SHUFFLE:
+            if constexpr (K == 2) return conv1d_launch_tiles<K, D, TTSAMD_CONV_SHUFFLE>(a, st);
+            break;
+        case TTSAMD_CONV_COUPLE:
+            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_COUPLE>(a, st);
+            break;
+        case TTSAMD_CONV_RES_SKIP:
+            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_RES_SKIP>(a, st);
+            break;
+        case TTSAMD_CONV_COUPLE_AFFINE:
+            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_COUPLE_AFFINE>(a, st);
+            break;
     }
-    if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2>(a, st);
-    if (mtiles % 2 == 0) return conv1d_launch_cfg<K, D, 2, 2, 1, 4>(a, st);
-    return conv1d_launch_cfg<K, D, 1, 2, 1, 4>(a, st);
+    return conv1d_mode_unsupported(a);
 }
 
 // one translation unit per kernel size (conv_k*.hip) so hipcc compiles them in parallel

@@ -41,6 +41,35 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
+class ConvTimer:
+    """Optional per-launch HIP-event timing of conv launches (bench.py's live roofline measurement).
+    Events are recorded on the stream the kernel is launched on (torch's current stream).  `select(pc, args)`
+    picks the launches to time; everything else runs untouched."""
+
+    def __init__(self, select):
+        self.select = select
+        self.records = []  # (key, flops, bytes, event0, event1)
+
+    def results(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, nbytes, e0, e1 in self.records:
+            r = out.setdefault(key, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+            r["launches"] += 1
+            r["flops"] += flops
+            r["bytes"] += nbytes
+            r["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+_TIMER = None
+
+
+def set_conv_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
 class PackedConv:
     """A conv layer's weights in MFMA fragment order on the device (+ bias in packed-row order)."""
 
@@ -96,6 +125,20 @@ def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, 
     if y2 is not None:
         a.y2, a.y2_bstride, a.y2_rstride = y2.data_ptr(), y2.shape[1] * y2.shape[2], y2.shape[2]
     a.split_row, a.row_bias = split_row, _dp(row_bias)
+    if _TIMER is not None:
+        key = _TIMER.select(pc, a)
+        if key is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().ttsamd_conv1d(ctypes.byref(a), stream_ptr()), "conv1d")
+            e1.record()
+            flops = 2.0 * pc.c_out * pc.c_in * pc.kernel * t_out * B
+            # algorithmic HBM bytes of this launch: input read once + output written once (+ residual / accumulate
+            # operands read once); weights excluded (L2-resident, amortised) — SURVEY.md §8(d)
+            n_out = pc.c_out * t_out * B
+            nbytes = 4.0 * (pc.c_in * T_in * B + n_out * (1 + (res is not None) + (accum is not None)))
+            _TIMER.records.append((key, flops, nbytes, e0, e1))
+            return y
     check(lib().ttsamd_conv1d(ctypes.byref(a), stream_ptr()), "conv1d")
     return y
 

@@ -1,0 +1,72 @@
+"""Multi-GPU: utterances are independent (the reference itself loops sentences, synthesizer.py:384), so
+the path shards as replicas — one process per GPU, a contiguous slab of utterances per rank, NO data-path
+collective.  The only exchange is a one-time broadcast of the weights from rank 0 (RCCL over xGMI on GPUs,
+gloo in the CPU tests): the whole reference-layout state_dict travels as ONE flat fp32 blob (~116 MB for
+VITS) instead of hundreds of small broadcasts — a single large transfer is what a point-to-point xGMI
+ring/tree wants.  SURVEY.md §8(e).
+"""
+import torch
+import torch.distributed as dist
+
+
+def flatten_state_dict(sd):
+    """-> (blob fp32 [N], manifest [(name, shape, dtype_str, offset, numel)]).  Non-float tensors are
+    carried as fp32 values (exact for the small integer buffers a checkpoint may hold)."""
+    manifest, parts, off = [], [], 0
+    for name in sorted(sd):
+        t = sd[name]
+        n = t.numel()
+        manifest.append((name, tuple(t.shape), str(t.dtype).replace("torch.", ""), off, n))
+        parts.append(t.detach().reshape(-1).to(torch.float32).cpu())
+        off += n
+    blob = torch.cat(parts) if parts else torch.zeros(0)
+    return blob, manifest
+
+
+def unflatten_state_dict(blob, manifest):
+    sd = {}
+    for name, shape, dtype, off, n in manifest:
+        sd[name] = blob[off:off + n].reshape(shape).to(getattr(torch, dtype)).cpu()
+    return sd
+
+
+def broadcast_state_dict(sd, src=0, device=None):
+    """Rank `src` passes its state_dict, the others pass None; every rank returns an identical CPU copy.
+    One object broadcast (the manifest, a few KB) + one tensor broadcast (the blob)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sd
+    rank = dist.get_rank()
+    if rank == src:
+        blob, manifest = flatten_state_dict(sd)
+        meta = [manifest]
+    else:
+        blob, meta = None, [None]
+    dist.broadcast_object_list(meta, src=src)
+    manifest = meta[0]
+    total = sum(m[4] for m in manifest)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if rank == src:
+        buf = blob.to(dev)
+    else:
+        buf = torch.empty(total, dtype=torch.float32, device=dev)
+    dist.broadcast(buf, src=src)
+    return unflatten_state_dict(buf.cpu(), manifest)
+
+
+def shard_range(n_items, rank=None, world_size=None):
+    """Contiguous slab [lo, hi) of `n_items` utterances owned by `rank` (sizes differ by at most one)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_length(lengths, world_size):
+    """Length-balanced partition: sort utterances by length (longest first) and deal them round-robin, so
+    every rank gets the same count (+-1) and a near-equal total number of frames.
+    -> list of index lists, one per rank."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    return [order[r::world_size] for r in range(world_size)]

@@ -153,7 +153,9 @@ class Vits:
         H = a.hidden_channels
         durations = aux_input.get("durations") if aux_input else None
         logw = None
-        if durations is None:
+        # the reference skips the duration predictor when durations are injected (vits.py:1124-1143);
+        # "run_duration_predictor" keeps it in the pass anyway (bench.py: fixed output length, no work skipped)
+        if durations is None or aux_input.get("run_duration_predictor"):
             if a.use_sdp:
                 noise_dp = aux_input.get("noise_dp") if aux_input else None
                 if noise_dp is None:
@@ -162,6 +164,7 @@ class Vits:
                                                self.inference_noise_scale_dp)
             else:
                 logw = self.duration_predictor(h, x_mask)
+        if durations is None:
             w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale))
         else:
             d = durations.to(dev, torch.float32).reshape(B, T).contiguous()       # vits.py:1141-1143 (+ batches)
