@@ -125,10 +125,12 @@ def main():
     for _ in range(args.warmup):
         out = step()
     # live roofline measurement: HIP events around every launch of the dominant kernel instantiation
-    # (ResBlock k=11 d=1 256->256 convs, conv1d_mfma_kernel<11,1,2,2,2,2>) and around all conv launches of the
+    # (ResBlock k=11 d=1 convs of the 256/128-channel stages, conv1d_mfma_kernel<11,1,2,2,2,2,0>) and around all conv launches of the
     # waveform decoder in aggregate, on the stream they are launched on, during the timed region.
     def select(pc, a):
-        if pc.kernel == 11 and pc.dilation == 1 and pc.c_out == 256 and pc.c_in == 256:
+        # every launch that dispatches to the instantiation conv1d_mfma_kernel<11,1,2,2,2,2,NORMAL> (128x128 tile):
+        # the ResBlock1 k=11 d=1 convs of the 256- and 128-channel MRF stages (8 per step)
+        if pc.kernel == 11 and pc.dilation == 1 and a.mode == 0 and ((pc.c_out + 31) // 32) % 4 == 0:
             return "dominant"
         # every other waveform-decoder / flow conv; the tiny text-side launches are left untouched
         return "other_conv" if 2.0 * pc.c_out * pc.c_in * pc.kernel * a.t_out * a.batch >= 1e9 else None
@@ -179,7 +181,7 @@ def main():
                        "utterances_per_gpu": args.batch, "chars": args.chars, "parallelism": "replicas x%d" % world,
                        "weights": "random-init VitsArgs defaults (29.1 M params), broadcast from rank 0 in %.3f s" % bcast_s},
             "roofline": {
-                "bound": "mfma", "kernel": "ttsamd::conv1d_mfma_kernel<11,1,2,2,2,2> (ResBlock1 k=11 d=1, 256->256)",
+                "bound": "mfma", "kernel": "ttsamd::conv1d_mfma_kernel<11,1,2,2,2,2,0> (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
                 "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                 "launches_timed": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
