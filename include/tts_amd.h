@@ -245,6 +245,27 @@ int ttsamd_expand_prior(float *z_p, float *z_p2, float *m_p, float *logs_p, floa
 int ttsamd_scale(float *y, const float *x, float s, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Glow-TTS decoder glue (HBM-bound permutations / 4-wide mixing; one pass each)
+ * ---------------------------------------------------------------------------------------- */
+/* squeeze (TTS/tts/layers/glow_tts/decoder.py:8-28): x [B,C,T] -> y [B,C*n,T/n] (an odd tail frame is dropped),
+ * y[b, s*C+c, t'] = x[b,c,t'*n+s] * mask[b, t'*n+n-1];  mask_out [B,T/n] = mask[:, n-1::n] (may be NULL). */
+int ttsamd_glow_squeeze(float *y, float *mask_out, const float *x, const float *mask, int batch, int c, int t, int n,
+                        void *stream);
+/* unsqueeze (decoder.py:31-47): x [B,Cq,Tq] -> y [B,Cq/n,t_out], y[b,c,t'*n+s] = x[b, s*(Cq/n)+c, t'] * mask_q[b,t'];
+ * columns >= Tq*n (the dropped odd frame) are written as zeros. */
+int ttsamd_glow_unsqueeze(float *y, const float *x, const float *mask_q, int batch, int cq, int tq, int n, int t_out,
+                          void *stream);
+/* InvConvNear reverse (TTS/tts/layers/glow_tts/glow.py:107-137, stored 4x4 inverse `w_inv` row-major) followed by
+ * ActNorm reverse (TTS/tts/layers/generic/normalization.py:98-101; bias/logs [C], or both NULL to skip), IN PLACE
+ * on x [B,C,T]:  z = (w_inv . x_group) * mask;  x = (z - bias) * exp(-logs) * mask.   num_splits must be 4. */
+int ttsamd_glow_invconv_actnorm(float *x, const float *w_inv, const float *bias, const float *logs, const float *mask,
+                                int batch, int c, int t, int num_splits, void *stream);
+/* o_attn_dur = log(1 + sum_y attn[b,x,y]) * x_mask (GlowTTS.compute_outputs, TTS/tts/models/glow_tts.py:147), with
+ * the row sums taken from the cumulative durations.  o [B,T_x]. */
+int ttsamd_attn_durations(float *o, const int32_t *cum, const float *x_mask, const int64_t *y_lengths, int batch,
+                          int t_x, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Small streaming kernels (HBM-bound; coalesced, one pass)
  * ---------------------------------------------------------------------------------------- */
 /* y[b,c,:] = F.pad(x[b,c,:], (pad,pad), "replicate")  — HifiganGenerator.inference,

@@ -1,0 +1,124 @@
+"""GPU parity: tts_amd.GlowTTS / tts_amd.GAN (HIP) vs the CPU oracle (oracle/tts_oracle.py) and vs the golden fixtures
+generated from the real reference modules.  Mel tolerance: 1e-5 relative RMS; durations / alignments exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tts_oracle as O
+from oracle import weights as W
+from tts_amd import layers, ops
+from tts_amd.gan import GAN
+from tts_amd.glow_tts import GlowTTS
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+def _model(args, sd, gpu):
+    m = GlowTTS(dict(args, num_chars=130))
+    m.load_state_dict(sd)
+    return m.to(gpu)
+
+
+def test_glow_squeeze_invconv_unsqueeze(gpu):
+    g = torch.Generator().manual_seed(0)
+    B, C, T = 2, 80, 31
+    x = torch.randn(B, C, T, generator=g)
+    mask = (torch.arange(T)[None] < torch.tensor([31, 18])[:, None]).float()
+    xs, ms = O.glow_squeeze(x, mask[:, None], 2)
+    got, gm = ops.glow_squeeze(x.to(gpu), mask.to(gpu), 2)
+    assert torch.equal(got.cpu(), xs) and torch.equal(gm.cpu(), ms[:, 0])
+    w = torch.linalg.qr(torch.randn(4, 4, generator=g))[0] + 0.1 * torch.randn(4, 4, generator=g)
+    bias, logs = 0.1 * torch.randn(160, generator=g), 0.1 * torch.randn(160, generator=g)
+    b, c, t = xs.shape
+    xx = xs.view(b, 2, c // 4, 2, t).permute(0, 1, 3, 2, 4).contiguous().view(b, 4, c // 4, t)
+    z = torch.nn.functional.conv2d(xx, w.view(4, 4, 1, 1))
+    z = z.view(b, 2, 2, c // 4, t).permute(0, 1, 3, 2, 4).contiguous().view(b, c, t) * ms
+    want = (z - bias.view(1, -1, 1)) * torch.exp(-logs.view(1, -1, 1)) * ms
+    ops.glow_invconv_actnorm(got, w.contiguous().to(gpu), bias.to(gpu), logs.to(gpu), gm, 4)
+    assert _rel(got, want) < 1e-6
+    xu, _ = O.glow_unsqueeze(want, ms, 2)
+    gu = ops.glow_unsqueeze(got, gm, 2, 30)
+    assert _rel(gu, xu) < 1e-6 and gu.shape == (B, C, 30)
+
+
+@pytest.mark.parametrize("variant", ["default", "relwin", "not_mean_only"])
+def test_glow_inference_matches_oracle(gpu, variant):
+    torch.set_num_threads(8)
+    args = dict(num_flow_blocks_dec=3, inference_noise_scale=0.4)
+    args["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    if variant == "relwin":
+        args["encoder_params"].update(rel_attn_window_size=4, layer_norm_type="2")
+    if variant == "not_mean_only":
+        args["mean_only"] = False
+    sd = W.make_glow_state(args, seed=31)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 130, (3, 26), generator=g)
+    xl = torch.tensor([26, 19, 4])
+    pre = O.glow_tts_inference(sd, x, xl, dict(args, num_flow_blocks_dec=0, inference_noise_scale=0.0))
+    t_dec = int(pre["y_lengths"].max())
+    noise = torch.randn(3, 80, t_dec, generator=g)
+    want = O.glow_tts_inference(sd, x, xl, args, noise=noise)
+    m = _model(args, sd, gpu)
+    out = m.inference(x.to(gpu), {"x_lengths": xl.to(gpu), "noise": noise.to(gpu)})
+    assert _rel(out["durations_log"], want["durations_log"]) < 1e-5
+    assert torch.equal(out["alignments"].cpu(), want["alignments"]), "paths differ (ceil cliff?)"
+    assert _rel(out["y_mean"], want["y_mean"]) < 1e-5
+    assert out["model_outputs"].shape == want["model_outputs"].shape
+    assert _rel(out["model_outputs"], want["model_outputs"]) < 1e-5
+    tot = torch.log(1 + want["alignments"].permute(0, 2, 1).sum(-1)) * O.sequence_mask(xl, 26).float()
+    assert _rel(out["total_durations_log"][:, :, 0], tot) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["glow_small", "glow_small_relwin"])
+def test_glow_matches_reference_golden(gpu, name):
+    from tests.golden import cases
+
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    args = dict(cases.GLOW_SMALL)
+    window, ln = (4, "2") if name.endswith("relwin") else (None, "1")
+    args["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], rel_attn_window_size=window, layer_norm_type=ln,
+                                  num_layers=3)
+    sd = W.make_glow_state(args, seed=4321)
+    x = torch.randint(0, 130, (2, 29), generator=torch.Generator().manual_seed(1))
+    xl = torch.tensor([29, 20])
+    t_dec = gold["y_mean"].shape[1]
+    torch.manual_seed(3)   # randn_like(y_mean): y_mean is a transposed matmul result (strides of [B,T,C])
+    noise = torch.randn_like(torch.empty(2, t_dec, 80).transpose(1, 2))
+    m = _model(args, sd, gpu)
+    out = m.inference(x.to(gpu), {"x_lengths": xl.to(gpu), "noise": noise.to(gpu)})
+    assert _rel(out["durations_log"], torch.from_numpy(gold["durations_log"])) < 1e-5
+    assert _rel(out["y_mean"], torch.from_numpy(gold["y_mean"])) < 1e-5
+    assert _rel(out["model_outputs"], torch.from_numpy(gold["model_outputs"])) < 1e-5
+
+
+def test_gan_wrapper_matches_oracle(gpu):
+    """GAN.init_from_config -> HifiganGenerator(num_mels, 1, **generator_model_params); state_dict with model_g./model_d.
+    prefixes as a training checkpoint has them (gan.py:229-252)."""
+    cfg = dict(W.HIFIGAN_V2)
+    sd = O.make_hifigan_state(cfg, 80, seed=3)
+    full = {"model_g." + k: v for k, v in sd.items()}
+    full["model_d.dummy.weight"] = torch.zeros(3)
+    conf = {"generator_model": "hifigan_generator", "discriminator_model": "hifigan_discriminator",
+            "audio": {"num_mels": 80, "sample_rate": 22050},
+            "generator_model_params": {k: cfg[k] for k in ("upsample_factors", "upsample_kernel_sizes",
+                                                           "upsample_initial_channel", "resblock_kernel_sizes",
+                                                           "resblock_dilation_sizes", "resblock_type")}}
+    v = GAN.init_from_config(conf)
+    v.load_state_dict(full)
+    v.cuda()
+    mel = torch.randn(1, 80, 37, generator=torch.Generator().manual_seed(4))
+    want = O.hifigan_inference(sd, "", mel, cfg)
+    got = v.inference(mel.to(gpu))
+    assert got.shape == want.shape == (1, 1, 47 * 256)
+    a, b = got.double().cpu(), want.double()
+    rms = float((a - b).pow(2).mean().sqrt())
+    assert rms < 1e-4 and rms / float(b.pow(2).mean().sqrt()) < 1e-5
+    assert next(v.parameters()).is_cuda

@@ -1,0 +1,125 @@
+"""Glow-TTS on hand-written HIP kernels — drop-in for the inference surface of
+`TTS.tts.models.glow_tts.GlowTTS` (glow_tts.py:59-105 wiring, :341-374 inference, :519-530 store_inverse /
+load_checkpoint, :541-557 init_from_config).  Config field names/defaults: GlowTTSConfig
+(TTS/tts/configs/glow_tts_config.py:101-152).  Single-speaker (LJSpeech) path; training is out of scope.
+"""
+import torch
+
+from . import _lib, layers, ops
+from .vits import _Args, _get
+
+GLOW_DEFAULTS = dict(  # glow_tts_config.py:101-152
+    num_chars=None, encoder_type="rel_pos_transformer",
+    encoder_params=dict(kernel_size=3, dropout_p=0.1, num_layers=6, num_heads=2, hidden_channels_ffn=768,
+                        input_length=None),
+    use_encoder_prenet=True, hidden_channels_enc=192, hidden_channels_dec=192, hidden_channels_dp=256,
+    dropout_p_dp=0.1, dropout_p_dec=0.05, mean_only=True, out_channels=80, num_flow_blocks_dec=12,
+    inference_noise_scale=0.0, kernel_size_dec=5, dilation_rate=1, num_block_layers=4, num_speakers=0,
+    c_in_channels=0, num_splits=4, num_squeeze=2, sigmoid_scale=False, d_vector_dim=0, length_scale=1.0,
+    use_speaker_embedding=False, use_d_vector_file=False,
+)
+
+
+class GlowTTS:
+    def __init__(self, config=None, ap=None, tokenizer=None, speaker_manager=None):
+        self.config = config
+        self.args = _Args(GLOW_DEFAULTS)
+        for k in GLOW_DEFAULTS:
+            v = _get(config, k, None)
+            if v is not None:
+                self.args[k] = v
+        a = self.args
+        for k, v in a.items():      # "pass all config fields to self" (glow_tts.py:69-72)
+            setattr(self, k, v)
+        self.ap, self.tokenizer, self.speaker_manager, self.language_manager = ap, tokenizer, speaker_manager, None
+        self.decoder_output_dim = a.out_channels
+        if a.encoder_type != "rel_pos_transformer":
+            raise _lib.TtsAmdError("tts_amd.GlowTTS: only encoder_type='rel_pos_transformer' (the config default) is built")
+        if a.use_speaker_embedding or a.use_d_vector_file:
+            raise _lib.TtsAmdError("tts_amd.GlowTTS: multi-speaker conditioning is not built (LJSpeech path only)")
+        if a.num_chars is None and tokenizer is not None:
+            a.num_chars = tokenizer.characters.num_chars
+        self.device = torch.device("cpu")
+        self._sd = None
+        self.encoder = self.decoder = None
+
+    @staticmethod
+    def init_from_config(config, samples=None, verbose=True):
+        return GlowTTS(config, ap=_get(config, "_ap", None), tokenizer=_get(config, "_tokenizer", None))
+
+    def parameters(self):
+        return iter([self.encoder.emb] if self.encoder is not None else [])
+
+    def eval(self):
+        return self
+
+    def store_inverse(self):  # done at pack time (4x4 inverses + weight-norm folding)
+        pass
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self._sd is not None:
+            self._pack()
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        self._sd = {k: v.detach().cpu() for k, v in sd.items()}
+        if self.device.type == "cuda":
+            self._pack()
+
+    def load_checkpoint(self, config, checkpoint_path, eval=False):  # noqa: A002
+        state = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        self.load_state_dict(state["model"])
+
+    def _pack(self):
+        if self.device.type != "cuda":
+            raise _lib.TtsAmdError("tts_amd.GlowTTS runs only on a GPU (no CPU fallback)")
+        a, sd, dev = self.args, self._sd, self.device
+        self.encoder = layers.GlowEncoder(sd, "encoder.", dev, a.hidden_channels_enc, a.out_channels, a.encoder_params,
+                                          a.mean_only, a.use_encoder_prenet)
+        self.decoder = layers.GlowDecoder(sd, "decoder.", dev, a.out_channels, a.hidden_channels_dec, a.kernel_size_dec,
+                                          a.dilation_rate, a.num_flow_blocks_dec, a.num_block_layers, a.num_splits,
+                                          a.num_squeeze, a.sigmoid_scale)
+
+    @torch.no_grad()
+    def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None}):  # noqa: B006
+        """glow_tts.py:341-374.  Optional aux key "noise" [B,C,T_dec] pins the randn_like(y_mean) draw."""
+        if self.encoder is None:
+            raise _lib.TtsAmdError("tts_amd.GlowTTS: no weights loaded / not moved to the GPU")
+        _lib.require_gpu(x, "x")
+        a = self.args
+        dev = x.device
+        x = x.to(torch.int64).contiguous()
+        B, T = x.shape
+        x_lengths = aux_input.get("x_lengths") if aux_input else None
+        if x_lengths is None:
+            x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+        x_mask = ops.sequence_mask(x_lengths.to(dev), T)
+        o_mean, o_logs, logw = self.encoder(x, x_mask)
+        w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), glow=True)
+        t_dec = int(y_lengths.max().item())
+        noise = aux_input.get("noise") if aux_input else None
+        C = a.out_channels
+        if noise is None and self.inference_noise_scale != 0.0:
+            noise = torch.randn(B, C, t_dec, device=dev, dtype=torch.float32)
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+        pri = ops.expand_prior(o_mean, o_logs, noise, cum, x_mask, y_lengths, t_dec, float(self.inference_noise_scale),
+                               mask_out=True)
+        attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)
+        y = self.decoder(pri["z_p"], pri["y_mask"])
+        y_log_scale = pri["logs_p"]
+        return {
+            "model_outputs": y.transpose(1, 2),
+            "logdet": None,
+            "y_mean": pri["m_p"].transpose(1, 2),
+            "y_log_scale": y_log_scale.transpose(1, 2),
+            "alignments": attn.permute(0, 2, 1),
+            "durations_log": logw.unsqueeze(1).transpose(1, 2),
+            "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
+        }
+
+    __call__ = inference

@@ -301,3 +301,100 @@ class ResidualCouplingBlocks:
             # x1 = (x1 - post(h) * mask) * mask   (mean_only: exp(-log_scale) == 1), in place on the other half
             ops.conv1d(F_["post"], out, z, mode=CONV_COUPLE, res=z, res_row_offset=dst, y_row_offset=dst, out_mask=mask)
         return z
+
+
+# ------------------------------------------------------------------------------------------------
+# Glow-TTS encoder — TTS/tts/layers/glow_tts/encoder.py:15-179 (rel_pos_transformer type)
+# ------------------------------------------------------------------------------------------------
+class GlowEncoder:
+    def __init__(self, sd, p, device, hidden, out_channels, encoder_params, mean_only=True, use_prenet=True):
+        self.hidden, self.out_channels, self.mean_only = hidden, out_channels, mean_only
+        self.emb = _dev(sd[p + "emb.weight"], device)
+        self.prenet = None
+        if use_prenet:  # ResidualConv1dLayerNormBlock(hidden, hidden, hidden, kernel 5, 3 layers), glow.py:11-67
+            self.prenet = dict(
+                convs=[PackedConv(sd[p + "prenet.conv_layers.%d.weight" % i], sd[p + "prenet.conv_layers.%d.bias" % i],
+                                  device) for i in range(3)],
+                norms=[_Norm(sd, p + "prenet.norm_layers.%d" % i, device, 1e-4) for i in range(3)],
+                proj=PackedConv(sd[p + "prenet.proj.weight"], sd[p + "prenet.proj.bias"], device))
+        ep = encoder_params
+        self.encoder = RelativePositionTransformer(sd, p + "encoder.", device, ep["num_layers"], ep["num_heads"],
+                                                   ep["kernel_size"], ep.get("rel_attn_window_size"),
+                                                   ep.get("layer_norm_type", "1"))
+        self.proj_m = PackedConv(sd[p + "proj_m.weight"], sd[p + "proj_m.bias"], device)
+        self.proj_s = None if mean_only else PackedConv(sd[p + "proj_s.weight"], sd[p + "proj_s.bias"], device)
+        self.duration_predictor = DurationPredictor(sd, p + "duration_predictor.", device)
+
+    def __call__(self, tokens, x_mask):
+        """-> o_mean [B,80,T], o_log_scale [B,80,T] or None (mean_only: zeros), logw [B,T]   (encoder.py:143-179)."""
+        B, T = tokens.shape
+        x = torch.empty((B, self.hidden, T), dtype=torch.float32, device=tokens.device)
+        ops.embed(tokens, self.emb, x_mask, math.sqrt(self.hidden), x)   # masked here; every consumer masks anyway
+        if self.prenet is not None:
+            h = x
+            for conv, nrm in zip(self.prenet["convs"], self.prenet["norms"]):
+                c = _new(x)
+                ops.conv1d(conv, h, c, in_mask=x_mask, out_mask=x_mask)
+                h = ops.channel_norm(c, _new(x), nrm.gamma, nrm.beta, nrm.eps, act=ACT_RELU)
+            x2 = _new(x)
+            ops.conv1d(self.prenet["proj"], h, x2, res=x, out_mask=x_mask)
+            x = x2
+        x = self.encoder(x, x_mask)
+        o_mean = _new(x, self.out_channels)
+        ops.conv1d(self.proj_m, x, o_mean, out_mask=x_mask)
+        o_logs = None
+        if self.proj_s is not None:
+            o_logs = _new(x, self.out_channels)
+            ops.conv1d(self.proj_s, x, o_logs, out_mask=x_mask)
+        logw = self.duration_predictor(x, x_mask)
+        return o_mean, o_logs, logw
+
+
+# ------------------------------------------------------------------------------------------------
+# Glow-TTS decoder (reverse) — TTS/tts/layers/glow_tts/decoder.py:50-141, glow.py:70-233
+# ------------------------------------------------------------------------------------------------
+class GlowDecoder:
+    def __init__(self, sd, p, device, in_channels, hidden, kernel_size, dilation_rate, num_flow_blocks,
+                 num_coupling_layers, num_splits=4, num_squeeze=2, sigmoid_scale=False):
+        if sigmoid_scale:
+            raise ops._lib.TtsAmdError("GlowDecoder: sigmoid_scale=True has no HIP epilogue (GlowTTSConfig default is False)")
+        self.nsq, self.ns = num_squeeze, num_splits
+        c = in_channels * num_squeeze
+        self.c, self.half, self.hidden = c, c // 2, hidden
+        half = self.half
+        ntile = (half + 31) // 32
+        self.blocks = []
+        for b in range(num_flow_blocks):
+            pa, pi, pc = (p + "flows.%d." % (3 * b + j) for j in range(3))
+            w_end, b_end = sd[pc + "end.weight"].float(), sd[pc + "end.bias"].float()   # [c, hidden, 1]: t rows | s rows
+            # pair-tile packing for the COUPLE_AFFINE epilogue: tile 2a = t rows [32a, 32a+32), tile 2a+1 = s rows
+            wp = torch.zeros(64 * ntile, w_end.shape[1], 1)
+            bp = torch.zeros(64 * ntile)
+            for a in range(ntile):
+                n = min(32, half - 32 * a)
+                wp[64 * a: 64 * a + n] = w_end[32 * a: 32 * a + n]
+                wp[64 * a + 32: 64 * a + 32 + n] = w_end[half + 32 * a: half + 32 * a + n]
+                bp[64 * a: 64 * a + n] = b_end[32 * a: 32 * a + n]
+                bp[64 * a + 32: 64 * a + 32 + n] = b_end[half + 32 * a: half + 32 * a + n]
+            w_inv = sd[pi + "weight_inv"] if (pi + "weight_inv") in sd else torch.inverse(sd[pi + "weight"].float())
+            self.blocks.append(dict(
+                start=PackedConv(fold_weight_norm(sd, pc + "start"), sd[pc + "start.bias"], device),
+                wn=WN(sd, pc + "wn.", device, hidden, kernel_size, dilation_rate, num_coupling_layers),
+                end=PackedConv(wp, bp, device),
+                w_inv=_dev(w_inv.reshape(num_splits, num_splits), device),     # store_inverse(), glow.py:139-141
+                an_bias=_dev(sd[pa + "bias"].reshape(-1), device), an_logs=_dev(sd[pa + "logs"].reshape(-1), device)))
+
+    def __call__(self, z, y_mask):
+        """z [B,C,T] (masked), y_mask [B,T] -> mel [B,C,T]; reverse pass: for every block (last to first)
+        CouplingBlock^-1, InvConvNear^-1, ActNorm^-1, all in place on the squeezed buffer."""
+        B, C, T = z.shape
+        x, mq = ops.glow_squeeze(z, y_mask, self.nsq)
+        h = _new(x, self.hidden)
+        out = _new(x, self.hidden)
+        for blk in reversed(self.blocks):
+            ops.conv1d(blk["start"], x, h, out_mask=mq)                       # start(x0) * mask   (x0 = first half)
+            blk["wn"](h, mq, out)
+            ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE, res=x, res_row_offset=self.half,
+                       y_row_offset=self.half, out_mask=mq, split_row=self.half)
+            ops.glow_invconv_actnorm(x, blk["w_inv"], blk["an_bias"], blk["an_logs"], mq, self.ns)
+        return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)

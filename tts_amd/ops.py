@@ -327,3 +327,35 @@ def scale(x, s):
     y = torch.empty_like(x)
     check(lib().ttsamd_scale(P(y), P(x.contiguous()), ctypes.c_float(s), ctypes.c_int64(x.numel()), stream_ptr()), "scale")
     return y
+
+
+def glow_squeeze(x, mask, n):
+    """decoder.py:8-28 -> (x_sqz [B,C*n,T//n], mask_sqz [B,T//n])."""
+    B, C, T = x.shape
+    Tq = T // n
+    y = torch.empty((B, C * n, Tq), dtype=torch.float32, device=x.device)
+    mq = torch.empty((B, Tq), dtype=torch.float32, device=x.device)
+    check(lib().ttsamd_glow_squeeze(P(y), P(mq), P(x), P(mask), B, C, T, n, stream_ptr()), "glow_squeeze")
+    return y, mq
+
+
+def glow_unsqueeze(x, mask_q, n, t_out):
+    """decoder.py:31-47 -> [B, Cq//n, t_out] (t_out >= Tq*n; an odd dropped frame comes back as zeros)."""
+    B, Cq, Tq = x.shape
+    y = torch.empty((B, Cq // n, t_out), dtype=torch.float32, device=x.device)
+    check(lib().ttsamd_glow_unsqueeze(P(y), P(x), P(mask_q), B, Cq, Tq, n, t_out, stream_ptr()), "glow_unsqueeze")
+    return y
+
+
+def glow_invconv_actnorm(x, w_inv, bias, logs, mask, num_splits=4):
+    B, C, T = x.shape
+    check(lib().ttsamd_glow_invconv_actnorm(P(x), P(w_inv), P(bias), P(logs), P(mask), B, C, T, num_splits,
+                                            stream_ptr()), "glow_invconv_actnorm")
+    return x
+
+
+def attn_durations(cum, x_mask, y_lengths):
+    B, Tx = cum.shape
+    o = torch.empty((B, Tx), dtype=torch.float32, device=cum.device)
+    check(lib().ttsamd_attn_durations(P(o), P(cum), P(x_mask), P(y_lengths), B, Tx, stream_ptr()), "attn_durations")
+    return o
