@@ -61,6 +61,13 @@ int ttsamd_maximum_path(void *paths, const float *values_in, const float *mask, 
                         float max_neg_val, void *workspace, size_t workspace_bytes, int flags,
                         void *stream);
 
+/* Log-likelihood matrix feeding MAS — replaces the einsum/matmul block of Vits.forward_mas (TTS/tts/models/vits.py:912-918;
+ * glow_order=0: logp2+logp3+logp1+logp4) and of GlowTTS.forward / inference_with_MAS (TTS/tts/models/glow_tts.py:241-247,
+ * 291-296; glow_order=1: logp1+logp2+logp3+logp4).  z [B,C,T_y] (latent), m / logs [B,C,T_x] (text-side prior stats)
+ * -> logp [B,T_x,T_y], ready for ttsamd_maximum_path on the device. */
+int ttsamd_mas_logp(float *logp, const float *z, const float *m, const float *logs, int batch, int c, int t_x, int t_y,
+                    int glow_order, void *stream);
+
 /* t_xs[i] = sum_x mask[i,x,0], t_ys[i] = sum_y mask[i,0,y]   (helpers.py:191-192). */
 int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, int t_x, int t_y,
                         void *stream);
@@ -219,6 +226,8 @@ int ttsamd_sdp_affine_reverse(float *z_out, const float *z_in, const float *m, c
  * VITS (vits.py:1140-1146):   w = exp(logw) * mask * length_scale;  w_ceil = ceil(w)
  * Glow (glow_tts.py:350-352): w = (exp(logw) - 1) * mask * length_scale;  w_ceil = max(ceil(w), 1)   [glow != 0]
  *   durations [B,T] float (= w_ceil), cum [B,T] int32 inclusive cumsum, y_lengths int64 [B] = max(sum, 1).
+ *   glow == 2: as Glow but padded tokens get 0 frames (w_ceil *= mask) — the reference counts one frame per PADDED token
+ *   into y_lengths when batching; 2 makes a padded batch reproduce the per-sentence results.
  * `durations_in` (may be NULL) overrides w_ceil (logw ignored). */
 int ttsamd_durations(float *durations, int32_t *cum, int64_t *y_lengths, const float *logw,
                      const float *durations_in, const float *mask, float length_scale, int glow, int batch,
@@ -271,6 +280,24 @@ int ttsamd_attn_durations(float *o, const int32_t *cum, const float *x_mask, con
 /* y[b,c,:] = F.pad(x[b,c,:], (pad,pad), "replicate")  — HifiganGenerator.inference,
  * TTS/vocoder/models/hifigan_generator.py:281.  x [rows, t], y [rows, t + 2*pad]. */
 int ttsamd_replicate_pad(float *y, const float *x, int64_t rows, int t, int pad, void *stream);
+/* Ragged-batch form: item b of x [B,C,t] holds lengths[b] valid frames; y [B,C,t+2*pad] replicates item b's OWN first
+ * and last valid frame (y[b,c,i] = x[b,c,clamp(i-pad, 0, lengths[b]-1)]), so that a padded batch reproduces what the
+ * reference computes sentence by sentence (synthesizer.py:384). */
+int ttsamd_replicate_pad_ragged(float *y, const float *x, const int64_t *lengths, int batch, int c, int t, int pad,
+                                void *stream);
+
+/* The Synthesizer's Glow-TTS -> vocoder seam on the device: `vocoder_ap.normalize(tts_ap.denormalize(mel))`
+ * (TTS/utils/synthesizer.py:412-416; AudioProcessor.normalize / denormalize, TTS/utils/audio/processor.py:259-336;
+ * StandardScaler, TTS/tts/utils/helpers.py:14-39) — the reference does this in numpy after a D2H copy and copies the
+ * result back.  x, y [B, C, T]; same op order as the numpy code, fp32.  `mean`/`scale` ([C] device pointers, both
+ * or neither) select the mean-variance scaler path (`stats_path` models). */
+typedef struct ttsamd_mel_norm {
+    int32_t signal_norm, symmetric_norm, clip_norm;
+    float max_norm, min_level_db, ref_level_db;
+    const float *mean, *scale;
+} ttsamd_mel_norm;
+int ttsamd_mel_renorm(float *y, const float *x, const ttsamd_mel_norm *tts /* host */,
+                      const ttsamd_mel_norm *voc /* host */, int batch, int c, int t, void *stream);
 
 #ifdef __cplusplus
 }

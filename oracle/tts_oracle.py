@@ -595,6 +595,16 @@ def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None):
             "y_lengths": y_lengths}
 
 
+def mas_logp(z, m, logs, glow_order=False):
+    """vits.py:912-918 (glow_tts.py:241-247 when glow_order): log-likelihood matrix [B,T_x,T_y] fed to MAS."""
+    o_scale = torch.exp(-2 * logs)
+    logp1 = torch.sum(-0.5 * math.log(2 * math.pi) - logs, [1]).unsqueeze(-1)
+    logp2 = torch.einsum("klm, kln -> kmn", [o_scale, -0.5 * (z ** 2)])
+    logp3 = torch.einsum("klm, kln -> kmn", [m * o_scale, z])
+    logp4 = torch.sum(-0.5 * (m ** 2) * o_scale, [1]).unsqueeze(-1)
+    return (logp1 + logp2 + logp3 + logp4) if glow_order else (logp2 + logp3 + logp1 + logp4)
+
+
 # ----------------------------------------------------------------------------------------------
 # seeded weight factory: lives in the product package (bench.py needs synthetic checkpoints too and may not
 # import oracle/); re-exported here for the tests.

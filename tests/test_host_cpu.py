@@ -1,0 +1,72 @@
+"""CPU tests of the host-side mirrors that carry no kernels: grapheme tokenizer (known answers from
+TTS/tts/utils/text/characters.py:280-291 + tokenizer.py:87-134), AudioProcessor (de)normalisation arithmetic
+(processor.py:259-336, defaults shared_configs.py:126-153), sentence splitting, config loading, and that the
+product package never imports the oracle."""
+import json
+import os
+import re
+
+import numpy as np
+
+from tts_amd.audio import AudioProcessor
+from tts_amd.synthesizer import Synthesizer, load_config
+from tts_amd.text import Graphemes, TTSTokenizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_grapheme_vocab_and_tokenizer_known_answers():
+    g = Graphemes()
+    assert g.vocab[:4] == ["<PAD>", "<EOS>", "<BOS>", "<BLNK>"] and g.num_chars == 67
+    assert (g.char_to_id("A"), g.char_to_id("a"), g.char_to_id("!"), g.char_to_id(" ")) == (4, 30, 56, 66)
+    assert (g.pad_id, g.eos_id, g.bos_id, g.blank_id) == (0, 1, 2, 3)
+    t = TTSTokenizer(add_blank=False)
+    assert t.text_to_ids("Ab!") == [30, 31, 56]
+    assert t.text_to_ids("a  b\n") == [30, 66, 31]                       # whitespace collapsed, stripped
+    tb = TTSTokenizer(add_blank=True, use_eos_bos=True)
+    assert tb.text_to_ids("ab") == [2, 3, 30, 3, 31, 3, 1]               # blank interspersed (2n+1), then bos/eos
+    assert t.text_to_ids("a#b") == [30, 31] and t.not_found_characters == ["#"]
+    tok, _ = TTSTokenizer.init_from_config({"add_blank": True, "characters": {"characters": "ba", "punctuations": ".",
+                                                                              "pad": "_", "eos": "", "bos": "", "blank": "~"}})
+    assert tok.characters.vocab == ["_", "~", "a", "b", "."] and tok.text_to_ids("b.") == [1, 3, 1, 4, 1]
+
+
+def test_audio_processor_norm_denorm_known_answers():
+    ap = AudioProcessor()
+    S = np.array([[-5.0, -4.0, 0.0, 4.0, 7.0]], np.float32)
+    d = ap.denormalize(S)
+    assert np.allclose(d, [[-80.0, -80.0, -30.0, 20.0, 20.0]])           # clip to +-4, ((S+4)*100/8)-100+20
+    assert np.allclose(ap.normalize(d), np.clip(S, -4, 4))
+    ap2 = AudioProcessor(symmetric_norm=False, max_norm=1.0, clip_norm=True)
+    assert np.allclose(ap2.normalize(np.array([[20.0, -80.0, -200.0]], np.float32)), [[1.0, 0.0, 0.0]])
+    assert np.allclose(ap2.denormalize(np.array([[1.0, 0.5]], np.float32)), [[20.0, -30.0]])
+    ap3 = AudioProcessor(signal_norm=False)
+    assert np.array_equal(ap3.normalize(S), S) and np.array_equal(ap3.denormalize(S), S)
+    wav = np.concatenate([0.5 * np.ones(30000, np.float32), np.zeros(40000, np.float32)])
+    assert ap.find_endpoint(wav) < 40000 and ap.find_endpoint(0.5 * np.ones(50000, np.float32)) == 50000
+
+
+def test_mean_var_scaler_path(tmp_path):
+    stats = {"mel_mean": np.arange(3, dtype=np.float32), "mel_std": np.array([1.0, 2.0, 4.0], np.float32)}
+    p = str(tmp_path / "scale_stats.npy")
+    np.save(p, stats, allow_pickle=True)
+    ap = AudioProcessor(stats_path=p, num_mels=3)
+    S = np.array([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]], np.float32)
+    n = ap.normalize(S)
+    assert np.allclose(n, [[1.0, 2.0], [1.0, 1.5], [0.75, 1.0]]) and np.allclose(ap.denormalize(n), S)
+
+
+def test_split_sentences_and_config_loading(tmp_path):
+    assert Synthesizer.split_into_sentences("Hello there. How are you? Fine!") == ["Hello there.", "How are you?", "Fine!"]
+    assert Synthesizer.split_into_sentences("No punctuation") == ["No punctuation"]
+    p = str(tmp_path / "c.json")
+    open(p, "w").write('{\n // a comment\n "model": "vits", "audio": {"sample_rate": 22050}\n}\n')
+    assert load_config(p)["model"] == "vits"
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tts_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f

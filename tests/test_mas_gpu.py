@@ -71,3 +71,30 @@ def test_full_size_property(gpu):
         rows = got[i].argmax(0)[: ty[i]]
         assert rows[0] == 0 and rows[-1] == tx[i] - 1
         assert ((np.diff(rows) == 0) | (np.diff(rows) == 1)).all()
+
+
+def test_mas_logp_and_attention_match_oracle(gpu):
+    """vits.py:909-919: logp from (z_p, m_p, logs_p) then maximum_path — logp to fp32 tolerance, and the path
+    bit-exact with the CPU MAS oracle run on the SAME logp (MAS is exact given its input)."""
+    import torch
+
+    from oracle import tts_oracle as O
+
+    g = torch.Generator().manual_seed(11)
+    B, C, Tx, Ty = 3, 192, 45, 131
+    z = torch.randn(B, C, Ty, generator=g)
+    m = torch.randn(B, C, Tx, generator=g)
+    logs = 0.3 * torch.randn(B, C, Tx, generator=g)
+    for glow in (False, True):
+        want = O.mas_logp(z, m, logs, glow)
+        got = helpers.mas_logp(z.to(gpu), m.to(gpu), logs.to(gpu), glow)
+        rel = float((got.cpu().double() - want.double()).pow(2).mean().sqrt() / want.double().pow(2).mean().sqrt())
+        assert rel < 1e-6, rel
+    xl, yl = np.array([45, 30, 7], np.int32), np.array([131, 100, 9], np.int32)
+    xm = torch.from_numpy(mas.sequence_mask(xl, Tx)).float()
+    ym = torch.from_numpy(mas.sequence_mask(yl, Ty)).float()
+    attn = helpers.mas_attention(z.to(gpu), m.to(gpu), logs.to(gpu), xm.to(gpu), ym.unsqueeze(1).to(gpu))
+    mask = (xm[:, :, None] * ym[:, None, :]).numpy()
+    ref = mas.maximum_path(got.cpu().numpy(), mask, "c")
+    assert np.array_equal(attn.cpu().numpy().astype(np.int32), ref)
+    assert np.array_equal(attn.sum(1).cpu().numpy(), ym.numpy())      # every valid frame is aligned to exactly one token

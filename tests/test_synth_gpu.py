@@ -1,0 +1,92 @@
+"""GPU end-to-end: Synthesizer / TTS.tts_to_file over the HIP models (BASELINE config 1 shape: Glow-TTS +
+HiFiGAN-v2 through the mel seam; and VITS), checked against the oracle pipeline with the reference's numpy seam
+(synthesizer.py:412-429).  Checkpoints are synthetic `{"model": state_dict}` files + reference-style JSON configs."""
+import json
+
+import numpy as np
+import pytest
+import scipy.io.wavfile
+import torch
+
+from oracle import tts_oracle as O
+from oracle import weights as W
+from tts_amd.api import TTS
+from tts_amd.audio import AudioProcessor, mel_renorm_device
+from tts_amd.synthesizer import Synthesizer
+
+pytestmark = pytest.mark.gpu
+
+
+def _write(tmp_path, name, sd, cfg):
+    ck, cf = str(tmp_path / (name + ".pth")), str(tmp_path / (name + ".json"))
+    torch.save({"model": sd}, ck)
+    json.dump(cfg, open(cf, "w"))
+    return ck, cf
+
+
+def test_mel_renorm_device_matches_numpy(gpu, tmp_path):
+    g = torch.Generator().manual_seed(0)
+    mel = 5.0 * torch.randn(2, 80, 37, generator=g)
+    a, b = AudioProcessor(), AudioProcessor(max_norm=2.0, ref_level_db=10, min_level_db=-90)
+    want = np.stack([b.normalize(a.denormalize(m.numpy())) for m in mel])
+    got = mel_renorm_device(mel.to(gpu), a, b).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-5
+    stats = {"mel_mean": np.linspace(-3, 1, 80).astype(np.float32), "mel_std": np.linspace(0.5, 2, 80).astype(np.float32)}
+    p = str(tmp_path / "s.npy")
+    np.save(p, stats, allow_pickle=True)
+    c = AudioProcessor(stats_path=p)
+    want = np.stack([b.normalize(c.denormalize(m.numpy())) for m in mel])
+    assert np.abs(mel_renorm_device(mel.to(gpu), c, b).cpu().numpy() - want).max() < 1e-4
+
+
+def test_glow_hifigan_tts_to_file(gpu, tmp_path):
+    gargs = dict(num_flow_blocks_dec=3)
+    gargs["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    gsd = W.make_glow_state(dict(gargs, num_chars=67), seed=8)
+    audio = {"sample_rate": 22050, "num_mels": 80, "do_trim_silence": False}
+    gcfg = dict(gargs, model="glow_tts", audio=audio, add_blank=False, use_phonemes=False,
+                encoder_params=dict(gargs["encoder_params"]))
+    hcfg = dict(W.HIFIGAN_V2)
+    hsd = O.make_hifigan_state(hcfg, 80, seed=9)
+    vcfg = {"model": "hifigan", "generator_model": "hifigan_generator", "discriminator_model": "hifigan_discriminator",
+            "audio": dict(audio, max_norm=3.0),
+            "generator_model_params": {k: hcfg[k] for k in ("upsample_factors", "upsample_kernel_sizes",
+                                                            "upsample_initial_channel", "resblock_kernel_sizes",
+                                                            "resblock_dilation_sizes", "resblock_type")}}
+    gck, gcf = _write(tmp_path, "glow", gsd, gcfg)
+    vck, vcf = _write(tmp_path, "voc", {"model_g." + k: v for k, v in hsd.items()}, vcfg)
+    tts = TTS(model_path=gck, config_path=gcf, vocoder_path=vck, vocoder_config_path=vcf, gpu=True)
+    text = "Hello world. This is a test!"
+    out = str(tmp_path / "o.wav")
+    assert tts.tts_to_file(text, file_path=out) == out
+    sr, data = scipy.io.wavfile.read(out)
+    assert sr == 22050 and data.dtype == np.int16 and np.abs(data).max() > 30000      # peak-normalised (save_wav)
+    # oracle pipeline, sentence by sentence (reference semantics), numpy seam
+    syn = tts.synthesizer
+    sens = syn.split_into_sentences(text)
+    got = syn.tts_batch(sens)
+    tok = syn.tts_model.tokenizer
+    a_t, a_v = AudioProcessor(**audio), AudioProcessor(**vcfg["audio"])
+    for s, w in zip(sens, got):
+        ids = torch.tensor([tok.text_to_ids(s)])
+        o = O.glow_tts_inference(gsd, ids, torch.tensor([ids.shape[1]]), dict(gargs, num_chars=67))
+        mel = o["model_outputs"][0].numpy()                                  # [T, C]
+        voc_in = a_v.normalize(a_t.denormalize(mel.T).T.T)                   # synthesizer.py:414-416
+        want = O.hifigan_inference(hsd, "", torch.tensor(voc_in).unsqueeze(0), hcfg)[0, 0].numpy()
+        assert w.shape == want.shape, (w.shape, want.shape)
+        rms = float(np.sqrt(np.mean((w.astype(np.float64) - want) ** 2)))
+        assert rms < 1e-4, rms
+    flat = syn.tts(text)
+    assert isinstance(flat, list) and len(flat) == sum(len(w) for w in got) + 10000 * len(got)
+
+
+def test_vits_synthesizer_smoke(gpu, tmp_path):
+    vargs = dict(upsample_initial_channel_decoder=64, num_chars=67 + 1)
+    sd = W.make_vits_state(vargs, seed=12)
+    cfg = {"model": "vits", "model_args": vargs, "audio": {"sample_rate": 22050, "hop_length": 256}, "add_blank": True,
+           "use_phonemes": False}
+    ck, cf = _write(tmp_path, "vits", sd, cfg)
+    syn = Synthesizer(tts_checkpoint=ck, tts_config_path=cf, use_cuda=True)
+    ws = syn.tts_batch(["Short one.", "A considerably longer second sentence, with commas."])
+    assert len(ws) == 2 and all(np.isfinite(w).all() and len(w) % 256 == 0 and len(w) > 0 for w in ws)
+    assert len(ws[1]) != len(ws[0])

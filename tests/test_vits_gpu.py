@@ -121,3 +121,37 @@ def test_vits_default_size_single_utterance(gpu):
     m = _model({}, sd, gpu)
     out = m.inference(x.to(gpu), {"durations": dur.to(gpu), "noise_z": noise_z.to(gpu)})
     _compare(out, want, 1)
+
+
+def test_vits_ragged_exact_rows_equal_single_sentence_runs(gpu):
+    """aux_input["ragged_exact"]: row b of a padded batch == the reference's B=1 sentence loop (synthesizer.py:384) on
+    sentence b alone (oracle), including the last frames next to the padding."""
+    torch.set_num_threads(8)
+    args = dict(upsample_initial_channel_decoder=64)
+    sd = W.make_vits_state(args, seed=78)
+    g = torch.Generator().manual_seed(5)
+    B, T = 3, 33
+    xl = [33, 21, 8]
+    x = torch.randint(0, 100, (B, T), generator=g)
+    noise_dp = torch.randn(B, 2, T, generator=g)
+    m = _model(args, sd, gpu)
+    aux = {"x_lengths": torch.tensor(xl).to(gpu), "noise_dp": noise_dp.to(gpu), "ragged_exact": True}
+    singles = []
+    for b in range(B):
+        o = O.vits_inference(sd, x[b:b + 1, :xl[b]], torch.tensor([xl[b]]), args, noise_dp=noise_dp[b:b + 1, :, :xl[b]],
+                             stop_after="prior", noise_z=torch.zeros(1, 192, 1))
+        singles.append(o["durations"])
+    t_dec = max(int(d.sum()) for d in singles)
+    noise_z = torch.randn(B, 192, t_dec, generator=g)
+    dur = torch.zeros(B, 1, T)
+    for b in range(B):
+        dur[b, :, :xl[b]] = singles[b]
+    out = m.inference(x.to(gpu), dict(aux, noise_z=noise_z.to(gpu), durations=dur.to(gpu)))
+    assert out["y_lengths"].tolist() == [int(d.sum()) for d in singles]
+    for b in range(B):
+        n = int(singles[b].sum())
+        want = O.vits_inference(sd, x[b:b + 1, :xl[b]], torch.tensor([xl[b]]), args, durations=singles[b],
+                                noise_z=noise_z[b:b + 1, :, :n])["model_outputs"]
+        got = out["model_outputs"][b:b + 1, :, : n * 256]
+        rms, rel = _errs(got, want)
+        assert rms < 1e-4 and rel < 1e-5, (b, rms, rel)

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kTxtThreads) void durations_kernel(float *__restric
             w = w * m * length_scale;
             wc = ceilf(w);
             if (glow) wc = fmaxf(wc, 1.f);
+            if (glow == 2) wc *= m;   // ragged-exact batching: padded tokens own no frame
         }
         dur[o] = wc;
         const float cl = fminf(fmaxf(wc, 0.f), 1048576.f);  // keep the int offsets finite for inf/NaN inputs

@@ -6,14 +6,20 @@ namespace ttsamd {
 constexpr int kEwThreads = 256;
 inline int ew_blocks(long n) { long b = (n + kEwThreads - 1) / kEwThreads; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 
-__global__ void replicate_pad_kernel(float *__restrict__ y, const float *__restrict__ x, long rows, int t, int pad)
+__global__ void replicate_pad_kernel(float *__restrict__ y, const float *__restrict__ x, long rows, int t, int pad,
+                                     const long *__restrict__ lengths, int rows_per_item)
 {
     const int to = t + 2 * pad;
     const long n = rows * to;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long r = i / to;
         int c = (int)(i - r * to) - pad;
-        c = c < 0 ? 0 : (c >= t ? t - 1 : c);
+        int last = t - 1;
+        if (lengths) {  // ragged batch: every item replicates ITS OWN last valid frame
+            const long l = lengths[r / rows_per_item];
+            last = (int)(l < 1 ? 0 : (l > t ? t - 1 : l - 1));
+        }
+        c = c < 0 ? 0 : (c > last ? last : c);
         y[i] = x[r * t + c];
     }
 }
@@ -25,7 +31,78 @@ extern "C" int ttsamd_replicate_pad(float *y, const float *x, int64_t rows, int 
 {
     TTSAMD_CHECK_ARG(y && x && rows >= 0 && t > 0 && pad >= 0, "replicate_pad: bad args");
     if (rows == 0) return TTSAMD_OK;
-    hipLaunchKernelGGL(replicate_pad_kernel, dim3(ew_blocks(rows * (t + 2 * pad))), dim3(kEwThreads), 0, as_stream(stream), y, x, (long)rows, t, pad);
+    hipLaunchKernelGGL(replicate_pad_kernel, dim3(ew_blocks(rows * (t + 2 * pad))), dim3(kEwThreads), 0, as_stream(stream), y, x, (long)rows, t, pad,
+                       (const long *)nullptr, 1);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_replicate_pad_ragged(float *y, const float *x, const int64_t *lengths, int batch, int c, int t,
+                                           int pad, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && x && lengths && batch >= 0 && c > 0 && t > 0 && pad >= 0, "replicate_pad_ragged: bad args");
+    if (batch == 0) return TTSAMD_OK;
+    const long rows = (long)batch * c;
+    hipLaunchKernelGGL(replicate_pad_kernel, dim3(ew_blocks(rows * (t + 2 * pad))), dim3(kEwThreads), 0, as_stream(stream), y, x, rows, t, pad,
+                       reinterpret_cast<const long *>(lengths), c);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+// ---- Synthesizer mel seam on the device --------------------------------------------------------
+namespace ttsamd {
+
+__device__ __forceinline__ float mel_denorm(float s, int c, const ttsamd_mel_norm &p)
+{
+    if (!p.signal_norm) return s;
+    if (p.mean) return s * p.scale[c] + p.mean[c];                      // StandardScaler.inverse_transform
+    if (p.symmetric_norm) {
+        if (p.clip_norm) s = fminf(fmaxf(s, -p.max_norm), p.max_norm);
+        s = ((s + p.max_norm) * -p.min_level_db / (2.f * p.max_norm)) + p.min_level_db;
+    } else {
+        if (p.clip_norm) s = fminf(fmaxf(s, 0.f), p.max_norm);
+        s = (s * -p.min_level_db / p.max_norm) + p.min_level_db;
+    }
+    return s + p.ref_level_db;
+}
+
+__device__ __forceinline__ float mel_norm(float s, int c, const ttsamd_mel_norm &p)
+{
+    if (!p.signal_norm) return s;
+    if (p.mean) return (s - p.mean[c]) / p.scale[c];                    // StandardScaler.transform
+    s -= p.ref_level_db;
+    float n = (s - p.min_level_db) / (-p.min_level_db);
+    if (p.symmetric_norm) {
+        n = ((2.f * p.max_norm) * n) - p.max_norm;
+        if (p.clip_norm) n = fminf(fmaxf(n, -p.max_norm), p.max_norm);
+    } else {
+        n = p.max_norm * n;
+        if (p.clip_norm) n = fminf(fmaxf(n, 0.f), p.max_norm);
+    }
+    return n;
+}
+
+__global__ void mel_renorm_kernel(float *__restrict__ y, const float *__restrict__ x, ttsamd_mel_norm tts,
+                                  ttsamd_mel_norm voc, int C, long T, long total)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / T) % C);
+        y[i] = mel_norm(mel_denorm(x[i], c, tts), c, voc);
+    }
+}
+
+}  // namespace ttsamd
+
+extern "C" int ttsamd_mel_renorm(float *y, const float *x, const ttsamd_mel_norm *tts, const ttsamd_mel_norm *voc,
+                                 int batch, int c, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && x && tts && voc && batch >= 0 && c > 0 && t >= 0, "mel_renorm: bad args");
+    TTSAMD_CHECK_ARG((tts->mean == nullptr) == (tts->scale == nullptr) && (voc->mean == nullptr) == (voc->scale == nullptr),
+                     "mel_renorm: mean and scale go together");
+    const long total = (long)batch * c * t;
+    if (total == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(mel_renorm_kernel, dim3(ew_blocks(total)), dim3(kEwThreads), 0, as_stream(stream), y, x, *tts, *voc,
+                       c, (long)t, total);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

@@ -86,7 +86,9 @@ class GlowTTS:
 
     @torch.no_grad()
     def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None}):  # noqa: B006
-        """glow_tts.py:341-374.  Optional aux key "noise" [B,C,T_dec] pins the randn_like(y_mean) draw."""
+        """glow_tts.py:341-374.  Optional aux keys: "noise" [B,C,T_dec] pins the randn_like(y_mean) draw;
+        "ragged_exact": padded tokens own no frames (the reference gives each PADDED token one frame via clamp_min,
+        which only matters in batches) so that row b equals a B=1 run on sentence b."""
         if self.encoder is None:
             raise _lib.TtsAmdError("tts_amd.GlowTTS: no weights loaded / not moved to the GPU")
         _lib.require_gpu(x, "x")
@@ -99,7 +101,8 @@ class GlowTTS:
             x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
         o_mean, o_logs, logw = self.encoder(x, x_mask)
-        w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), glow=True)
+        ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
+        w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), glow=2 if ragged else 1)
         t_dec = int(y_lengths.max().item())
         noise = aux_input.get("noise") if aux_input else None
         C = a.out_channels
@@ -120,6 +123,7 @@ class GlowTTS:
             "alignments": attn.permute(0, 2, 1),
             "durations_log": logw.unsqueeze(1).transpose(1, 2),
             "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
+            "y_lengths": y_lengths,
         }
 
     __call__ = inference

@@ -60,3 +60,25 @@ def maximum_path_c(paths: torch.Tensor, values: torch.Tensor, t_xs: torch.Tensor
                                     ctypes.c_float(max_neg_val), stream_ptr()),
         "maximum_path_c",
     )
+
+
+def mas_logp(z, m, logs, glow_order=False):
+    """logp [B,T_x,T_y] of vits.py:912-918 (glow_tts.py:241-247 with glow_order=True) on the device.
+    z [B,C,T_y] latent, m / logs [B,C,T_x] text-side prior statistics."""
+    _lib.require_gpu(z, "z")
+    z, m, logs = (t.detach().float().contiguous() for t in (z, m, logs))
+    B, C, Ty = z.shape
+    Tx = m.shape[2]
+    assert m.shape == logs.shape == (B, C, Tx)
+    logp = torch.empty((B, Tx, Ty), dtype=torch.float32, device=z.device)
+    check(lib().ttsamd_mas_logp(P(logp), P(z), P(m), P(logs), B, C, Tx, Ty, int(glow_order), stream_ptr()), "mas_logp")
+    return logp
+
+
+def mas_attention(z, m, logs, x_mask, y_mask, glow_order=False):
+    """`attn = maximum_path(logp, attn_mask)` of Vits.forward_mas (vits.py:909-919) / GlowTTS.forward
+    (glow_tts.py:236-248), entirely on the GPU.  x_mask [B,1,T_x] or [B,T_x], y_mask likewise -> attn [B,T_x,T_y]."""
+    xm = x_mask.reshape(x_mask.shape[0], -1).float()
+    ym = y_mask.reshape(y_mask.shape[0], -1).float()
+    attn_mask = xm.unsqueeze(-1) * ym.unsqueeze(1)
+    return maximum_path(mas_logp(z, m, logs, glow_order), attn_mask)

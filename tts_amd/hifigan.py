@@ -105,8 +105,11 @@ class HifiganGenerator:
 
     # ---- forward (hifigan_generator.py:236-265) ----------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, g=None, in_mask=None):
-        """`in_mask` [B,T] (optional) multiplies x inside conv_pre's load: VITS feeds `z * y_mask` (vits.py:1161)."""
+    def forward(self, x, g=None, in_mask=None, lengths=None):
+        """`in_mask` [B,T] (optional) multiplies x inside conv_pre's load: VITS feeds `z * y_mask` (vits.py:1161).
+        `lengths` [B] (optional, frames): ragged-exact batching — every conv of every stage reads item b as if its
+        tensor ended at lengths[b] (positions beyond are zero, exactly the zero padding a stand-alone run of that item
+        sees), so the first lengths[b]*hop samples of row b equal a B=1 run on that item alone."""
         if self._packed is None:
             raise _lib.TtsAmdError("HifiganGenerator: no weights loaded / not moved to the GPU")
         _lib.require_gpu(x, "x")
@@ -117,6 +120,15 @@ class HifiganGenerator:
         new = lambda c, t: torch.empty((B, c, t), dtype=torch.float32, device=dev)  # noqa: E731
         ch = self.upsample_initial_channel
         o = new(ch, T)
+        sm = [None] * (self.num_upsamples + 1)        # per-stage length masks [B, T_stage]
+        if lengths is not None:
+            lengths = lengths.to(dev, torch.int64)
+            scale = 1
+            sm[0] = ops.sequence_mask(lengths, T)
+            in_mask = sm[0] if in_mask is None else in_mask * sm[0]
+            for i, u in enumerate(self.upsample_factors):
+                scale *= u
+                sm[i + 1] = ops.sequence_mask(lengths * scale, T * scale)
         if g is not None and "cond_layer" in P:
             # o = conv_pre(x) + cond_layer(g): g is [B, C, 1]; its 1x1 conv is a per-(b, channel) offset that
             # rides in conv_pre's epilogue (hifigan_generator.py:250-251)
@@ -131,7 +143,8 @@ class HifiganGenerator:
             T_up = T * u
             up = new(ch, T_up)
             ops.conv1d(P["ups.%d" % i], o, up, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, mode=CONV_SHUFFLE,
-                       shuffle_u=u, shuffle_pad=u // 2)
+                       shuffle_u=u, shuffle_pad=u // 2, in_mask=sm[i])
+            msk = sm[i + 1]
             T = T_up
             o_next = new(ch, T)
             zsum = new(ch, T) if nk > 1 else None
@@ -149,29 +162,31 @@ class HifiganGenerator:
                     else:
                         dst, accum, div = (xa if cur is not xa else xb), None, 0.0
                     if self.resblock_type == "1":
-                        ops.conv1d(P[rp + "convs1.%d" % m], cur, tmp, in_act=ACT_LRELU, in_slope=LRELU_SLOPE)
+                        ops.conv1d(P[rp + "convs1.%d" % m], cur, tmp, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, in_mask=msk)
                         ops.conv1d(P[rp + "convs2.%d" % m], tmp, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
-                                   res=cur, accum=accum, out_div=div)
+                                   res=cur, accum=accum, out_div=div, in_mask=msk)
                     else:
                         ops.conv1d(P[rp + "convs.%d" % m], cur, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
-                                   res=cur, accum=accum, out_div=div)
+                                   res=cur, accum=accum, out_div=div, in_mask=msk)
                     cur = dst
             o = o_next
         wav = new(self.out_channels, T)
         # final F.leaky_relu(o) uses the DEFAULT slope 0.01 (hifigan_generator.py:262)
-        ops.conv1d(P["conv_post"], o, wav, in_act=ACT_LRELU, in_slope=0.01, out_act=ACT_TANH)
+        ops.conv1d(P["conv_post"], o, wav, in_act=ACT_LRELU, in_slope=0.01, out_act=ACT_TANH, in_mask=sm[-1])
         return wav
 
     __call__ = forward
 
     @torch.no_grad()
-    def inference(self, c):
-        """hifigan_generator.py:267-282: replicate-pad `inference_padding` frames each side, no crop."""
+    def inference(self, c, lengths=None):
+        """hifigan_generator.py:267-282: replicate-pad `inference_padding` frames each side, no crop.
+        `lengths` [B] (frames, optional) = ragged-exact batching (see forward): row b's first
+        (lengths[b] + 2*pad)*hop samples equal `inference(c[b:b+1, :, :lengths[b]])`."""
         c = c.to(self.device).contiguous().float()
         p = self.inference_padding
         if p > 0:
             B, C, T = c.shape
             cp = torch.empty((B, C, T + 2 * p), dtype=torch.float32, device=c.device)
-            ops.replicate_pad(c, cp, p)
+            ops.replicate_pad(c, cp, p, lengths)
             c = cp
-        return self.forward(c)
+        return self.forward(c, lengths=None if lengths is None else lengths.to(self.device) + 2 * p)

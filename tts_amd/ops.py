@@ -181,8 +181,14 @@ def gate_permute(w, bias, hidden):
     return w[idx].contiguous(), (None if bias is None else bias[idx].contiguous())
 
 
-def replicate_pad(x, y, pad):
-    """y = F.pad(x, (pad, pad), 'replicate') on the last dim (hifigan_generator.py:281)."""
+def replicate_pad(x, y, pad, lengths=None):
+    """y = F.pad(x, (pad, pad), 'replicate') on the last dim (hifigan_generator.py:281); with `lengths` [B] (int64)
+    every item of the ragged batch replicates its own last valid frame."""
+    if lengths is not None:
+        B, C, T = x.shape
+        check(lib().ttsamd_replicate_pad_ragged(P(y), P(x), P(lengths.to(torch.int64).contiguous()), B, C, T, pad,
+                                                stream_ptr()), "replicate_pad_ragged")
+        return y
     rows = x.numel() // x.shape[-1]
     check(lib().ttsamd_replicate_pad(P(y), P(x), ctypes.c_int64(rows), x.shape[-1], pad, stream_ptr()),
           "replicate_pad")
@@ -292,7 +298,7 @@ def durations(logw, mask, length_scale, glow=False, durations_in=None):
     cum = torch.empty((B, T), dtype=torch.int32, device=dev)
     ylen = torch.empty((B,), dtype=torch.int64, device=dev)
     check(lib().ttsamd_durations(P(dur), P(cum), P(ylen), P(logw), P(durations_in), P(mask),
-                                 ctypes.c_float(length_scale), int(glow), B, T, stream_ptr()), "durations")
+                                 ctypes.c_float(length_scale), int(glow), B, T, stream_ptr()), "durations")  # glow: 0 VITS, 1 Glow, 2 Glow ragged-exact
     return dur, cum, ylen
 
 

@@ -1,0 +1,149 @@
+"""`Synthesizer`-compatible inference driver (TTS/utils/synthesizer.py:25-505) over the HIP models.
+
+Same constructor arguments and `tts()` / `save_wav()` / `split_into_sentences()` contract for the model
+families this build covers (`vits`, `glow_tts` + `hifigan` GAN vocoder); configs are the reference's JSON files
+read as plain dicts (coqpit is not needed).  Differences, all on the fast side:
+  * sentences of one request are synthesised as ONE padded batch (the reference loops B=1, synthesizer.py:384);
+  * the Glow-TTS -> vocoder mel seam (denormalize / normalize, synthesizer.py:412-429) runs on the device;
+  * waveforms come back as numpy arrays and are concatenated once (`tts()` still returns a flat list of floats
+    like the reference; `tts_batch()` is the array API).
+"""
+import json
+import re
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .audio import AudioProcessor, mel_renorm_device
+from .gan import GAN
+from .glow_tts import GlowTTS
+from .text import TTSTokenizer
+from .vits import Vits, _get
+
+_MODELS = {"vits": Vits, "glow_tts": GlowTTS}
+
+
+def load_config(path):
+    """config/__init__.py:68-100 without coqpit: JSON (comments tolerated, :14-21) -> dict."""
+    txt = open(path, "r", encoding="utf-8").read()
+    try:
+        return json.loads(txt)
+    except json.JSONDecodeError:
+        txt = re.sub(r"\\\n", "", txt)
+        txt = re.sub(r"//.*\n", "\n", txt)
+        return json.loads(txt)
+
+
+def setup_tts_model(config):
+    """tts/models/__init__.py:6-14: class found by `config["model"]`."""
+    name = str(_get(config, "model", "")).lower()
+    if name not in _MODELS:
+        raise _lib.TtsAmdError("no HIP implementation for tts model %r (have: %s)" % (name, sorted(_MODELS)))
+    cfg = dict(config) if isinstance(config, dict) else config
+    ap = AudioProcessor.init_from_config(cfg)
+    tok, _ = TTSTokenizer.init_from_config(cfg)
+    if isinstance(cfg, dict):
+        cfg = dict(cfg, _ap=ap, _tokenizer=tok)
+        if name == "glow_tts" and cfg.get("num_chars") is None:
+            cfg["num_chars"] = tok.characters.num_chars
+    return _MODELS[name].init_from_config(cfg)
+
+
+class Synthesizer:
+    def __init__(self, tts_checkpoint="", tts_config_path="", tts_speakers_file="", tts_languages_file="",
+                 vocoder_checkpoint="", vocoder_config="", encoder_checkpoint="", encoder_config="", vc_checkpoint="",
+                 vc_config="", model_dir="", voice_dir=None, use_cuda=True):
+        if not use_cuda or not torch.cuda.is_available():
+            raise _lib.TtsAmdError("tts_amd.Synthesizer needs a GPU (use_cuda=True): there is no CPU path")
+        self.use_cuda = True
+        self.tts_config = load_config(tts_config_path) if isinstance(tts_config_path, str) else tts_config_path
+        self.tts_model = setup_tts_model(self.tts_config)
+        if tts_checkpoint:
+            self.tts_model.load_checkpoint(self.tts_config, tts_checkpoint, eval=True)
+        self.tts_model.cuda()
+        self.output_sample_rate = _get(_get(self.tts_config, "audio", {}), "sample_rate", 22050)
+        self.vocoder_model = self.vocoder_ap = self.vocoder_config = None
+        if vocoder_checkpoint or vocoder_config:
+            self.vocoder_config = load_config(vocoder_config) if isinstance(vocoder_config, str) else vocoder_config
+            self.vocoder_ap = AudioProcessor.init_from_config(self.vocoder_config)
+            self.vocoder_model = GAN.init_from_config(self.vocoder_config)
+            if vocoder_checkpoint:
+                self.vocoder_model.load_checkpoint(self.vocoder_config, vocoder_checkpoint, eval=True)
+            self.vocoder_model.cuda()
+            self.output_sample_rate = _get(_get(self.vocoder_config, "audio", {}), "sample_rate", self.output_sample_rate)
+        self.device = next(self.tts_model.parameters()).device if self.tts_model._sd is not None else torch.device("cuda")
+
+    @staticmethod
+    def split_into_sentences(text):
+        """synthesizer.py:227-236 uses pysbd (not installed): split after sentence-final punctuation."""
+        parts = re.split(r"(?<=[.!?])\s+", text.strip())
+        return [p for p in parts if p]
+
+    def save_wav(self, wav, path, pipe_out=None):
+        AudioProcessor.save_wav(np.asarray(wav), path, self.output_sample_rate, pipe_out)
+
+    @torch.no_grad()
+    def tts_batch(self, sentences, trim=True):
+        """Synthesize a list of sentences as one padded batch -> list of float32 waveforms (numpy)."""
+        tok = self.tts_model.tokenizer
+        ids = [tok.text_to_ids(s) for s in sentences]
+        if any(len(i) == 0 for i in ids):
+            raise ValueError("a sentence has no symbol of the model's vocabulary")
+        T = max(len(i) for i in ids)
+        x = torch.zeros(len(ids), T, dtype=torch.int64)
+        for r, i in enumerate(ids):
+            x[r, : len(i)] = torch.tensor(i)
+        xl = torch.tensor([len(i) for i in ids], dtype=torch.int64)
+        dev = self.device
+        # ragged_exact: every sentence of the padded batch gets the result of a B=1 run on it (reference semantics)
+        out = self.tts_model.inference(x.to(dev), {"x_lengths": xl.to(dev), "ragged_exact": True})
+        frames = out["y_lengths"]
+        if self.vocoder_model is None:
+            wav = out["model_outputs"]                                        # VITS: [B,1,T_wav]
+            lens = (frames * (wav.shape[-1] // out["y_mask"].shape[-1])).tolist()
+        else:
+            mel = out["model_outputs"].transpose(1, 2)                        # [B,C,T]
+            sr_t = _get(_get(self.tts_config, "audio", {}), "sample_rate", 22050)
+            sr_v = _get(_get(self.vocoder_config, "audio", {}), "sample_rate", 22050)
+            if sr_t != sr_v:
+                raise _lib.TtsAmdError("vocoder / tts sample-rate mismatch (interpolate_vocoder_input) is not built")
+            voc_in = mel_renorm_device(mel, self.tts_model.ap, self.vocoder_ap)
+            if isinstance(self.tts_model, GlowTTS):                           # squeeze drops an odd last frame
+                nsq = self.tts_model.num_squeeze
+                frames = torch.div(frames, nsq, rounding_mode="floor") * nsq
+            wav = self.vocoder_model.model_g.inference(voc_in, lengths=frames)
+            pad = self.vocoder_model.model_g.inference_padding
+            hop_total = wav.shape[-1] // (mel.shape[-1] + 2 * pad)
+            lens = ((frames + 2 * pad) * hop_total).tolist()
+        wav = wav.float().cpu().numpy().reshape(len(ids), -1)
+        res = []
+        do_trim = trim and bool(_get(_get(self.tts_config, "audio", {}), "do_trim_silence", False))
+        for r in range(len(ids)):
+            w = wav[r, : int(lens[r])]
+            if do_trim:
+                w = w[: self.tts_model.ap.find_endpoint(w)]
+            res.append(w)
+        return res
+
+    def tts(self, text="", speaker_name=None, language_name=None, speaker_wav=None, style_wav=None, style_text=None,
+            reference_wav=None, reference_speaker_name=None, split_sentences=True, **kwargs):
+        """synthesizer.py:257-505 for single-speaker models: returns a flat list of samples, sentences separated by
+        10000 zeros (synthesizer.py:441)."""
+        start = time.time()
+        if not text:
+            raise ValueError("You need to define either `text` (for sythesis) or a `reference_wav` (for voice conversion) to use the Coqui TTS API.")
+        if speaker_name or language_name or speaker_wav or reference_wav:
+            raise _lib.TtsAmdError("multi-speaker / multi-lingual / voice-conversion requests are not built")
+        sens = self.split_into_sentences(text) if split_sentences else [text]
+        wavs = []
+        for w in self.tts_batch(sens):
+            wavs.append(w)
+            wavs.append(np.zeros(10000, np.float32))
+        flat = np.concatenate(wavs)
+        dt = time.time() - start
+        audio_time = len(flat) / self.output_sample_rate
+        print(" > Processing time: %s" % dt)
+        print(" > Real-time factor: %s" % (dt / audio_time))
+        return flat.tolist()

@@ -182,7 +182,9 @@ class Vits:
         z = self.flow(pri["z_p2"], y_mask)
         zd = z if self.max_inference_len is None else z[:, :, : self.max_inference_len].contiguous()
         md = y_mask if self.max_inference_len is None else y_mask[:, : self.max_inference_len].contiguous()
-        o = self.waveform_decoder.forward(zd, in_mask=md)                         # (z * y_mask)[:, :, :max_len]
+        # "ragged_exact": every decoder conv treats row b as ending at y_lengths[b] -> row b equals a B=1 run
+        ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
+        o = self.waveform_decoder.forward(zd, in_mask=md, lengths=y_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
         outputs = {
             "model_outputs": o,
             "alignments": attn,
@@ -193,6 +195,8 @@ class Vits:
             "logs_p": pri["logs_p"],
             "y_mask": y_mask.unsqueeze(1),
         }
+        if ragged:
+            outputs["y_lengths"] = y_lengths
         if aux_input and aux_input.get("return_extras"):
             outputs.update(x=h, logw=None if logw is None else logw.unsqueeze(1), y_lengths=y_lengths)
         return outputs
