@@ -1,11 +1,12 @@
 """Multi-process (gloo, world_size 2, CPU) test of the only multi-GPU mechanism the path needs: the one-shot
 flat-blob weight broadcast + utterance sharding (tts_amd/parallel.py)."""
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import torch
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -18,39 +19,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-
-    from tts_amd import parallel, synthetic
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    args = dict(upsample_initial_channel_decoder=32)
-    sd = synthetic.make_vits_state(args, seed=9) if rank == 0 else None
-    got = parallel.broadcast_state_dict(sd, src=0)
-    ref = synthetic.make_vits_state(args, seed=9)
-    ok = set(got) == set(ref) and all(torch.equal(got[k], ref[k]) and got[k].dtype == ref[k].dtype for k in ref)
-    lo, hi = parallel.shard_range(33)
-    q.put((rank, ok, lo, hi))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 def test_broadcast_and_shard_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    worker = os.path.join(ROOT, "tests", "_parallel_worker.py")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    ps = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, env=env, cwd=ROOT) for r in range(2)]
+    res = {}
     for p in ps:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert res[0][1] and res[1][1], "broadcast state_dict differs from the source"
-    assert (res[0][2], res[0][3], res[1][2], res[1][3]) == (0, 17, 17, 33)
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        line = [ln for ln in out.splitlines() if ln.startswith("RESULT ")][-1]
+        r = json.loads(line[7:])
+        res[r["rank"]] = r
+    assert res[0]["ok"] and res[1]["ok"], "broadcast state_dict differs from the source"
+    assert (res[0]["lo"], res[0]["hi"], res[1]["lo"], res[1]["hi"]) == (0, 17, 17, 33)
 
 
 def test_flatten_roundtrip_and_length_sharding():
