@@ -61,11 +61,22 @@ extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_GATE || (a.c_out % 64) == 0, "conv1d: GATE needs c_out %% 64 == 0");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_COUPLE_AFFINE || ((a.c_out % 64) == 0 && a.res && a.split_row > 0),
                      "conv1d: COUPLE_AFFINE needs c_out %% 64 == 0, res and split_row");
-    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_RES_SKIP || (a.res && a.y2 && a.split_row > 0),
-                     "conv1d: RES_SKIP needs res, y2 and split_row");
+    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_RES_SKIP || (a.res && a.y2 && a.split_row > 0 && a.split_row % 32 == 0),
+                     "conv1d: RES_SKIP needs res, y2 and split_row %% 32 == 0");
     TTSAMD_CHECK_ARG(a.mode >= 0 && a.mode <= TTSAMD_CONV_COUPLE_AFFINE, "conv1d: unknown mode %d", a.mode);
     if (a.batch == 0 || a.t_out == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(a.batch <= 65535, "conv1d: batch > 65535");
+    {   // the kernel addresses every per-item slab with 32-bit byte offsets (buffer resources)
+        const int64_t lim = 0x7FFFFFF0;
+        const int64_t rows_y = (a.mode == TTSAMD_CONV_SHUFFLE) ? (a.c_out / (a.shuffle_u > 0 ? a.shuffle_u : 1)) : a.c_out;
+        const int64_t cols_y = (a.mode == TTSAMD_CONV_SHUFFLE) ? a.shuffle_t_out : a.t_out;
+        if (((int64_t)a.c_in * a.x_rstride + a.t_in) * 4 >= lim || (rows_y * a.y_rstride + cols_y) * 4 >= lim ||
+            (a.res && ((int64_t)a.c_out * a.res_rstride + a.t_out) * 4 >= lim) ||
+            (a.accum && ((int64_t)a.c_out * a.accum_rstride + a.t_out) * 4 >= lim)) {
+            set_error("conv1d: a per-item [C, T] slab exceeds 2 GiB (time-tile the call)");
+            return TTSAMD_ERR_UNSUPPORTED;
+        }
+    }
     if (!ttsamd_conv1d_supported(a.kernel, a.dilation)) {
         set_error("conv1d: (kernel=%d, dilation=%d) has no instantiation", a.kernel, a.dilation);
         return TTSAMD_ERR_UNSUPPORTED;

@@ -46,6 +46,20 @@ struct ConvGeom {
     static constexpr size_t kLdsBytes = (size_t)2 * kStageElems * sizeof(float);
 };
 
+// Buffer-resource helpers (raw buffer, stride 0; dword 3 = 0x00020000 as on gfx90a/gfx94x/gfx950).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0));
+}
+__device__ __forceinline__ void st_buf(__amdgpu_buffer_rsrc_t r, float v, int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voffset, soffset, 0);
+}
+
 __device__ __forceinline__ float conv_in_act(float v, int act, float slope)
 {
     return (act == TTSAMD_ACT_LRELU) ? (v > 0.f ? v : v * slope) : v;
@@ -70,32 +84,51 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
     const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
     const long ksg_total = (long)nchunks * G::kGroupsPerChunk;  // groups per m-tile
 
-    const float *xb = a.x + (long)b * a.x_bstride;
-    const float *mrow = a.in_mask ? a.in_mask + (long)b * a.t_in : nullptr;
+    // ---- global memory goes through buffer resources (SRSRC + 32-bit offsets): one VGPR offset per access, no
+    // 64-bit address arithmetic, and out-of-range lanes are dropped / read as 0 by the hardware range check
+    // (invalid lanes get kOob as their offset).  One resource per (tensor, batch item) slab; slabs are < 2 GiB
+    // (checked on the host).
+    constexpr int kOob = 0x7FFFFFF0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * a.x_bstride, ((long)(a.c_in - 1) * a.x_rstride + a.t_in) * 4);
 
-    // ---- staging helpers (branch-free: clamped always-valid address + select) --------------
-    float st[G::kNStage];
-    auto stage_load = [&](int chunk) {
-        const bool has_mask = (mrow != nullptr);  // wave-uniform
+    // Staged element i of this thread: row = channel inside the chunk, col = column of the [BN + halo] strip.
+    // Everything but the chunk's channel offset is chunk-independent and computed ONCE: byte offset (kOob when the
+    // column is outside [0, t_in) or the slot is padding) and the input-mask value.
+    int soff[G::kNStage];
+    float smask[G::kNStage];
+#pragma unroll
+    for (int i = 0; i < G::kNStage; ++i) {
+        const int e = tid + i * G::kThreads;
+        const int row = e / G::kXW;
+        const int col = e - row * G::kXW;
+        const int gt = t0 - a.pad_left + col;
+        const bool ok = (e < G::kStageElems) && (gt >= 0) && (gt < a.t_in);
+        soff[i] = ok ? (int)(((long)row * a.x_rstride + gt) * 4) : kOob;
+        smask[i] = 1.f;
+    }
+    if (a.in_mask) {
+        const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.in_mask + (long)b * a.t_in, (long)a.t_in * 4);
 #pragma unroll
         for (int i = 0; i < G::kNStage; ++i) {
             const int e = tid + i * G::kThreads;
-            const int row = e / G::kXW;
-            const int col = e - row * G::kXW;
-            const int ci = chunk * kConvCK + row;
+            const int col = e - (e / G::kXW) * G::kXW;
             const int gt = t0 - a.pad_left + col;
-            const bool ok = (e < G::kStageElems) && (ci < a.c_in) && (gt >= 0) && (gt < a.t_in);
-            const long off = ok ? ((long)ci * a.x_rstride + gt) : 0;
-            float v = xb[off];
-            if (has_mask) v *= mrow[ok ? gt : 0];
-            st[i] = ok ? v : 0.f;
+            smask[i] = ld_buf(rm, (gt >= 0 && gt < a.t_in) ? gt * 4 : kOob, 0);
         }
+    }
+    const int chunk_bytes = kConvCK * (int)a.x_rstride * 4;   // channel offset of one chunk (slab < 2 GiB)
+    float st[G::kNStage];
+    auto stage_load = [&](int chunk) {
+        const int cb = chunk * chunk_bytes;
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i)   // channels >= c_in fall outside the slab -> 0
+            st[i] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb, 0);
     };
     auto stage_store = [&](float *buf) {
 #pragma unroll
         for (int i = 0; i < G::kNStage; ++i) {
             const int e = tid + i * G::kThreads;
-            if (e < G::kStageElems) buf[e] = conv_in_act(st[i], a.in_act, a.in_slope);
+            if (e < G::kStageElems) buf[e] = conv_in_act(st[i] * smask[i], a.in_act, a.in_slope);
         }
     };
 
@@ -121,18 +154,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
     bool folded = false;
     if constexpr (MODE == TTSAMD_CONV_NORMAL) folded = (a.out_act == TTSAMD_ACT_NONE) && a.res;
     if (folded) {
-        const float *rp = a.res + (long)b * a.res_bstride;
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.res + (long)b * a.res_bstride,
+                                                    ((long)(a.c_out - 1) * a.res_rstride + a.t_out) * 4);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+            const int row0 = (((int)blockIdx.y * WM + wm) * MI + mi) * 32;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+                const int vo = (t < a.t_out) ? (int)(((long)(4 * h) * a.res_rstride + t) * 4) : kOob;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const bool ok = row < a.c_out && t < a.t_out;
-                    acc[mi][ni][r] = rp[ok ? row * a.res_rstride + t : 0];   // out-of-range lanes are never stored
+                    const int rb = row0 + (r & 3) + 8 * (r >> 2);                 // wave-uniform part of the row
+                    const int vr = (rb + 4 * h < a.c_out) ? vo : kOob;
+                    acc[mi][ni][r] = ld_buf(rr, vr, rb * (int)a.res_rstride * 4);
                 }
             }
         }
@@ -242,53 +277,110 @@ __global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_
             }
         }
     } else {
+        // Branch-free passes: every optional operand is fetched by a whole pass of buffer loads behind ONE
+        // wave-uniform branch (never a branch + wait per element); validity lives in the offsets (kOob).
         const int out_act = ep->out_act;
         const float out_div = ep->out_div;
-        const float *accum = ep->accum ? ep->accum + (long)b * ep->accum_bstride : nullptr;
-        const long accum_rs = ep->accum_rstride;
+        const int split = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->split_row : 0;
+        const int y_rs4 = (int)y_rs * 4, res_rs4 = (int)res_rs * 4, acc_rs4 = (int)ep->accum_rstride * 4;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(
+            y + (long)b * y_bs, (MODE == TTSAMD_CONV_SHUFFLE)
+                                    ? ((long)((c_out - 1) / ep->shuffle_u) * y_rs + ep->shuffle_t_out) * 4
+                                    : ((long)((MODE == TTSAMD_CONV_RES_SKIP ? split : c_out) - 1) * y_rs + t_out) * 4);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(res, res ? ((long)(c_out - 1) * res_rs + t_out) * 4 : 0);
+        const __amdgpu_buffer_rsrc_t racc = make_rsrc(
+            ep->accum ? ep->accum + (long)b * ep->accum_bstride : nullptr,
+            ep->accum ? ((long)(c_out - split - 1) * ep->accum_rstride + t_out) * 4 : 0);
+        const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(
+            (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2 + (long)b * ep->y2_bstride : nullptr,
+            (MODE == TTSAMD_CONV_RES_SKIP) ? ((long)(c_out - split - 1) * ep->y2_rstride + t_out) * 4 : 0);
+        const int y2_rs4 = (MODE == TTSAMD_CONV_RES_SKIP) ? (int)ep->y2_rstride * 4 : 0;
+        const bool has_accum = ep->accum != nullptr;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+            const int row0 = (((int)blockIdx.y * WM + wm) * MI + mi) * 32;
+            const bool lower = (MODE == TTSAMD_CONV_RES_SKIP) && (row0 < split);   // res rows vs skip rows
+            float radd[16];   // bias (+ per-item row bias) of this lane's 16 rows of the m-tile
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+            for (int r = 0; r < 16; ++r) radd[r] = 0.f;
+            if (bias) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row >= c_out || t >= t_out) continue;
-                    float v = acc[mi][ni][r];
-                    if (bias) v += bias[row];
-                    if (rbias) v += rbias[row];
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    radd[r] = bias[row < c_out ? row : 0];
+                }
+            }
+            if (rbias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    radd[r] += rbias[row < c_out ? row : 0];
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                // one 32x32 tile at a time: keeps the epilogue's live registers below the main loop's
+                __builtin_amdgcn_sched_barrier(0);
+                const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+                const bool tv = t < t_out;
+                const float om = omask ? omask[tv ? t : 0] : 1.f;
+                float e1[16], e2[16];   // optional operands of this 32x32 tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { e1[r] = 0.f; e2[r] = 0.f; }
+                const bool need_res = (MODE == TTSAMD_CONV_COUPLE) || (MODE == TTSAMD_CONV_RES_SKIP && lower) ||
+                                      (MODE == TTSAMD_CONV_NORMAL && res && !folded);
+                if (need_res) {
+                    const int vo = tv ? (4 * h * res_rs4 + t * 4) : kOob;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rb = row0 + (r & 3) + 8 * (r >> 2);
+                        e1[r] = ld_buf(rres, (rb + 4 * h < c_out) ? vo : kOob, rb * res_rs4);
+                    }
+                }
+                const bool need_acc = has_accum && (MODE == TTSAMD_CONV_NORMAL || (MODE == TTSAMD_CONV_RES_SKIP && !lower));
+                if (need_acc) {
+                    const int vo = tv ? (4 * h * acc_rs4 + t * 4) : kOob;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rb = row0 - split + (r & 3) + 8 * (r >> 2);
+                        e2[r] = ld_buf(racc, (rb + 4 * h + split < c_out) ? vo : kOob, rb * acc_rs4);
+                    }
+                }
+                const int voy = tv ? (4 * h * y_rs4 + t * 4) : kOob;
+                const int voy2 = tv ? (4 * h * y2_rs4 + t * 4) : kOob;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rb = row0 + (r & 3) + 8 * (r >> 2);
+                    const int row = rb + 4 * h;
+                    const bool rok = row < c_out;
+                    float v = acc[mi][ni][r] + radd[r];
                     if constexpr (MODE == TTSAMD_CONV_SHUFFLE) {
                         const int u = ep->shuffle_u;
-                        const int co = (int)(row / u);
-                        const int rr = (int)(row - (long)co * u);
+                        const int co = row / u;
+                        const int rr = row - co * u;
                         const int n = t * u + rr - ep->shuffle_pad;
-                        if (n >= 0 && n < ep->shuffle_t_out) y[(long)b * y_bs + (long)co * y_rs + n] = v;
+                        const bool ok = tv && rok && n >= 0 && n < ep->shuffle_t_out;
+                        st_buf(ry, v, ok ? (co * y_rs4 + n * 4) : kOob, 0);
                     } else if constexpr (MODE == TTSAMD_CONV_COUPLE) {
-                        const float m = omask ? omask[t] : 1.f;
-                        v = v * m;
-                        v = (res[row * res_rs + t] - v) * m;
-                        y[(long)b * y_bs + row * y_rs + t] = v;
+                        v = v * om;
+                        v = (e1[r] - v) * om;
+                        st_buf(ry, v, rok ? voy : kOob, rb * y_rs4);
                     } else if constexpr (MODE == TTSAMD_CONV_RES_SKIP) {
-                        const int split = ep->split_row;
-                        if (row < split) {
-                            v = res[row * res_rs + t] + v;
-                            if (omask) v *= omask[t];
-                            y[(long)b * y_bs + row * y_rs + t] = v;
+                        if (lower) {
+                            v = (e1[r] + v) * om;
+                            st_buf(ry, v, rok ? voy : kOob, rb * y_rs4);
                         } else {
-                            const long r2 = row - split;
-                            if (accum) v = accum[r2 * accum_rs + t] + v;
-                            ep->y2[(long)b * ep->y2_bstride + r2 * ep->y2_rstride + t] = v;
+                            v = e2[r] + v;
+                            st_buf(ry2, v, rok ? voy2 : kOob, (rb - split) * y2_rs4);
                         }
                     } else {
                         if (out_act == TTSAMD_ACT_RELU) v = fmaxf(v, 0.f);
                         else if (out_act == TTSAMD_ACT_TANH) v = tanhf(v);
-                        if (res && !folded) v += res[row * res_rs + t];
-                        if (accum) v = accum[row * accum_rs + t] + v;
-                        if (omask) v *= omask[t];
+                        v += e1[r];              // 0 when absent / folded
+                        v = e2[r] + v;
+                        v *= om;
                         if (out_div != 0.f) v = v / out_div;
-                        y[(long)b * y_bs + row * y_rs + t] = v;
+                        st_buf(ry, v, rok ? voy : kOob, rb * y_rs4);
                     }
                 }
             }
