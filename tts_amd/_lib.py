@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtts_amd.so")
+LIB_PATH = os.environ.get("TTSAMD_LIB_PATH") or os.path.join(_HERE, "libtts_amd.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "tts_amd.h")
 
 _lib = None
