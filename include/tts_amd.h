@@ -299,6 +299,13 @@ typedef struct ttsamd_mel_norm {
 int ttsamd_mel_renorm(float *y, const float *x, const ttsamd_mel_norm *tts /* host */,
                       const ttsamd_mel_norm *voc /* host */, int batch, int c, int t, void *stream);
 
+/* Speaker-conditioning helpers.
+ * g = F.normalize(d_vectors) (Vits._set_cond_input, TTS/tts/models/vits.py:882): y[r,:] = x[r,:] / max(||x[r,:]||, eps). */
+int ttsamd_l2_normalize(float *y, const float *x, int rows, int cols, float eps, void *stream);
+/* y[r,t] = x[r,t] + row_bias[r] over rows = B*C  (DurationPredictor `x + cond(g)`, TTS/tts/layers/glow_tts/duration_predictor.py:58-59;
+ * everywhere else the per-(b,channel) conditioning offset rides in a conv epilogue as ttsamd_conv1d_args.row_bias). */
+int ttsamd_add_row_bias(float *y, const float *x, const float *row_bias, int64_t rows, int t, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

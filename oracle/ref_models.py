@@ -14,12 +14,13 @@ def _sub(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def hifigan(sd, cfg, in_channels, prefix="", pre_wn=True, post_wn=True, post_bias=True):
+def hifigan(sd, cfg, in_channels, prefix="", pre_wn=True, post_wn=True, post_bias=True, cond_channels=0):
     hg = ref_shim.ref("TTS.vocoder.models.hifigan_generator")
     m = hg.HifiganGenerator(in_channels, 1, cfg["resblock_type"], cfg["resblock_dilation_sizes"],
                             cfg["resblock_kernel_sizes"], cfg["upsample_kernel_sizes"],
                             cfg["upsample_initial_channel"], cfg["upsample_factors"],
-                            inference_padding=cfg.get("inference_padding", 5), conv_pre_weight_norm=pre_wn,
+                            inference_padding=cfg.get("inference_padding", 5), cond_channels=cond_channels,
+                            conv_pre_weight_norm=pre_wn,
                             conv_post_weight_norm=post_wn, conv_post_bias=post_bias)
     m.load_state_dict(_sub(sd, prefix), strict=True)
     return m.eval()
@@ -36,17 +37,19 @@ class RefVits:
         sdp = ref_shim.ref("TTS.tts.layers.vits.stochastic_duration_predictor")
         dp = ref_shim.ref("TTS.tts.layers.glow_tts.duration_predictor")
         h = a["hidden_channels"]
+        spk = int(a.get("embedded_speaker_dim", 0) or 0)
         self.text_encoder = nw.TextEncoder(a["num_chars"], h, h, a["hidden_channels_ffn_text_encoder"],
                                            a["num_heads_text_encoder"], a["num_layers_text_encoder"],
                                            a["kernel_size_text_encoder"], 0.1, language_emb_dim=0)
         self.flow = nw.ResidualCouplingBlocks(h, h, kernel_size=a["kernel_size_flow"],
                                               dilation_rate=a["dilation_rate_flow"], num_layers=a["num_layers_flow"],
-                                              cond_channels=0)
+                                              cond_channels=spk)
         if a["use_sdp"]:
-            self.duration_predictor = sdp.StochasticDurationPredictor(h, 192, 3, 0.5, 4, cond_channels=0,
+            self.duration_predictor = sdp.StochasticDurationPredictor(h, 192, 3, 0.5, 4, cond_channels=spk,
                                                                       language_emb_dim=0)
         else:
-            self.duration_predictor = dp.DurationPredictor(h, 256, 3, 0.5, cond_channels=0, language_emb_dim=0)
+            self.duration_predictor = dp.DurationPredictor(h, 256, 3, 0.5, cond_channels=spk, language_emb_dim=0)
+        self.emb_g = sd.get("emb_g.weight")
         self.text_encoder.load_state_dict(_sub(sd, "text_encoder."), strict=True)
         self.flow.load_state_dict(_sub(sd, "flow."), strict=True)
         self.duration_predictor.load_state_dict(_sub(sd, "duration_predictor."), strict=True)
@@ -60,21 +63,26 @@ class RefVits:
                        upsample_kernel_sizes=a["upsample_kernel_sizes_decoder"],
                        upsample_initial_channel=a["upsample_initial_channel_decoder"],
                        upsample_factors=a["upsample_rates_decoder"], inference_padding=0)
-            self.waveform_decoder = hifigan(sd, cfg, h, "waveform_decoder.", False, False, False)
+            self.waveform_decoder = hifigan(sd, cfg, h, "waveform_decoder.", False, False, False, cond_channels=spk)
 
     @torch.no_grad()
-    def inference(self, x, x_lengths, seed):
+    def inference(self, x, x_lengths, seed, speaker_ids=None, d_vectors=None):
         """vits.py:1112-1173 over the real modules; RNG draws happen inside the reference modules
         (stochastic_duration_predictor.py:287, vits.py:1155) under torch.manual_seed(seed)."""
         helpers = ref_shim.ref("TTS.tts.utils.helpers")
         a = self.a
         torch.manual_seed(seed)
+        g = None                                                     # vits.py:873-886,1116-1117
+        if d_vectors is not None:
+            g = torch.nn.functional.normalize(d_vectors).unsqueeze(-1)
+        elif speaker_ids is not None:
+            g = torch.nn.functional.embedding(speaker_ids, self.emb_g).unsqueeze(-1)
         x, m_p, logs_p, x_mask = self.text_encoder(x, x_lengths, lang_emb=None)
         if a["use_sdp"]:
-            logw = self.duration_predictor(x, x_mask, g=None, reverse=True, noise_scale=a["inference_noise_scale_dp"],
+            logw = self.duration_predictor(x, x_mask, g=g, reverse=True, noise_scale=a["inference_noise_scale_dp"],
                                            lang_emb=None)
         else:
-            logw = self.duration_predictor(x, x_mask, g=None, lang_emb=None)
+            logw = self.duration_predictor(x, x_mask, g=g, lang_emb=None)
         w = torch.exp(logw) * x_mask * a["length_scale"]
         w_ceil = torch.ceil(w)
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
@@ -84,8 +92,8 @@ class RefVits:
         m_p = torch.matmul(attn.transpose(1, 2), m_p.transpose(1, 2)).transpose(1, 2)
         logs_p = torch.matmul(attn.transpose(1, 2), logs_p.transpose(1, 2)).transpose(1, 2)
         z_p = m_p + torch.randn_like(m_p) * torch.exp(logs_p) * a["inference_noise_scale"]
-        z = self.flow(z_p, y_mask, g=None, reverse=True)
-        o = self.waveform_decoder((z * y_mask)[:, :, : a["max_inference_len"]], g=None)
+        z = self.flow(z_p, y_mask, g=g, reverse=True)
+        o = self.waveform_decoder((z * y_mask)[:, :, : a["max_inference_len"]], g=g)
         return {"model_outputs": o, "alignments": attn, "durations": w_ceil, "z": z, "z_p": z_p, "m_p": m_p,
                 "logs_p": logs_p, "y_mask": y_mask, "logw": logw, "x": x}
 
@@ -116,7 +124,7 @@ class RefGlow:
         self.decoder.store_inverse()  # GlowTTS.load_checkpoint(eval=True), glow_tts.py:522-530
 
     @torch.no_grad()
-    def inference(self, x, x_lengths, seed):
+    def inference(self, x, x_lengths, seed, speaker_ids=None, d_vectors=None):
         helpers = ref_shim.ref("TTS.tts.utils.helpers")
         a = self.a
         torch.manual_seed(seed)

@@ -429,8 +429,17 @@ def vits_decoder_cfg(args):
                 upsample_factors=args["upsample_rates_decoder"], inference_padding=0)
 
 
+def vits_speaker_g(sd, speaker_ids=None, d_vectors=None):
+    """vits.py:873-886,1116-1117: g [B,C,1] from the speaker-embedding table or L2-normalised d-vectors."""
+    if d_vectors is not None:
+        return F.normalize(d_vectors).unsqueeze(-1)
+    if speaker_ids is not None:
+        return F.embedding(speaker_ids, sd["emb_g.weight"]).unsqueeze(-1)
+    return None
+
+
 def vits_inference(sd, tokens, x_lengths=None, args=None, noise_dp=None, noise_z=None, durations=None,
-                   stop_after=None):
+                   stop_after=None, g=None):
     """Vits.inference, vits.py:1088-1173 (single speaker: g=None, lang_emb=None).
 
     noise_dp [B,2,T_text] / noise_z [B,C,T_dec] replace the internal randn draws
@@ -448,9 +457,10 @@ def vits_inference(sd, tokens, x_lengths=None, args=None, noise_dp=None, noise_z
             if noise_dp is None:
                 noise_dp = torch.randn(x.size(0), 2, x.size(2))
             logw = sdp_reverse(sd, "duration_predictor.", x, x_mask, noise_dp, a["inference_noise_scale_dp"],
-                               hidden=192)
+                               hidden=192, g=g if a.get("condition_dp_on_speaker", True) else None)
         else:
-            logw = duration_predictor(sd, "duration_predictor.", x, x_mask)
+            logw = duration_predictor(sd, "duration_predictor.", x, x_mask,
+                                      g=g if a.get("condition_dp_on_speaker", True) else None)
         out["logw"] = logw
         w = torch.exp(logw) * x_mask * a["length_scale"]                    # vits.py:1140
         w_ceil = torch.ceil(w)
@@ -471,11 +481,11 @@ def vits_inference(sd, tokens, x_lengths=None, args=None, noise_dp=None, noise_z
         return out
     flow_cfg = dict(hidden=a["hidden_channels"], kernel_size=a["kernel_size_flow"],
                     dilation_rate=a["dilation_rate_flow"], num_layers=a["num_layers_flow"])
-    z = residual_coupling_blocks_reverse(sd, "flow.", z_p, y_mask, flow_cfg)
+    z = residual_coupling_blocks_reverse(sd, "flow.", z_p, y_mask, flow_cfg, g=g)
     out["z"] = z
     if stop_after == "flow":
         return out
-    o = hifigan_forward(sd, "waveform_decoder.", (z * y_mask)[:, :, : a["max_inference_len"]], vits_decoder_cfg(a))
+    o = hifigan_forward(sd, "waveform_decoder.", (z * y_mask)[:, :, : a["max_inference_len"]], vits_decoder_cfg(a), g=g)
     out["model_outputs"] = o
     return out
 

@@ -46,6 +46,26 @@ def vits_small(impl, use_sdp=True):
     return {k: out[k] for k in keys}
 
 
+def vits_small_speaker(impl, mode):
+    """Multi-speaker conditioning (vits.py:873-886,1116-1117): speaker-embedding table or external d-vectors feeding the
+    duration predictor, every flow WN and the waveform decoder."""
+    args = dict(VITS_SMALL, embedded_speaker_dim=24, use_speaker_embedding=(mode == "emb"), num_speakers=5,
+                use_sdp=(mode == "emb"))
+    sd = W.make_vits_state(args, seed=4242)
+    x = torch.randint(0, 100, (2, 25), generator=_g(3))
+    xl = torch.tensor([25, 16])
+    sid = torch.tensor([3, 1]) if mode == "emb" else None
+    dv = None if mode == "emb" else torch.randn(2, 24, generator=_g(4))
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        out = RM.RefVits(sd, args).inference(x, xl, seed=9, speaker_ids=sid, d_vectors=dv)
+    else:
+        torch.manual_seed(9)
+        out = O.vits_inference(sd, x, xl, args, g=O.vits_speaker_g(sd, sid, dv))
+    return {k: out[k] for k in ["logw", "durations", "z_p", "z", "model_outputs"]}
+
+
 GLOW_SMALL = dict(inference_noise_scale=0.33, num_flow_blocks_dec=4)
 
 
@@ -71,6 +91,8 @@ CASES = {
     "hifigan_small_rb2": lambda impl: hifigan_small(impl, "2"),
     "vits_small_sdp": lambda impl: vits_small(impl, True),
     "vits_small_dp": lambda impl: vits_small(impl, False),
+    "vits_small_spk_emb": lambda impl: vits_small_speaker(impl, "emb"),
+    "vits_small_spk_dvec": lambda impl: vits_small_speaker(impl, "dvec"),
     "glow_small": lambda impl: glow_small(impl),
     "glow_small_relwin": lambda impl: glow_small(impl, 4, "2"),
 }

@@ -106,3 +106,49 @@ extern "C" int ttsamd_mel_renorm(float *y, const float *x, const ttsamd_mel_norm
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
+
+// ---- speaker conditioning helpers ------------------------------------------------------------------------------
+namespace ttsamd {
+
+// y[r,:] = x[r,:] / max(||x[r,:]||_2, eps)   (F.normalize, vits.py:882); one wavefront per row
+__global__ void l2_normalize_kernel(float *__restrict__ y, const float *__restrict__ x, int rows, int cols, float eps)
+{
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = x[(long)r * cols + c]; s += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float d = fmaxf(sqrtf(s), eps);
+    for (int c = lane; c < cols; c += 64) y[(long)r * cols + c] = x[(long)r * cols + c] / d;
+}
+
+// y[b,c,t] = x[b,c,t] + rb[b,c]     (DurationPredictor: x + cond(g), duration_predictor.py:58-59)
+__global__ void add_row_bias_kernel(float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ rb,
+                                    long rows, int t)
+{
+    const long n = rows * t;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = x[i] + rb[i / t];
+}
+
+}  // namespace ttsamd
+
+extern "C" int ttsamd_l2_normalize(float *y, const float *x, int rows, int cols, float eps, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && x && rows >= 0 && cols > 0, "l2_normalize: bad args");
+    if (rows == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3(rows), dim3(64), 0, as_stream(stream), y, x, rows, cols, eps);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_add_row_bias(float *y, const float *x, const float *row_bias, int64_t rows, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && x && row_bias && rows >= 0 && t >= 0, "add_row_bias: bad args");
+    if (rows == 0 || t == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(add_row_bias_kernel, dim3(ew_blocks(rows * t)), dim3(kEwThreads), 0, as_stream(stream), y, x, row_bias,
+                       (long)rows, t);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}

@@ -167,12 +167,8 @@ class StochasticDurationPredictor:
     def __call__(self, x, mask, noise, noise_scale=1.0, g=None):
         """x [B,C,T] (text-encoder hidden), mask [B,T], noise [B,2,T] -> logw [B,T] view of z[:,0]."""
         h = _new(x, self.hidden)
-        row_bias = None
-        if g is not None and self.cond is not None:
-            gb = torch.empty((g.shape[0], self.hidden, 1), dtype=torch.float32, device=x.device)
-            ops.conv1d(self.cond, g.contiguous().float(), gb)
-            row_bias = gb.reshape(g.shape[0], self.hidden)
-        ops.conv1d(self.pre, x, h, row_bias=row_bias)
+        row_bias = ops.speaker_cond(self.cond, g) if (g is not None and self.cond is not None) else None
+        ops.conv1d(self.pre, x, h, row_bias=row_bias)          # pre(x) + cond(g)  (:230-233)
         h = self.convs(h, mask)
         cond = _new(h)
         ops.conv1d(self.proj, h, cond, out_mask=mask)
@@ -200,14 +196,17 @@ class StochasticDurationPredictor:
 # ------------------------------------------------------------------------------------------------
 class DurationPredictor:
     def __init__(self, sd, p, device):
+        self.cond = PackedConv(sd[p + "cond.weight"], sd[p + "cond.bias"], device) if (p + "cond.weight") in sd else None
         self.c1 = PackedConv(sd[p + "conv_1.weight"], sd[p + "conv_1.bias"], device)
         self.c2 = PackedConv(sd[p + "conv_2.weight"], sd[p + "conv_2.bias"], device)
         self.n1 = _Norm(sd, p + "norm_1", device, 1e-4)
         self.n2 = _Norm(sd, p + "norm_2", device, 1e-4)
         self.proj = PackedConv(sd[p + "proj.weight"], sd[p + "proj.bias"], device)
 
-    def __call__(self, x, mask):
+    def __call__(self, x, mask, g=None):
         """x [B,C,T] -> logw [B,T]   (conv -> relu -> LayerNorm twice, then 1x1; dropout is off in eval)."""
+        if g is not None and self.cond is not None:
+            x = ops.add_row_bias(x, ops.speaker_cond(self.cond, g))     # x + cond(g)
         h = _new(x, self.c1.c_out)
         ops.conv1d(self.c1, x, h, in_mask=mask, out_act=ACT_RELU)
         h = ops.channel_norm(h, _new(h), self.n1.gamma, self.n1.beta, self.n1.eps)
@@ -245,10 +244,8 @@ class WN:
         wavenet.py:92-116; the tanh*sigmoid gate (:6-13) lives in the in_layer conv's epilogue."""
         H = self.hidden
         gl = None
-        if g is not None and self.cond is not None:
-            gc = torch.empty((g.shape[0], self.cond.c_out, 1), dtype=torch.float32, device=x.device)
-            ops.conv1d(self.cond, g.contiguous().float(), gc)
-            gl = gc.reshape(g.shape[0], self.num_layers, 2 * H)[:, :, self.gate_idx].contiguous()
+        if g is not None and self.cond is not None:   # cond_layer(g) sliced per layer (wavenet.py:98-105), gate row order
+            gl = ops.speaker_cond(self.cond, g).reshape(g.shape[0], self.num_layers, 2 * H)[:, :, self.gate_idx].contiguous()
         acts = _new(x)
         for i in range(self.num_layers):
             ops.conv1d(self.in_layers[i], x, acts, mode=CONV_GATE, row_bias=None if gl is None else gl[:, i].contiguous())

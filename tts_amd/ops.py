@@ -365,3 +365,27 @@ def attn_durations(cum, x_mask, y_lengths):
     o = torch.empty((B, Tx), dtype=torch.float32, device=cum.device)
     check(lib().ttsamd_attn_durations(P(o), P(cum), P(x_mask), P(y_lengths), B, Tx, stream_ptr()), "attn_durations")
     return o
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x) over the last dim of a [rows, cols] tensor (vits.py:882)."""
+    x = x.float().contiguous()
+    y = torch.empty_like(x)
+    check(lib().ttsamd_l2_normalize(P(y), P(x), x.shape[0], x.shape[1], ctypes.c_float(eps), stream_ptr()), "l2_normalize")
+    return y
+
+
+def add_row_bias(x, rb):
+    """x [B,C,T] + rb [B,C] broadcast over time."""
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    check(lib().ttsamd_add_row_bias(P(y), P(x), P(rb.contiguous()), ctypes.c_int64(B * C), T, stream_ptr()), "add_row_bias")
+    return y
+
+
+def speaker_cond(pc: PackedConv, g):
+    """1x1 conv of the speaker vector g [B,Cg,1] -> per-(b, row) offsets [B, c_out] (a `row_bias` operand)."""
+    B = g.shape[0]
+    out = torch.empty((B, pc.c_out, 1), dtype=torch.float32, device=g.device)
+    conv1d(pc, g.contiguous().float(), out)
+    return out.reshape(B, pc.c_out)

@@ -140,8 +140,10 @@ def _flows(f, p, hidden, k, nflows):
         f.conv(q + "proj", 29, hidden, 1, std=0.5 / math.sqrt(hidden))  # zero-init in the reference
 
 
-def _wn(f, p, hidden, k, layers, in_channels=None):
+def _wn(f, p, hidden, k, layers, in_channels=None, cond=0):
     in_channels = in_channels or hidden
+    if cond:  # wavenet.py:60-62: weight-normed 1x1 conv producing every layer's conditioning at once
+        f.conv(p + "cond_layer", 2 * hidden * layers, cond, 1, wn=True, gain=0.5)
     for i in range(layers):
         f.conv(p + "in_layers.%d" % i, 2 * hidden, in_channels if i == 0 else hidden, k, wn=True)
         f.conv(p + "res_skip_layers.%d" % i, 2 * hidden if i < layers - 1 else hidden, hidden, 1, wn=True, gain=0.5)
@@ -159,7 +161,12 @@ def make_vits_state(args=None, seed=1234, with_decoder=True):
     _transformer(f, p + "encoder.", h, a["hidden_channels_ffn_text_encoder"], a["num_layers_text_encoder"],
                  a["num_heads_text_encoder"], a["kernel_size_text_encoder"], 4, False)
     f.conv(p + "proj", 2 * h, h, 1, gain=0.5)
+    spk = int(a.get("embedded_speaker_dim", 0) or 0)   # speaker_embedding_channels or d_vector_dim (vits.py:729-778)
+    if spk and a.get("use_speaker_embedding", False):
+        f.sd["emb_g.weight"] = f.randn(int(a.get("num_speakers", 4)), spk, std=0.5)
     p = "duration_predictor."
+    if spk:
+        f.conv(p + "cond", 192 if a["use_sdp"] else h, spk, 1, gain=0.5)
     if a["use_sdp"]:
         f.conv(p + "pre", 192, h, 1)
         _dds(f, p + "convs.", 192, 3, 3)
@@ -178,7 +185,7 @@ def make_vits_state(args=None, seed=1234, with_decoder=True):
     for i in range(4):
         q = "flow.flows.%d." % i
         f.conv(q + "pre", h, h // 2, 1)
-        _wn(f, q + "enc.", h, a["kernel_size_flow"], a["num_layers_flow"])
+        _wn(f, q + "enc.", h, a["kernel_size_flow"], a["num_layers_flow"], cond=spk)
         f.conv(q + "post", h // 2, h, 1, gain=0.5)  # zero-init in the reference
     sd = f.sd
     if with_decoder:
@@ -189,6 +196,11 @@ def make_vits_state(args=None, seed=1234, with_decoder=True):
                    upsample_factors=a["upsample_rates_decoder"])
         sd.update(make_hifigan_state(cfg, h, seed=seed + 1, prefix="waveform_decoder.", pre_wn=False, post_wn=False,
                                      post_bias=False))
+        if spk:  # hifigan_generator.py:215-216
+            g2 = torch.Generator().manual_seed(seed + 2)
+            sd["waveform_decoder.cond_layer.weight"] = torch.randn(a["upsample_initial_channel_decoder"], spk, 1,
+                                                                   generator=g2) * (0.5 / math.sqrt(spk))
+            sd["waveform_decoder.cond_layer.bias"] = torch.randn(a["upsample_initial_channel_decoder"], generator=g2) * 0.05
     return sd
 
 

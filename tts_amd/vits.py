@@ -59,15 +59,24 @@ class Vits:
         self.inference_noise_scale = a.inference_noise_scale
         self.inference_noise_scale_dp = a.inference_noise_scale_dp
         self.max_inference_len = a.max_inference_len
-        if a.use_language_embedding or a.use_speaker_embedding or a.use_d_vector_file:
-            raise _lib.TtsAmdError("tts_amd.Vits: multi-speaker / multi-lingual conditioning is not built yet "
-                                   "(LJSpeech single-speaker path only)")
+        if a.use_language_embedding:
+            raise _lib.TtsAmdError("tts_amd.Vits: language embeddings (multi-lingual models) are not built")
+        # init_multispeaker (vits.py:729-778): learned table or external d-vectors
+        self.embedded_speaker_dim = 0
+        if a.use_speaker_embedding and a.num_speakers > 0:
+            self.embedded_speaker_dim = a.speaker_embedding_channels
+        if a.use_d_vector_file:
+            if self.embedded_speaker_dim:
+                raise ValueError("[!] Speaker embedding layer already initialized before d_vector settings.")
+            self.embedded_speaker_dim = a.d_vector_dim
+        self.emb_g = None
         if a.encoder_sample_rate:
             raise _lib.TtsAmdError("tts_amd.Vits: encoder_sample_rate / interpolate_z is not built")
         self.waveform_decoder = HifiganGenerator(
             a.hidden_channels, 1, a.resblock_type_decoder, a.resblock_dilation_sizes_decoder,
             a.resblock_kernel_sizes_decoder, a.upsample_kernel_sizes_decoder, a.upsample_initial_channel_decoder,
-            a.upsample_rates_decoder, inference_padding=0, cond_channels=0, conv_pre_weight_norm=False,
+            a.upsample_rates_decoder, inference_padding=0, cond_channels=self.embedded_speaker_dim,
+            conv_pre_weight_norm=False,
             conv_post_weight_norm=False, conv_post_bias=False)  # vits.py:704-718
         self.device = torch.device("cpu")
         self._sd = None
@@ -118,18 +127,39 @@ class Vits:
         a, sd, dev = self.args, self._sd, self.device
         self.text_encoder = layers.TextEncoder(sd, "text_encoder.", dev, a.hidden_channels, a.num_layers_text_encoder,
                                                a.num_heads_text_encoder, a.kernel_size_text_encoder)
+        spk = self.embedded_speaker_dim
+        self.emb_g = sd["emb_g.weight"].to(dev, torch.float32).contiguous() if (spk and "emb_g.weight" in sd) else None
         if a.use_sdp:
             self.duration_predictor = layers.StochasticDurationPredictor(sd, "duration_predictor.", dev, a.hidden_channels,
-                                                                         192, 3, 4)
+                                                                         192, 3, 4, cond_channels=spk)
         else:
             self.duration_predictor = layers.DurationPredictor(sd, "duration_predictor.", dev)
         self.flow = layers.ResidualCouplingBlocks(sd, "flow.", dev, a.hidden_channels, a.hidden_channels, a.kernel_size_flow,
-                                                  a.dilation_rate_flow, a.num_layers_flow)
+                                                  a.dilation_rate_flow, a.num_layers_flow, cond_channels=spk)
         self.waveform_decoder.load_state_dict(sd, prefix="waveform_decoder.")
         self.waveform_decoder.to(dev)
 
     def weight_bytes(self):
         return sum(v.numel() * 4 for v in self._sd.values())
+
+    def _speaker_g(self, aux_input, B, dev):
+        """_set_cond_input / _set_speaker_input (vits.py:873-905,1112-1117): g [B, C_spk, 1] or None."""
+        aux_input = aux_input or {}
+        sid, dvec = aux_input.get("speaker_ids"), aux_input.get("d_vectors")
+        if sid is None and dvec is None:
+            return None
+        if not self.embedded_speaker_dim:
+            raise ValueError("[!] speaker_ids / d_vectors given to a single-speaker model.")
+        if dvec is not None and sid is not None:
+            raise ValueError("[!] Cannot use d-vectors and speaker-ids together.")
+        if dvec is not None:
+            dvec = dvec.to(dev, torch.float32)
+            return ops.l2_normalize(dvec.reshape(-1, dvec.shape[-1])).unsqueeze(-1)
+        if self.emb_g is None:
+            raise ValueError("[!] Cannot use speaker-ids without enabling speaker embedding.")
+        sid = sid.to(dev, torch.int64).reshape(-1, 1).contiguous()
+        g = torch.empty((sid.shape[0], self.emb_g.shape[1], 1), dtype=torch.float32, device=dev)
+        return ops.embed(sid, self.emb_g, None, 1.0, g)               # emb_g(sid).unsqueeze(-1)
 
     # ---- inference (vits.py:1088-1173) ---------------------------------------------------------------
     @torch.no_grad()
@@ -149,6 +179,8 @@ class Vits:
         if x_lengths is None:
             x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)       # vits.py:1082-1086
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
+        g = self._speaker_g(aux_input, B, dev)
+        g_dp = g if a.condition_dp_on_speaker else None
         h, stats = self.text_encoder(x, x_mask)
         H = a.hidden_channels
         durations = aux_input.get("durations") if aux_input else None
@@ -161,9 +193,9 @@ class Vits:
                 if noise_dp is None:
                     noise_dp = torch.randn(B, 2, T, device=dev, dtype=torch.float32)
                 logw = self.duration_predictor(h, x_mask, noise_dp.to(dev, torch.float32).contiguous(),
-                                               self.inference_noise_scale_dp)
+                                               self.inference_noise_scale_dp, g=g_dp)
             else:
-                logw = self.duration_predictor(h, x_mask)
+                logw = self.duration_predictor(h, x_mask, g=g_dp)
         if durations is None:
             w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale))
         else:
@@ -179,12 +211,12 @@ class Vits:
                                float(self.inference_noise_scale), second_copy=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)
         y_mask = pri["y_mask"]
-        z = self.flow(pri["z_p2"], y_mask)
+        z = self.flow(pri["z_p2"], y_mask, g=g)
         zd = z if self.max_inference_len is None else z[:, :, : self.max_inference_len].contiguous()
         md = y_mask if self.max_inference_len is None else y_mask[:, : self.max_inference_len].contiguous()
         # "ragged_exact": every decoder conv treats row b as ending at y_lengths[b] -> row b equals a B=1 run
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
-        o = self.waveform_decoder.forward(zd, in_mask=md, lengths=y_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
+        o = self.waveform_decoder.forward(zd, g=g, in_mask=md, lengths=y_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
         outputs = {
             "model_outputs": o,
             "alignments": attn,
