@@ -5,8 +5,8 @@
 // DilatedDepthSeparableConv (vits/stochastic_duration_predictor.py:46-63).
 //
 // HBM/latency-bound.  Layout decision: the normalised axis (C) is the STRIDED one, so lanes run along
-// time (coalesced 256-byte row segments per wavefront) and each workgroup is 64 time columns x 4 channel
-// groups; a thread keeps its C/4 channel values in registers between the statistics passes (the tensor
+// time (coalesced 256-byte row segments per wavefront) and each workgroup is 64 time columns x 16 channel
+// groups; a thread keeps its C/16 channel values in registers between the statistics passes (the tensor
 // is read exactly once), partial sums meet in LDS in a fixed order (deterministic).
 #include "common.h"
 
@@ -109,9 +109,11 @@ extern "C" int ttsamd_channel_norm(const ttsamd_norm_args *args, void *stream)
     TTSAMD_CHECK_ARG(a.batch <= 65535, "channel_norm: batch > 65535");
     const dim3 grid((a.t + 63) / 64, a.batch);
     hipStream_t st = as_stream(stream);
-    if (a.c <= 192) hipLaunchKernelGGL((channel_norm_kernel<48, 4>), grid, dim3(64, 4), 0, st, a);
-    else if (a.c <= 256) hipLaunchKernelGGL((channel_norm_kernel<64, 4>), grid, dim3(64, 4), 0, st, a);
-    else hipLaunchKernelGGL((channel_norm_kernel<64, 8>), grid, dim3(64, 8), 0, st, a);
+    // 16 channel groups x 64 time lanes = 1024 threads per block: the launch is latency-bound (a few MB), so the
+    // per-thread dependent chain is kept short (12..32 channels) rather than the block count high
+    if (a.c <= 192) hipLaunchKernelGGL((channel_norm_kernel<12, 16>), grid, dim3(64, 16), 0, st, a);
+    else if (a.c <= 256) hipLaunchKernelGGL((channel_norm_kernel<16, 16>), grid, dim3(64, 16), 0, st, a);
+    else hipLaunchKernelGGL((channel_norm_kernel<32, 16>), grid, dim3(64, 16), 0, st, a);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

@@ -1,0 +1,47 @@
+"""hipGraph capture of launch-bound segments (the text encoder + duration predictor is ~170 tiny launches whose
+host-side issue cost exceeds their GPU time).  The segment is captured once per input shape on torch's capture
+stream — every kernel of this package is launched on `torch.cuda.current_stream()`, so plain HIP stream capture
+records them — and replayed as ONE graph launch.  Inputs are copied into static buffers; outputs alias static
+buffers and are valid until the next replay of the same graph."""
+import torch
+
+
+class GraphedSegment:
+    def __init__(self, fn, example_inputs):
+        self.static_in = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up outside capture: one-time hipFuncSetAttribute calls, allocator
+            for _ in range(2):
+                fn(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = fn(*self.static_in)
+
+    def __call__(self, *inputs):
+        for s, t in zip(self.static_in, inputs):
+            s.copy_(t)
+        self.graph.replay()
+        return self.static_out
+
+
+class GraphCache:
+    """Shape-keyed cache of captured segments with an eager escape hatch (capture disabled or failed)."""
+
+    def __init__(self, fn, max_entries=8):
+        self.fn, self.max_entries = fn, max_entries
+        self.entries = {}
+        self.enabled = True
+
+    def __call__(self, *inputs, key=None):
+        """`key`: extra hashable state the captured launches depend on (scalars baked into the graph)."""
+        if not self.enabled:
+            return self.fn(*inputs)
+        key = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
+        seg = self.entries.get(key)
+        if seg is None:
+            if len(self.entries) >= self.max_entries:
+                self.entries.pop(next(iter(self.entries)))
+            seg = self.entries[key] = GraphedSegment(self.fn, inputs)
+        return seg(*inputs)

@@ -9,7 +9,7 @@ the reference's names and argument meaning.  Training, ONNX export, voice conver
 """
 import torch
 
-from . import _lib, layers, ops
+from . import _lib, graphs, layers, ops
 from .hifigan import HifiganGenerator
 
 VITS_ARGS_DEFAULTS = dict(  # VitsArgs, vits.py:544-600
@@ -81,6 +81,10 @@ class Vits:
         self.device = torch.device("cpu")
         self._sd = None
         self.text_encoder = self.duration_predictor = self.flow = None
+        # the text encoder + duration predictor (~170 launches of a few microseconds) replay as one hipGraph per input
+        # shape; set `use_graphs = False` for eager launches
+        self.use_graphs = True
+        self._front = graphs.GraphCache(self._front_eager)
 
     # ---- plug-in surface ---------------------------------------------------------------------------
     @staticmethod
@@ -142,6 +146,16 @@ class Vits:
     def weight_bytes(self):
         return sum(v.numel() * 4 for v in self._sd.values())
 
+    def _front_eager(self, x, x_mask, noise_dp, g_dp):
+        """Text encoder + duration predictor: tokens -> (hidden, prior stats, logw).  g_dp [B,C,1] or an empty tensor."""
+        h, stats = self.text_encoder(x, x_mask)
+        g = g_dp if g_dp.numel() else None
+        if self.args.use_sdp:
+            logw = self.duration_predictor(h, x_mask, noise_dp, self.inference_noise_scale_dp, g=g)
+        else:
+            logw = self.duration_predictor(h, x_mask, g=g)
+        return h, stats, logw.contiguous()
+
     def _speaker_g(self, aux_input, B, dev):
         """_set_cond_input / _set_speaker_input (vits.py:873-905,1112-1117): g [B, C_spk, 1] or None."""
         aux_input = aux_input or {}
@@ -181,21 +195,22 @@ class Vits:
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
         g = self._speaker_g(aux_input, B, dev)
         g_dp = g if a.condition_dp_on_speaker else None
-        h, stats = self.text_encoder(x, x_mask)
         H = a.hidden_channels
         durations = aux_input.get("durations") if aux_input else None
-        logw = None
         # the reference skips the duration predictor when durations are injected (vits.py:1124-1143);
         # "run_duration_predictor" keeps it in the pass anyway (bench.py: fixed output length, no work skipped)
-        if durations is None or aux_input.get("run_duration_predictor"):
-            if a.use_sdp:
-                noise_dp = aux_input.get("noise_dp") if aux_input else None
-                if noise_dp is None:
-                    noise_dp = torch.randn(B, 2, T, device=dev, dtype=torch.float32)
-                logw = self.duration_predictor(h, x_mask, noise_dp.to(dev, torch.float32).contiguous(),
-                                               self.inference_noise_scale_dp, g=g_dp)
-            else:
-                logw = self.duration_predictor(h, x_mask, g=g_dp)
+        need_dp = durations is None or bool(aux_input.get("run_duration_predictor"))
+        logw = None
+        if need_dp:
+            noise_dp = aux_input.get("noise_dp") if aux_input else None
+            if noise_dp is None:
+                noise_dp = torch.randn(B, 2, T, device=dev, dtype=torch.float32) if a.use_sdp else torch.empty(0, device=dev)
+            noise_dp = noise_dp.to(dev, torch.float32).contiguous()
+            gd = g_dp if g_dp is not None else torch.empty(0, device=dev)
+            self._front.enabled = bool(self.use_graphs) and not (aux_input or {}).get("no_graph", False)
+            h, stats, logw = self._front(x, x_mask, noise_dp, gd, key=float(self.inference_noise_scale_dp))
+        else:
+            h, stats = self.text_encoder(x, x_mask)
         if durations is None:
             w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale))
         else:
@@ -230,7 +245,8 @@ class Vits:
         if ragged:
             outputs["y_lengths"] = y_lengths
         if aux_input and aux_input.get("return_extras"):
-            outputs.update(x=h, logw=None if logw is None else logw.unsqueeze(1), y_lengths=y_lengths)
+            # (h / logw may alias the captured front end's static buffers: hand out copies)
+            outputs.update(x=h.clone(), logw=None if logw is None else logw.clone().unsqueeze(1), y_lengths=y_lengths)
         return outputs
 
     __call__ = inference
