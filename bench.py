@@ -74,6 +74,63 @@ def cpu_baseline(sd, n_chars, seconds_budget=20.0):
                       % (n, n_chars, out["model_outputs"].shape[-1], threads, cores, samples / t_used / SAMPLE_RATE)}
 
 
+def bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel):
+    """BASELINE configs[2]: HiFiGAN-v1 vocoder only on precomputed 80-bin mels, batch 256 x 8192 frames per GPU
+    (hifigan_config.py:95-104 generator, inference_padding 5, weight-norm folded).  The layer-by-layer live set of the
+    literal shape is 6 x 69 GB, so the batch runs in slabs (HifiganGenerator.inference_slabbed); mels resident in HBM."""
+    from tts_amd.hifigan import HifiganGenerator
+
+    cfg = dict(W.HIFIGAN_V1)
+    sd = W.make_hifigan_state(cfg, 80, seed=1234) if rank == 0 else None
+    sd = parallel.broadcast_state_dict(sd, src=0, device=dev)
+    m = HifiganGenerator(80, 1, cfg["resblock_type"], cfg["resblock_dilation_sizes"], cfg["resblock_kernel_sizes"],
+                         cfg["upsample_kernel_sizes"], cfg["upsample_initial_channel"], cfg["upsample_factors"],
+                         inference_padding=cfg["inference_padding"])
+    m.load_state_dict(sd)
+    m.to(dev)
+    mel = torch.randn(args.items, 80, args.frames, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+    out = torch.empty((args.items, 1, (args.frames + 10) * 256), dtype=torch.float32, device=dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        m.inference_slabbed(mel, out)
+    timer = ops.ConvTimer(lambda pc, a: "conv")
+    ops.set_conv_timer(timer)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.inference_slabbed(mel, out)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.set_conv_timer(None)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        r = timer.results()["conv"]
+        samples = float(out.shape[0] * out.shape[2]) * world
+        value = samples * args.steps / float(tt.item())
+        print(json.dumps({
+            "metric": "audio samples/sec (HiFiGAN-v1 vocoder only, 80-bin mels -> 22.05 kHz waveform)", "value": value,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": float(tt.item()) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_x": value / SAMPLE_RATE,
+            "config": {"workload": "configs[2]: HiFiGAN-v1 vocoder only, batch=%d x %d-frame mels per GPU, slabbed"
+                                   % (args.items, args.frames), "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "all conv1d_mfma_kernel launches of the generator",
+                         "achieved": r["flops"] / (r["ms"] * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": r["flops"] / (r["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "algorithmic_gbps": r["bytes"] / (r["ms"] * 1e-3) / 1e9,
+                         "launches_timed": r["launches"]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,7 +139,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--chars", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e"])
+    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1"],
+                    help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
+    ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
+    ap.add_argument("--items", type=int, default=256, help="hifigan_v1: items per GPU per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +161,9 @@ def main():
     from tts_amd import synthetic as W         # seeded synthetic checkpoint (no network => no released weights)
     from tts_amd import ops, parallel
     from tts_amd.vits import Vits
+
+    if args.workload == "hifigan_v1":
+        return bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel)
 
     # rank 0 builds the weights, everyone else receives them in one RCCL broadcast
     sd = W.make_vits_state({}, seed=1234) if rank == 0 else None

@@ -16,6 +16,14 @@ from .ops import ACT_LRELU, ACT_TANH, CONV_SHUFFLE, PackedConv
 LRELU_SLOPE = 0.1  # hifigan_generator.py:11
 
 
+def _cumprod(xs):
+    out, p = [], 1
+    for x in xs:
+        p *= x
+        out.append(p)
+    return out
+
+
 class HifiganGenerator:
     def __init__(self, in_channels, out_channels, resblock_type, resblock_dilation_sizes, resblock_kernel_sizes,
                  upsample_kernel_sizes, upsample_initial_channel, upsample_factors, inference_padding=5,
@@ -176,6 +184,30 @@ class HifiganGenerator:
         return wav
 
     __call__ = forward
+
+    @torch.no_grad()
+    def inference_slabbed(self, c, out=None, max_live_bytes=48 << 30):
+        """`inference` over a batch too large to hold layer-by-layer (BASELINE config 3: [256, 80, 8192] mels would need
+        6 live tensors of 69 GB each): the batch is cut into slabs whose live activations fit `max_live_bytes`; items are
+        independent, so slabbing changes nothing numerically.  c may live on the host or the device; `out`
+        ([B,1,(T+2p)*hop], host or device) receives the waveforms (allocated on c's device if None)."""
+        B, C, T = c.shape
+        hop = 1
+        for u in self.upsample_factors:
+            hop *= u
+        t_out = (T + 2 * self.inference_padding) * hop
+        # peak live set per item: ~6 tensors of [C0/2, T*u0] floats at the widest stage (up, tmp, xa, xb, zsum, o_next)
+        widest = max((self.upsample_initial_channel >> (i + 1)) * hop_i for i, hop_i in
+                     enumerate(_cumprod(self.upsample_factors)))
+        per_item = 6 * 4 * widest * (T + 2 * self.inference_padding)
+        slab = max(1, min(B, int(max_live_bytes // max(per_item, 1))))
+        if out is None:
+            out = torch.empty((B, self.out_channels, t_out), dtype=torch.float32, device=c.device)
+        for lo in range(0, B, slab):
+            hi = min(B, lo + slab)
+            w = self.inference(c[lo:hi].to(self.device, non_blocking=True))
+            out[lo:hi].copy_(w, non_blocking=True)
+        return out
 
     @torch.no_grad()
     def inference(self, c, lengths=None):
