@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--chars", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-branches", action="store_true",
+                    help="run the MRF resblock branches on one stream (for rocprof: per-kernel durations are then not "
+                         "inflated by co-running kernels; the roofline pass always runs this way)")
     ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1"],
                     help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
@@ -198,16 +201,32 @@ def main():
         # every other waveform-decoder / flow conv; the tiny text-side launches are left untouched
         return "other_conv" if 2.0 * pc.c_out * pc.c_in * pc.kernel * a.t_out * a.batch >= 1e9 else None
 
-    timer = ops.ConvTimer(select)
-    if not os.environ.get("TTSAMD_BENCH_NO_TIMER"):
-        ops.set_conv_timer(timer)
+    if args.serial_branches:
+        model.waveform_decoder.concurrent_branches = False
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    ops.set_conv_timer(None)
+
+    # Roofline pass (rank 0 only, AFTER the timed region, same inputs): in the timed region the three MRF resblock
+    # branches run on three HIP streams, so an event pair around one launch also counts the kernels co-running with it.
+    # Here the branches are serialised on one stream and every conv launch of the decoder / flows is bracketed by HIP
+    # events on the stream it is launched on.
+    timer = ops.ConvTimer(select)
+    roof_steps = 2
+    if rank == 0:
+        was = model.waveform_decoder.concurrent_branches
+        model.waveform_decoder.concurrent_branches = False
+        step()
+        torch.cuda.synchronize()
+        ops.set_conv_timer(timer)
+        for _ in range(roof_steps):
+            step()
+        torch.cuda.synchronize()
+        ops.set_conv_timer(None)
+        model.waveform_decoder.concurrent_branches = was
 
     samples_per_step = int(out["y_mask"].sum().item()) * 256        # valid output samples of this rank's shard
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -242,7 +261,8 @@ def main():
             "config": {"workload": "configs[1]: LJSpeech VITS end-to-end, batch=%d random %d-char utterances per GPU "
                                    "(257 ids, 770 frames, 197120 samples each), 22.05 kHz" % (args.batch, args.chars),
                        "utterances_per_gpu": args.batch, "chars": args.chars, "parallelism": "replicas x%d" % world,
-                       "weights": "random-init VitsArgs defaults (29.1 M params), broadcast from rank 0 in %.3f s" % bcast_s},
+                       "weights": "random-init VitsArgs defaults (29.1 M params), broadcast from rank 0 in %.3f s" % bcast_s,
+                       "mrf_branch_streams": 1 if args.serial_branches else 3},
             "roofline": {
                 "bound": "mfma", "kernel": "ttsamd::conv1d_mfma_kernel<11,1,2,2,2,2,0> (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
                 "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -252,7 +272,10 @@ def main():
                 "all_conv_launches": {"launches": allc["launches"],
                                       "tflops": allc["flops"] / (allc["ms"] * 1e-3) / 1e12 if allc["ms"] else 0.0,
                                       "algorithmic_gbps": allc["bytes"] / (allc["ms"] * 1e-3) / 1e9 if allc["ms"] else 0.0,
-                                      "ms_per_step": allc["ms"] / args.steps},
+                                      "ms_per_step": allc["ms"] / roof_steps},
+                "measured": "%d extra steps after the timed region with the MRF branch streams serialised (in the timed "
+                            "region three branch streams overlap and inflate per-launch event times); HIP events on the "
+                            "launch stream" % roof_steps,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -46,6 +46,8 @@ class HifiganGenerator:
         self.device = torch.device("cpu")
         self._sd = None
         self._packed = None
+        self.concurrent_branches = True     # MRF resblocks on separate HIP streams (see forward)
+        self._side_streams = []
 
     # ---- torch.nn.Module-like surface used by Synthesizer (synthesizer.py:222-225,379) -----------
     def parameters(self):
@@ -111,6 +113,11 @@ class HifiganGenerator:
     def weight_bytes(self):
         return sum(p.nbytes() for p in self._packed.values())
 
+    def _streams(self, n):
+        while len(self._side_streams) < n:
+            self._side_streams.append(torch.cuda.Stream(device=self.device))
+        return self._side_streams[:n]
+
     # ---- forward (hifigan_generator.py:236-265) ----------------------------------------------------
     @torch.no_grad()
     def forward(self, x, g=None, in_mask=None, lengths=None):
@@ -156,27 +163,52 @@ class HifiganGenerator:
             T = T_up
             o_next = new(ch, T)
             zsum = new(ch, T) if nk > 1 else None
-            tmp, xa, xb = new(ch, T), new(ch, T), new(ch, T)
+            # The MRF's resblocks are independent until their last conv (which chains the accumulate r1 + r2 + r3 in
+            # the reference's order): each branch runs on its own HIP stream so that one branch's launch tail / ramp
+            # overlaps another branch's compute; events order only the accumulating convs.
+            main = torch.cuda.current_stream()
+            side = self._streams(nk) if self.concurrent_branches and nk > 1 else None
+            ev_up = torch.cuda.Event() if side else None
+            if side:
+                ev_up.record(main)
+            prev_done = None
+            keep = []   # branch buffers stay referenced until the branches are joined (allocator reuse is per stream)
             for j in range(nk):
                 rp = "resblocks.%d." % (i * nk + j)
                 dil = self.resblock_dilation_sizes[j]
-                cur = up
-                for m in range(len(dil)):
-                    last = m == len(dil) - 1
-                    if last:  # fuse the MRF accumulate / average into the block's last conv
-                        dst = o_next if j == nk - 1 else zsum
-                        accum = zsum if j > 0 else None
-                        div = float(nk) if j == nk - 1 else 0.0
-                    else:
-                        dst, accum, div = (xa if cur is not xa else xb), None, 0.0
-                    if self.resblock_type == "1":
-                        ops.conv1d(P[rp + "convs1.%d" % m], cur, tmp, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, in_mask=msk)
-                        ops.conv1d(P[rp + "convs2.%d" % m], tmp, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
-                                   res=cur, accum=accum, out_div=div, in_mask=msk)
-                    else:
-                        ops.conv1d(P[rp + "convs.%d" % m], cur, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
-                                   res=cur, accum=accum, out_div=div, in_mask=msk)
-                    cur = dst
+                tmp, xa, xb = new(ch, T), new(ch, T), new(ch, T)
+                keep += [tmp, xa, xb]
+                st = side[j] if side else main
+                if side:
+                    st.wait_event(ev_up)
+                with torch.cuda.stream(st):
+                    cur = up
+                    for m in range(len(dil)):
+                        last = m == len(dil) - 1
+                        if last:  # fuse the MRF accumulate / average into the block's last conv
+                            dst = o_next if j == nk - 1 else zsum
+                            accum = zsum if j > 0 else None
+                            div = float(nk) if j == nk - 1 else 0.0
+                        else:
+                            dst, accum, div = (xa if cur is not xa else xb), None, 0.0
+                        if self.resblock_type == "1":
+                            ops.conv1d(P[rp + "convs1.%d" % m], cur, tmp, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, in_mask=msk)
+                            if last and side and prev_done is not None:
+                                st.wait_event(prev_done)      # zsum holds the previous branches' sum
+                            ops.conv1d(P[rp + "convs2.%d" % m], tmp, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
+                                       res=cur, accum=accum, out_div=div, in_mask=msk)
+                        else:
+                            if last and side and prev_done is not None:
+                                st.wait_event(prev_done)
+                            ops.conv1d(P[rp + "convs.%d" % m], cur, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
+                                       res=cur, accum=accum, out_div=div, in_mask=msk)
+                        cur = dst
+                    if side:
+                        prev_done = torch.cuda.Event()
+                        prev_done.record(st)
+            if side:
+                main.wait_event(prev_done)       # the last branch's final conv completes the chain
+            del keep
             o = o_next
         wav = new(self.out_channels, T)
         # final F.leaky_relu(o) uses the DEFAULT slope 0.01 (hifigan_generator.py:262)
