@@ -306,6 +306,11 @@ int ttsamd_l2_normalize(float *y, const float *x, int rows, int cols, float eps,
  * everywhere else the per-(b,channel) conditioning offset rides in a conv epilogue as ttsamd_conv1d_args.row_bias). */
 int ttsamd_add_row_bias(float *y, const float *x, const float *row_bias, int64_t rows, int t, void *stream);
 
+/* 1-D linear interpolation along time, exactly torch.nn.functional.interpolate(x, scale_factor=[s], mode="linear")
+ * (align_corners=False, the given scale factor drives the coordinate map) — HifiDecoder.forward,
+ * TTS/tts/layers/xtts/hifigan_decoder.py:688-700.  x [rows, t_in] -> y [rows, t_out], t_out = floor(t_in * s). */
+int ttsamd_linear_interp(float *y, const float *x, int64_t rows, int t_in, int t_out, double scale_factor, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

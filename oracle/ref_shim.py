@@ -35,6 +35,11 @@ def install():
         stub.Coqpit = type("Coqpit", (), {})
         stub.check_argument = lambda *a, **k: None
         sys.modules["coqpit"] = stub
+    if "torchaudio" not in sys.modules:
+        try:
+            import torchaudio  # noqa: F401
+        except Exception:  # only the XTTS speaker encoder touches it (never instantiated here)
+            sys.modules["torchaudio"] = types.ModuleType("torchaudio")
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
     import TTS  # noqa: F401

@@ -105,6 +105,8 @@ def hifigan_forward(sd, p, x, cfg, g=None):
     for i, (u, k) in enumerate(zip(cfg["upsample_factors"], cfg["upsample_kernel_sizes"])):
         o = F.leaky_relu(o, LRELU_SLOPE)
         o = F.conv_transpose1d(o, weight(sd, p + "ups.%d" % i), bias(sd, p + "ups.%d" % i), u, (k - u) // 2)
+        if g is not None and (p + "conds.%d.weight" % i) in sd:   # XTTS variant, xtts/hifigan_decoder.py:283-284
+            o = o + conv1d(sd, p + "conds.%d" % i, g)
         z_sum = None
         for j in range(nk):
             r = rb(sd, p + "resblocks.%d." % (i * nk + j), o, cfg["resblock_kernel_sizes"][j],
@@ -114,6 +116,17 @@ def hifigan_forward(sd, p, x, cfg, g=None):
     o = F.leaky_relu(o)  # default slope 0.01 (hifigan_generator.py:262)
     o = conv1d(sd, p + "conv_post", o, padding=3)
     return torch.tanh(o)
+
+
+def hifi_decoder_forward(sd, latents, g, cfg, input_sample_rate=22050, output_sample_rate=24000, output_hop_length=256,
+                         ar_mel_length_compression=1024):
+    """HifiDecoder.forward, TTS/tts/layers/xtts/hifigan_decoder.py:675-701: latents [B,T,C] -> two linear
+    interpolations -> the conditioned generator (prefix `waveform_decoder.`)."""
+    z = F.interpolate(latents.transpose(1, 2), scale_factor=[ar_mel_length_compression / output_hop_length],
+                      mode="linear").squeeze(1)
+    if output_sample_rate != input_sample_rate:
+        z = F.interpolate(z, scale_factor=[output_sample_rate / input_sample_rate], mode="linear").squeeze(0)
+    return hifigan_forward(sd, "waveform_decoder.", z, cfg, g=g)
 
 
 def hifigan_inference(sd, p, c, cfg):

@@ -66,6 +66,30 @@ def vits_small_speaker(impl, mode):
     return {k: out[k] for k in ["logw", "durations", "z_p", "z", "model_outputs"]}
 
 
+def xtts_hifi_decoder(impl):
+    """XTTS HifiDecoder vocoder half (xtts/hifigan_decoder.py:675-701): interpolated GPT latents + d-vector conditioning
+    at the input and after every upsampling layer."""
+    sd, cfg = W.make_hifi_decoder_state(decoder_input_dim=96, d_vector_dim=32, upsample_initial_channel=64, seed=31)
+    lat = torch.randn(2, 9, 96, generator=_g(5))
+    g = torch.randn(2, 32, 1, generator=_g(6))
+    if impl == "ref":
+        from oracle import ref_shim
+
+        m = ref_shim.ref("TTS.tts.layers.xtts.hifigan_decoder")
+        net = m.HifiganGenerator(96, 1, "1", cfg["resblock_dilation_sizes"], cfg["resblock_kernel_sizes"],
+                                 cfg["upsample_kernel_sizes"], 64, cfg["upsample_factors"], inference_padding=0,
+                                 cond_channels=32, conv_pre_weight_norm=False, conv_post_weight_norm=False,
+                                 conv_post_bias=False, cond_in_each_up_layer=True).eval()
+        net.load_state_dict({k[len("waveform_decoder."):]: v for k, v in sd.items()}, strict=True)
+        with torch.no_grad():   # HifiDecoder.forward, restated over the real generator (the class itself needs torchaudio)
+            z = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[1024 / 256], mode="linear").squeeze(1)
+            z = torch.nn.functional.interpolate(z, scale_factor=[24000 / 22050], mode="linear").squeeze(0)
+            o = net(z, g=g)
+    else:
+        o = O.hifi_decoder_forward(sd, lat, g, cfg)
+    return {"wav": o}
+
+
 GLOW_SMALL = dict(inference_noise_scale=0.33, num_flow_blocks_dec=4)
 
 
@@ -93,6 +117,7 @@ CASES = {
     "vits_small_dp": lambda impl: vits_small(impl, False),
     "vits_small_spk_emb": lambda impl: vits_small_speaker(impl, "emb"),
     "vits_small_spk_dvec": lambda impl: vits_small_speaker(impl, "dvec"),
+    "xtts_hifi_decoder": xtts_hifi_decoder,
     "glow_small": lambda impl: glow_small(impl),
     "glow_small_relwin": lambda impl: glow_small(impl, 4, "2"),
 }

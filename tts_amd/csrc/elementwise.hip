@@ -152,3 +152,33 @@ extern "C" int ttsamd_add_row_bias(float *y, const float *x, const float *row_bi
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
+
+// ---- linear interpolation along time (F.interpolate(mode="linear", align_corners=False, scale_factor=s)) ---------
+namespace ttsamd {
+__global__ void linear_interp_kernel(float *__restrict__ y, const float *__restrict__ x, long rows, int t_in, int t_out,
+                                     float rscale)
+{
+    const long n = rows * t_out;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / t_out;
+        const int o = (int)(i - r * t_out);
+        float src = rscale * ((float)o + 0.5f) - 0.5f;        // area_pixel_compute_source_index (align_corners=False)
+        src = src < 0.f ? 0.f : src;
+        const int i0 = min((int)src, t_in - 1);
+        const int i1 = i0 + (i0 < t_in - 1 ? 1 : 0);
+        const float l1 = src - (float)i0, l0 = 1.f - l1;
+        y[i] = l0 * x[r * t_in + i0] + l1 * x[r * t_in + i1];
+    }
+}
+}  // namespace ttsamd
+
+extern "C" int ttsamd_linear_interp(float *y, const float *x, int64_t rows, int t_in, int t_out, double scale_factor,
+                                    void *stream)
+{
+    TTSAMD_CHECK_ARG(y && x && rows >= 0 && t_in > 0 && t_out >= 0 && scale_factor > 0, "linear_interp: bad args");
+    if (rows == 0 || t_out == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(linear_interp_kernel, dim3(ew_blocks(rows * t_out)), dim3(kEwThreads), 0, as_stream(stream), y, x,
+                       (long)rows, t_in, t_out, (float)(1.0 / scale_factor));
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}

@@ -27,7 +27,8 @@ def _cumprod(xs):
 class HifiganGenerator:
     def __init__(self, in_channels, out_channels, resblock_type, resblock_dilation_sizes, resblock_kernel_sizes,
                  upsample_kernel_sizes, upsample_initial_channel, upsample_factors, inference_padding=5,
-                 cond_channels=0, conv_pre_weight_norm=True, conv_post_weight_norm=True, conv_post_bias=True):
+                 cond_channels=0, conv_pre_weight_norm=True, conv_post_weight_norm=True, conv_post_bias=True,
+                 cond_in_each_up_layer=False):
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.resblock_type = str(resblock_type)
@@ -38,6 +39,8 @@ class HifiganGenerator:
         self.upsample_factors = list(upsample_factors)
         self.inference_padding = inference_padding
         self.cond_channels = cond_channels
+        # XTTS variant (TTS/tts/layers/xtts/hifigan_decoder.py:183-299): `o = ups[i](o) + conds[i](g)` after every upsample
+        self.cond_in_each_up_layer = cond_in_each_up_layer
         self.num_kernels = len(self.resblock_kernel_sizes)
         self.num_upsamples = len(self.upsample_factors)
         for u, k in zip(self.upsample_factors, self.upsample_kernel_sizes):
@@ -95,6 +98,11 @@ class HifiganGenerator:
         for i, u in enumerate(self.upsample_factors):
             w, b = ops.convt_polyphase_weight(ops.fold_weight_norm(sd, "ups.%d" % i), sd.get("ups.%d.bias" % i), u)
             P["ups.%d" % i] = PackedConv(w, b, dev, pad_left=1)
+            if self.cond_in_each_up_layer and ("conds.%d.weight" % i) in sd:
+                # conds[i] is a 1x1 conv of g: its output (one offset per (b, channel)) rides in the transposed conv's
+                # epilogue; rows are repeated per polyphase row (packed row = channel*u + phase)
+                P["conds.%d" % i] = PackedConv(sd["conds.%d.weight" % i].repeat_interleave(u, 0),
+                                               sd["conds.%d.bias" % i].repeat_interleave(u, 0), dev)
         for i in range(self.num_upsamples):
             for j, (k, dil) in enumerate(zip(self.resblock_kernel_sizes, self.resblock_dilation_sizes)):
                 rp = "resblocks.%d." % (i * self.num_kernels + j)
@@ -157,8 +165,9 @@ class HifiganGenerator:
             ch //= 2
             T_up = T * u
             up = new(ch, T_up)
+            rb = ops.speaker_cond(P["conds.%d" % i], g) if (g is not None and ("conds.%d" % i) in P) else None
             ops.conv1d(P["ups.%d" % i], o, up, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, mode=CONV_SHUFFLE,
-                       shuffle_u=u, shuffle_pad=u // 2, in_mask=sm[i])
+                       shuffle_u=u, shuffle_pad=u // 2, in_mask=sm[i], row_bias=rb)
             msk = sm[i + 1]
             T = T_up
             o_next = new(ch, T)

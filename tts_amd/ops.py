@@ -389,3 +389,16 @@ def speaker_cond(pc: PackedConv, g):
     out = torch.empty((B, pc.c_out, 1), dtype=torch.float32, device=g.device)
     conv1d(pc, g.contiguous().float(), out)
     return out.reshape(B, pc.c_out)
+
+
+def linear_interp(x, scale_factor):
+    """F.interpolate(x, scale_factor=[s], mode="linear") on [B, C, T] (hifigan_decoder.py:688-700)."""
+    import math
+
+    B, C, T = x.shape
+    t_out = int(math.floor(T * float(scale_factor)))
+    x = x.float().contiguous()
+    y = torch.empty((B, C, t_out), dtype=torch.float32, device=x.device)
+    check(lib().ttsamd_linear_interp(P(y), P(x), ctypes.c_int64(B * C), T, t_out, ctypes.c_double(float(scale_factor)),
+                                     stream_ptr()), "linear_interp")
+    return y

@@ -250,3 +250,21 @@ HIFIGAN_V1 = dict(  # TTS/vocoder/configs/hifigan_config.py:95-104
     upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512, upsample_factors=[8, 8, 2, 2],
     inference_padding=5)
 HIFIGAN_V2 = dict(HIFIGAN_V1, upsample_initial_channel=128)  # HiFi-GAN paper V2
+
+
+def make_hifi_decoder_state(decoder_input_dim=1024, d_vector_dim=512, upsample_initial_channel=512, seed=77):
+    """`waveform_decoder.*` keys of the XTTS HifiDecoder (TTS/tts/layers/xtts/hifigan_decoder.py:615-667): a HiFiGAN-v1
+    generator without weight-norm on conv_pre/conv_post, no conv_post bias, `cond_layer` + one `conds.i` per upsample."""
+    cfg = dict(HIFIGAN_V1, upsample_initial_channel=upsample_initial_channel, inference_padding=0)
+    sd = make_hifigan_state(cfg, decoder_input_dim, seed=seed, prefix="waveform_decoder.", pre_wn=False, post_wn=False,
+                            post_bias=False)
+    g = torch.Generator().manual_seed(seed + 1)
+    std = 0.5 / math.sqrt(d_vector_dim)
+    sd["waveform_decoder.cond_layer.weight"] = torch.randn(upsample_initial_channel, d_vector_dim, 1, generator=g) * std
+    sd["waveform_decoder.cond_layer.bias"] = torch.randn(upsample_initial_channel, generator=g) * 0.05
+    ch = upsample_initial_channel
+    for i in range(len(cfg["upsample_factors"])):
+        ch //= 2
+        sd["waveform_decoder.conds.%d.weight" % i] = torch.randn(ch, d_vector_dim, 1, generator=g) * std
+        sd["waveform_decoder.conds.%d.bias" % i] = torch.randn(ch, generator=g) * 0.05
+    return sd, cfg
