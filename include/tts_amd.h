@@ -299,6 +299,11 @@ typedef struct ttsamd_mel_norm {
 int ttsamd_mel_renorm(float *y, const float *x, const ttsamd_mel_norm *tts /* host */,
                       const ttsamd_mel_norm *voc /* host */, int batch, int c, int t, void *stream);
 
+/* Posterior sample z = (mean + noise * exp(log_scale)) * mask (PosteriorEncoder.forward, TTS/tts/layers/vits/networks.py:286-287).
+ * stats [B, 2C, T] = mean | log_scale (the `proj` output, already masked), noise / z [B, C, T], mask [B, T]. */
+int ttsamd_sample_gaussian(float *z, const float *stats, const float *noise, const float *mask, int batch, int c, int t,
+                           void *stream);
+
 /* Speaker-conditioning helpers.
  * g = F.normalize(d_vectors) (Vits._set_cond_input, TTS/tts/models/vits.py:882): y[r,:] = x[r,:] / max(||x[r,:]||, eps). */
 int ttsamd_l2_normalize(float *y, const float *x, int rows, int cols, float eps, void *stream);

@@ -50,6 +50,15 @@ class RefVits:
         else:
             self.duration_predictor = dp.DurationPredictor(h, 256, 3, 0.5, cond_channels=spk, language_emb_dim=0)
         self.emb_g = sd.get("emb_g.weight")
+        self.posterior_encoder = None
+        if any(k.startswith("posterior_encoder.") for k in sd):
+            self.posterior_encoder = nw.PosteriorEncoder(a.get("out_channels", 513), h, h,
+                                                         kernel_size=a.get("kernel_size_posterior_encoder", 5),
+                                                         dilation_rate=a.get("dilation_rate_posterior_encoder", 1),
+                                                         num_layers=a.get("num_layers_posterior_encoder", 16),
+                                                         cond_channels=spk)
+            self.posterior_encoder.load_state_dict(_sub(sd, "posterior_encoder."), strict=True)
+            self.posterior_encoder.eval()
         self.text_encoder.load_state_dict(_sub(sd, "text_encoder."), strict=True)
         self.flow.load_state_dict(_sub(sd, "flow."), strict=True)
         self.duration_predictor.load_state_dict(_sub(sd, "duration_predictor."), strict=True)
@@ -96,6 +105,17 @@ class RefVits:
         o = self.waveform_decoder((z * y_mask)[:, :, : a["max_inference_len"]], g=g)
         return {"model_outputs": o, "alignments": attn, "durations": w_ceil, "z": z, "z_p": z_p, "m_p": m_p,
                 "logs_p": logs_p, "y_mask": y_mask, "logw": logw, "x": x}
+
+
+    @torch.no_grad()
+    def voice_conversion(self, y, y_lengths, g_src, g_tgt, seed):
+        """vits.py:1220-1228 over the real modules (the randn_like draw happens inside PosteriorEncoder)."""
+        torch.manual_seed(seed)
+        z, _, _, y_mask = self.posterior_encoder(y, y_lengths, g=g_src)
+        z_p = self.flow(z, y_mask, g=g_src)
+        z_hat = self.flow(z_p, y_mask, g=g_tgt, reverse=True)
+        o_hat = self.waveform_decoder(z_hat * y_mask, g=g_tgt)
+        return {"model_outputs": o_hat, "z": z, "z_p": z_p, "z_hat": z_hat}
 
 
 class RefGlow:

@@ -178,6 +178,56 @@ def residual_coupling_reverse(sd, p, x, x_mask, cfg, g=None):
     return torch.cat([x0, x1], 1)
 
 
+def residual_coupling_forward(sd, p, x, x_mask, cfg, g=None):
+    """ResidualCouplingBlock.forward(reverse=False), vits/networks.py:147-161 (mean_only=True)."""
+    half = x.shape[1] // 2
+    x0, x1 = x[:, :half], x[:, half:]
+    h = conv1d(sd, p + "pre", x0) * x_mask
+    h = wn_forward(sd, p + "enc.", h, x_mask, cfg["hidden"], cfg["kernel_size"], cfg["dilation_rate"],
+                   cfg["num_layers"], g=g)
+    m = conv1d(sd, p + "post", h) * x_mask
+    x1 = m + x1 * torch.exp(torch.zeros_like(m)) * x_mask
+    return torch.cat([x0, x1], 1)
+
+
+def residual_coupling_blocks_forward(sd, p, x, x_mask, cfg, g=None):
+    """ResidualCouplingBlocks.forward(reverse=False), vits/networks.py:221-225."""
+    for i in range(cfg.get("num_flows", 4)):
+        x = residual_coupling_forward(sd, p + "flows.%d." % i, x, x_mask, cfg, g=g)
+        x = torch.flip(x, [1])
+    return x
+
+
+def posterior_encoder(sd, p, y, y_lengths, hidden, kernel_size, dilation_rate, num_layers, g=None, noise=None):
+    """PosteriorEncoder.forward, vits/networks.py:275-288.  `noise` replaces randn_like(mean)."""
+    x_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(y.dtype)
+    x = conv1d(sd, p + "pre", y) * x_mask
+    x = wn_forward(sd, p + "enc.", x, x_mask, hidden, kernel_size, dilation_rate, num_layers, g=g)
+    stats = conv1d(sd, p + "proj", x) * x_mask
+    mean, log_scale = torch.split(stats, hidden, dim=1)
+    if noise is None:
+        noise = torch.randn_like(mean)
+    z = (mean + noise * torch.exp(log_scale)) * x_mask
+    return z, mean, log_scale, x_mask
+
+
+def vits_voice_conversion(sd, y, y_lengths, g_src, g_tgt, args=None, noise=None):
+    """Vits.voice_conversion, vits.py:1202-1228: posterior encoder -> flow (forward, source speaker) -> flow (reverse,
+    target speaker) -> waveform decoder.  y [B, C_spec, T] linear spectrogram."""
+    a = dict(VITS_DEFAULTS)
+    a.update(args or {})
+    h = a["hidden_channels"]
+    z, _, _, y_mask = posterior_encoder(sd, "posterior_encoder.", y, y_lengths, h, a.get("kernel_size_posterior_encoder", 5),
+                                        a.get("dilation_rate_posterior_encoder", 1),
+                                        a.get("num_layers_posterior_encoder", 16), g=g_src, noise=noise)
+    flow_cfg = dict(hidden=h, kernel_size=a["kernel_size_flow"], dilation_rate=a["dilation_rate_flow"],
+                    num_layers=a["num_layers_flow"])
+    z_p = residual_coupling_blocks_forward(sd, "flow.", z, y_mask, flow_cfg, g=g_src)
+    z_hat = residual_coupling_blocks_reverse(sd, "flow.", z_p, y_mask, flow_cfg, g=g_tgt)
+    o_hat = hifigan_forward(sd, "waveform_decoder.", z_hat * y_mask, vits_decoder_cfg(a), g=g_tgt)
+    return {"model_outputs": o_hat, "y_mask": y_mask, "z": z, "z_p": z_p, "z_hat": z_hat}
+
+
 def residual_coupling_blocks_reverse(sd, p, x, x_mask, cfg, g=None):
     """ResidualCouplingBlocks.forward(reverse=True), vits/networks.py:226-232."""
     for i in reversed(range(cfg.get("num_flows", 4))):

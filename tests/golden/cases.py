@@ -66,6 +66,28 @@ def vits_small_speaker(impl, mode):
     return {k: out[k] for k in ["logw", "durations", "z_p", "z", "model_outputs"]}
 
 
+VITS_VC = dict(VITS_SMALL, embedded_speaker_dim=24, use_speaker_embedding=True, num_speakers=5, out_channels=65,
+               num_layers_posterior_encoder=6)
+
+
+def vits_voice_conversion(impl):
+    """Vits.voice_conversion (vits.py:1202-1228): posterior encoder + flow forward (source speaker) + flow reverse and
+    decoder (target speaker)."""
+    sd = W.make_vits_state(VITS_VC, seed=555, with_posterior=True)
+    y = torch.randn(2, 65, 40, generator=_g(8))
+    yl = torch.tensor([40, 27])
+    g_src = torch.nn.functional.embedding(torch.tensor([0, 2]), sd["emb_g.weight"]).unsqueeze(-1)
+    g_tgt = torch.nn.functional.embedding(torch.tensor([4, 1]), sd["emb_g.weight"]).unsqueeze(-1)
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        out = RM.RefVits(sd, VITS_VC).voice_conversion(y, yl, g_src, g_tgt, seed=13)
+    else:
+        torch.manual_seed(13)
+        out = O.vits_voice_conversion(sd, y, yl, g_src, g_tgt, VITS_VC)
+    return {k: out[k] for k in ["z", "z_p", "z_hat", "model_outputs"]}
+
+
 def xtts_hifi_decoder(impl):
     """XTTS HifiDecoder vocoder half (xtts/hifigan_decoder.py:675-701): interpolated GPT latents + d-vector conditioning
     at the input and after every upsampling layer."""
@@ -118,6 +140,7 @@ CASES = {
     "vits_small_spk_emb": lambda impl: vits_small_speaker(impl, "emb"),
     "vits_small_spk_dvec": lambda impl: vits_small_speaker(impl, "dvec"),
     "xtts_hifi_decoder": xtts_hifi_decoder,
+    "vits_voice_conversion": vits_voice_conversion,
     "glow_small": lambda impl: glow_small(impl),
     "glow_small_relwin": lambda impl: glow_small(impl, 4, "2"),
 }

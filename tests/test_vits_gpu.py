@@ -198,3 +198,24 @@ def test_vits_speaker_conditioning_matches_reference_golden(gpu, mode):
     with pytest.raises(ValueError):
         _model(dict(cases.VITS_SMALL), W.make_vits_state(dict(cases.VITS_SMALL), seed=1), gpu).inference(
             x.to(gpu), {"speaker_ids": torch.tensor([0, 1]).to(gpu)})
+
+
+def test_vits_voice_conversion_matches_reference_golden(gpu):
+    """Vits.voice_conversion (vits.py:1202-1228): PosteriorEncoder (16-layer WaveNet in the real model, 6 here) -> flow
+    forward with the source speaker -> flow reverse + decoder with the target speaker."""
+    from tests.golden import cases
+
+    gold = np.load(os.path.join(GOLD, "vits_voice_conversion.npz"))
+    sd = W.make_vits_state(cases.VITS_VC, seed=555, with_posterior=True)
+    m = _model(dict(cases.VITS_VC, speaker_embedding_channels=24), sd, gpu)
+    y = torch.randn(2, 65, 40, generator=torch.Generator().manual_seed(8))
+    yl = torch.tensor([40, 27])
+    torch.manual_seed(13)
+    noise = torch.randn(2, 192, 40)                       # randn_like(mean): `mean` is a contiguous split -> same order
+    o, y_mask, (z, z_p, z_hat) = m.voice_conversion(y.to(gpu), yl.to(gpu), torch.tensor([0, 2]), torch.tensor([4, 1]),
+                                                    noise=noise.to(gpu))
+    assert y_mask.shape == (2, 1, 40)
+    for name, t in (("z", z), ("z_p", z_p), ("z_hat", z_hat)):
+        assert _errs(t, torch.from_numpy(gold[name]))[1] < 1e-5, name
+    rms, rel = _errs(o, torch.from_numpy(gold["model_outputs"]))
+    assert rms < 1e-4 and rel < 1e-5, (rms, rel)

@@ -256,6 +256,22 @@ __global__ void scale_kernel(float *__restrict__ y, const float *__restrict__ x,
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
 
+// z[b,c,t] = (m[b,c,t] + noise[b,c,t] * exp(logs[b,c,t])) * mask[b,t]; m / logs are the halves of one [B,2C,T] buffer
+__global__ void sample_gaussian_kernel(float *__restrict__ z, const float *__restrict__ stats,
+                                       const float *__restrict__ noise, const float *__restrict__ mask, int C, int T)
+{
+    const int b = blockIdx.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float mk = mask ? mask[(long)b * T + t] : 1.f;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        const float mv = stats[((long)b * 2 * C + c) * T + t];
+        const float lv = stats[((long)b * 2 * C + C + c) * T + t];
+        const long o = ((long)b * C + c) * T + t;
+        z[o] = (mv + noise[o] * expf(lv)) * mk;
+    }
+}
+
 }  // namespace ttsamd
 using namespace ttsamd;
 
@@ -377,6 +393,18 @@ extern "C" int ttsamd_scale(float *y, const float *x, float s, int64_t n, void *
     const long blocks = (n + kTxtThreads - 1) / kTxtThreads;
     hipLaunchKernelGGL(scale_kernel, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(kTxtThreads), 0, as_stream(stream),
                        y, x, s, (long)n);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_sample_gaussian(float *z, const float *stats, const float *noise, const float *mask, int batch, int c,
+                                      int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(z && stats && noise && batch >= 0 && c > 0 && t >= 0, "sample_gaussian: bad args");
+    if (batch == 0 || t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "sample_gaussian: batch > 65535");
+    hipLaunchKernelGGL(sample_gaussian_kernel, dim3(cdiv(t, 64), min(c, 32), batch), dim3(64), 0, as_stream(stream), z, stats,
+                       noise, mask, c, t);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

@@ -269,6 +269,8 @@ class ResidualCouplingBlocks:
     def __init__(self, sd, p, device, channels, hidden, kernel_size, dilation_rate, num_layers, num_flows=4,
                  cond_channels=0):
         self.half, self.hidden, self.num_flows = channels // 2, hidden, num_flows
+        if num_flows % 2:
+            raise ops._lib.TtsAmdError("ResidualCouplingBlocks: the folded channel flips need an even number of flows")
         self.flows = []
         for i in range(num_flows):
             q = p + "flows.%d." % i
@@ -284,6 +286,20 @@ class ResidualCouplingBlocks:
                                    post=PackedConv(wpost, bpost, device),
                                    wn=WN(sd, q + "enc.", device, hidden, kernel_size, dilation_rate, num_layers,
                                          cond_channels)))
+
+    def forward_flow(self, z, mask, g=None):
+        """Forward direction (networks.py:221-225; voice conversion, vits.py:1226): x1 = post(WN(pre(x0))) * mask +
+        x1 * mask, then flip — IN PLACE on z with the same folded flips as the reverse pass."""
+        half = self.half
+        h = _new(z, self.hidden)
+        out = _new(z, self.hidden)
+        for i in range(self.num_flows):
+            F_ = self.flows[i]
+            src, dst = (half, 0) if F_["flipped"] else (0, half)
+            ops.conv1d(F_["pre"], z, h, c_in_offset=src, out_mask=mask)
+            F_["wn"](h, mask, out, g=g)
+            ops.conv1d(F_["post"], out, z, res=z, res_row_offset=dst, y_row_offset=dst, out_mask=mask)   # (m + x1) * mask
+        return z
 
     def __call__(self, z, mask, g=None):
         """z [B,C,T] is transformed IN PLACE (reverse direction) and returned."""
@@ -395,3 +411,24 @@ class GlowDecoder:
                        y_row_offset=self.half, out_mask=mq, split_row=self.half)
             ops.glow_invconv_actnorm(x, blk["w_inv"], blk["an_bias"], blk["an_logs"], mq, self.ns)
         return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)
+
+
+# ------------------------------------------------------------------------------------------------
+# PosteriorEncoder — TTS/tts/layers/vits/networks.py:235-288 (voice conversion only at inference time)
+# ------------------------------------------------------------------------------------------------
+class PosteriorEncoder:
+    def __init__(self, sd, p, device, hidden, kernel_size, dilation_rate, num_layers, cond_channels=0):
+        self.hidden = hidden
+        self.pre = PackedConv(sd[p + "pre.weight"], sd[p + "pre.bias"], device)
+        self.enc = WN(sd, p + "enc.", device, hidden, kernel_size, dilation_rate, num_layers, cond_channels)
+        self.proj = PackedConv(sd[p + "proj.weight"], sd[p + "proj.bias"], device)
+
+    def __call__(self, y, mask, noise, g=None):
+        """y [B,C_spec,T], mask [B,T], noise [B,H,T] -> z [B,H,T], stats [B,2H,T] (mean | log_scale)."""
+        h = _new(y, self.hidden)
+        ops.conv1d(self.pre, y, h, out_mask=mask)
+        out = _new(h)
+        self.enc(h, mask, out, g=g)
+        stats = _new(h, 2 * self.hidden)
+        ops.conv1d(self.proj, out, stats, out_mask=mask)
+        return ops.sample_gaussian(stats, noise, mask), stats

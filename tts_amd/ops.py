@@ -402,3 +402,12 @@ def linear_interp(x, scale_factor):
     check(lib().ttsamd_linear_interp(P(y), P(x), ctypes.c_int64(B * C), T, t_out, ctypes.c_double(float(scale_factor)),
                                      stream_ptr()), "linear_interp")
     return y
+
+
+def sample_gaussian(stats, noise, mask):
+    """z = (mean + noise * exp(log_scale)) * mask with stats [B,2C,T] = mean | log_scale (networks.py:286-287)."""
+    B, C2, T = stats.shape
+    z = torch.empty((B, C2 // 2, T), dtype=torch.float32, device=stats.device)
+    check(lib().ttsamd_sample_gaussian(P(z), P(stats), P(noise.contiguous()), P(mask), B, C2 // 2, T, stream_ptr()),
+          "sample_gaussian")
+    return z

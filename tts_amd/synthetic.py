@@ -149,7 +149,7 @@ def _wn(f, p, hidden, k, layers, in_channels=None, cond=0):
         f.conv(p + "res_skip_layers.%d" % i, 2 * hidden if i < layers - 1 else hidden, hidden, 1, wn=True, gain=0.5)
 
 
-def make_vits_state(args=None, seed=1234, with_decoder=True):
+def make_vits_state(args=None, seed=1234, with_decoder=True, with_posterior=False):
     """Reference-layout state_dict for the inference-relevant sub-modules of `Vits`
     (text_encoder., duration_predictor., flow., waveform_decoder.; vits.py:653-718)."""
     a = dict(VITS_DEFAULTS)
@@ -187,6 +187,11 @@ def make_vits_state(args=None, seed=1234, with_decoder=True):
         f.conv(q + "pre", h, h // 2, 1)
         _wn(f, q + "enc.", h, a["kernel_size_flow"], a["num_layers_flow"], cond=spk)
         f.conv(q + "post", h // 2, h, 1, gain=0.5)  # zero-init in the reference
+    if with_posterior:  # PosteriorEncoder (networks.py:235-288), only used by voice conversion at inference time
+        q = "posterior_encoder."
+        f.conv(q + "pre", h, a.get("out_channels", 513), 1)
+        _wn(f, q + "enc.", h, a.get("kernel_size_posterior_encoder", 5), a.get("num_layers_posterior_encoder", 16), cond=spk)
+        f.conv(q + "proj", 2 * h, h, 1, gain=0.3)
     sd = f.sd
     if with_decoder:
         cfg = dict(resblock_type=a["resblock_type_decoder"], resblock_dilation_sizes=a["resblock_dilation_sizes_decoder"],

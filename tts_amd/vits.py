@@ -114,8 +114,7 @@ class Vits:
         return self
 
     def load_state_dict(self, sd, strict=True):
-        self._sd = {k: v.detach().cpu() for k, v in sd.items()
-                    if not k.startswith(("disc.", "posterior_encoder."))}  # training-only parts (vits.py:1716-1719)
+        self._sd = {k: v.detach().cpu() for k, v in sd.items() if not k.startswith("disc.")}   # discriminator: training only
         if self.device.type == "cuda":
             self._pack()
 
@@ -142,6 +141,12 @@ class Vits:
                                                   a.dilation_rate_flow, a.num_layers_flow, cond_channels=spk)
         self.waveform_decoder.load_state_dict(sd, prefix="waveform_decoder.")
         self.waveform_decoder.to(dev)
+        self.posterior_encoder = None
+        if "posterior_encoder.pre.weight" in sd:   # kept only for voice conversion (vits.py:1202-1228)
+            self.posterior_encoder = layers.PosteriorEncoder(sd, "posterior_encoder.", dev, a.hidden_channels,
+                                                             a.kernel_size_posterior_encoder,
+                                                             a.dilation_rate_posterior_encoder,
+                                                             a.num_layers_posterior_encoder, cond_channels=spk)
 
     def weight_bytes(self):
         return sum(v.numel() * 4 for v in self._sd.values())
@@ -174,6 +179,33 @@ class Vits:
         sid = sid.to(dev, torch.int64).reshape(-1, 1).contiguous()
         g = torch.empty((sid.shape[0], self.emb_g.shape[1], 1), dtype=torch.float32, device=dev)
         return ops.embed(sid, self.emb_g, None, 1.0, g)               # emb_g(sid).unsqueeze(-1)
+
+    @torch.no_grad()
+    def voice_conversion(self, y, y_lengths, speaker_cond_src, speaker_cond_tgt, noise=None):
+        """vits.py:1202-1228.  y [B, C_spec, T] linear spectrogram (the reference's `wav_to_spec` STFT front end is
+        training-side DSP, not built: pass the spectrogram), speaker conds = ids (use_speaker_embedding) or d-vectors.
+        Returns (o_hat [B,1,T*hop], y_mask [B,1,T], (z, z_p, z_hat))."""
+        if not self.embedded_speaker_dim:
+            raise RuntimeError(" [!] Voice conversion is only supported on multi-speaker models.")
+        if self.posterior_encoder is None:
+            raise _lib.TtsAmdError("voice_conversion needs the posterior_encoder.* weights in the checkpoint")
+        _lib.require_gpu(y, "y")
+        dev = y.device
+        y = y.float().contiguous()
+        B, _, T = y.shape
+        key = "d_vectors" if self.args.use_d_vector_file else "speaker_ids"
+        to_t = lambda v: v if torch.is_tensor(v) else torch.as_tensor(v)   # noqa: E731
+        g_src = self._speaker_g({key: to_t(speaker_cond_src)}, B, dev)
+        g_tgt = self._speaker_g({key: to_t(speaker_cond_tgt)}, B, dev)
+        mask = ops.sequence_mask(y_lengths.to(dev), T)
+        H = self.args.hidden_channels
+        if noise is None:
+            noise = torch.randn(B, H, T, device=dev, dtype=torch.float32)
+        z, _ = self.posterior_encoder(y, mask, noise.to(dev, torch.float32), g=g_src)
+        z_p = self.flow.forward_flow(z.clone(), mask, g=g_src)
+        z_hat = self.flow(z_p.clone(), mask, g=g_tgt)
+        o_hat = self.waveform_decoder.forward(z_hat, g=g_tgt, in_mask=mask)
+        return o_hat, mask.unsqueeze(1), (z, z_p, z_hat)
 
     # ---- inference (vits.py:1088-1173) ---------------------------------------------------------------
     @torch.no_grad()
