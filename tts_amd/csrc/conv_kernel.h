@@ -66,7 +66,7 @@ __device__ __forceinline__ float conv_in_act(float v, int act, float slope)
 }
 
 template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void conv1d_mfma_kernel(const ttsamd_conv1d_args a)
+__global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_mfma_kernel(const ttsamd_conv1d_args a)
 {
     using G = ConvGeom<K, D, MI, NI, WM, WN>;
     static_assert(((kConvCK / 2) * K) % 4 == 0, "k-steps per chunk must be a multiple of 4");
