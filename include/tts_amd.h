@@ -103,6 +103,8 @@ int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, 
 /* Glow affine coupling (glow.py:216-224): packed row tile pairs like GATE: tile 2a = t rows, 2a+1 = s rows;
  * y[32a+i] = (res[32a+i] - t) * exp(-s) * out_mask.  c_out = packed rows (2 * coupled channels). */
 #define TTSAMD_CONV_COUPLE_AFFINE 5
+/* forward direction of the same coupling (glow.py:225): y[32a+i] = (t + exp(s) * res[32a+i]) * out_mask */
+#define TTSAMD_CONV_COUPLE_AFFINE_FWD 6
 
 typedef struct ttsamd_conv1d_args {
     const float *x;        /* x[b,ci,t] = x[b*x_bstride + ci*x_rstride + t], t in [0,t_in) */
@@ -266,9 +268,13 @@ int ttsamd_glow_unsqueeze(float *y, const float *x, const float *mask_q, int bat
                           void *stream);
 /* InvConvNear reverse (TTS/tts/layers/glow_tts/glow.py:107-137, stored 4x4 inverse `w_inv` row-major) followed by
  * ActNorm reverse (TTS/tts/layers/generic/normalization.py:98-101; bias/logs [C], or both NULL to skip), IN PLACE
- * on x [B,C,T]:  z = (w_inv . x_group) * mask;  x = (z - bias) * exp(-logs) * mask.   num_splits must be 4. */
+ * on x [B,C,T]:  z = (w_inv . x_group) * mask;  x = (z - bias) * exp(-logs) * mask.   num_splits must be 4.
+ * forward != 0 runs the forward flow instead (ActNorm then InvConvNear, glow_tts/decoder.py:126-131):
+ *   x = (bias + exp(logs) * x) * mask;  x = (w . x_group) * mask   with `w_inv` holding the weight itself. */
 int ttsamd_glow_invconv_actnorm(float *x, const float *w_inv, const float *bias, const float *logs, const float *mask,
-                                int batch, int c, int t, int num_splits, void *stream);
+                                int batch, int c, int t, int num_splits, int forward, void *stream);
+/* o[r] = sum_t x[r,t]: token durations of a MAS alignment, `attn.sum(-1)` (glow_tts.py:147, vits.py:922). */
+int ttsamd_row_sum(float *o, const float *x, int64_t rows, int t, void *stream);
 /* o_attn_dur = log(1 + sum_y attn[b,x,y]) * x_mask (GlowTTS.compute_outputs, TTS/tts/models/glow_tts.py:147), with
  * the row sums taken from the cumulative durations.  o [B,T_x]. */
 int ttsamd_attn_durations(float *o, const int32_t *cum, const float *x_mask, const int64_t *y_lengths, int batch,

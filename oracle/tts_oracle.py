@@ -646,6 +646,54 @@ def glow_decoder_reverse(sd, p, x, x_mask, a):
     return x
 
 
+def glow_decoder_forward(sd, p, x, x_mask, a):
+    """Decoder.forward(reverse=False), glow_tts/decoder.py:113-137: per block ActNorm (normalization.py:102-103),
+    InvConvNear with the weight itself (glow.py:107-137), CouplingBlock forward (glow.py:200-226)."""
+    ns, nsq = a["num_splits"], a["num_squeeze"]
+    if nsq > 1:
+        x, x_mask = glow_squeeze(x, x_mask, nsq)
+    cin = x.shape[1]
+    for blk in range(a["num_flow_blocks_dec"]):
+        pa, pi, pc = (p + "flows.%d." % (3 * blk + j) for j in range(3))
+        x = (sd[pa + "bias"] + torch.exp(sd[pa + "logs"]) * x) * x_mask
+        b, c, t = x.size()
+        xx = x.view(b, 2, c // ns, ns // 2, t).permute(0, 1, 3, 2, 4).contiguous().view(b, ns, c // ns, t)
+        z = F.conv2d(xx, sd[pi + "weight"].view(ns, ns, 1, 1))
+        x = z.view(b, 2, ns // 2, c // ns, t).permute(0, 1, 3, 2, 4).contiguous().view(b, c, t) * x_mask
+        x0, x1 = x[:, : cin // 2], x[:, cin // 2:]
+        h = conv1d(sd, pc + "start", x0) * x_mask
+        h = wn_forward(sd, pc + "wn.", h, x_mask, a["hidden_channels_dec"], a["kernel_size_dec"], a["dilation_rate"],
+                       a["num_block_layers"])
+        out = conv1d(sd, pc + "end", h)
+        t_, s_ = out[:, : cin // 2], out[:, cin // 2:]
+        x = torch.cat([x0, (t_ + torch.exp(s_) * x1) * x_mask], 1)
+    if nsq > 1:
+        x, x_mask = glow_unsqueeze(x, x_mask, nsq)
+    return x
+
+
+def glow_inference_with_mas(sd, tokens, x_lengths, y, y_lengths, args=None, maximum_path=None):
+    """GlowTTS.inference_with_MAS, glow_tts.py:262-316.  y [B,T,C] mel.  `maximum_path(value, mask)` = the MAS
+    implementation to use (the test passes the C oracle)."""
+    a = dict(GLOW_DEFAULTS)
+    a.update(args or {})
+    y = y.transpose(1, 2)
+    o_mean, o_log_scale, o_dur_log, x_mask = glow_encoder(sd, "encoder.", tokens, x_lengths, a)
+    n = a["num_squeeze"]
+    y = y[:, :, : (y.size(2) // n) * n]
+    y_lengths = torch.div(y_lengths, n, rounding_mode="floor") * n
+    y_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(x_mask.dtype)
+    attn_mask = torch.unsqueeze(x_mask, -1) * torch.unsqueeze(y_mask, 2)
+    z = glow_decoder_forward(sd, "decoder.", y, y_mask, a)
+    logp = mas_logp(z, o_mean, o_log_scale, glow_order=True)
+    attn = maximum_path(logp, attn_mask.squeeze(1))
+    y_mean = torch.matmul(attn.transpose(1, 2), o_mean.transpose(1, 2)).transpose(1, 2)
+    o_attn_dur = torch.log(1 + torch.sum(attn, -1)).unsqueeze(1) * x_mask
+    zz = y_mean * y_mask
+    return {"model_outputs": zz.transpose(1, 2), "z": z, "logp": logp, "alignments": attn.permute(0, 2, 1),
+            "y_mean": y_mean.transpose(1, 2), "total_durations_log": o_attn_dur.transpose(1, 2)}
+
+
 def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None):
     """GlowTTS.inference, glow_tts.py:341-374 (single speaker)."""
     a = dict(GLOW_DEFAULTS)

@@ -122,3 +122,46 @@ def test_gan_wrapper_matches_oracle(gpu):
     rms = float((a - b).pow(2).mean().sqrt())
     assert rms < 1e-4 and rms / float(b.pow(2).mean().sqrt()) < 1e-5
     assert next(v.parameters()).is_cuda
+
+
+def test_glow_decoder_forward_and_inference_with_mas(gpu):
+    """GlowTTS.decoder_inference / inference_with_MAS (glow_tts.py:262-339): decoder FORWARD flow, log-likelihood matrix,
+    MAS and aligned prior — vs the oracle with the C MAS oracle.  The forward flow is also checked as the exact inverse
+    of the reverse flow (round trip)."""
+    from oracle import mas
+
+    torch.set_num_threads(8)
+    args = dict(num_flow_blocks_dec=3)
+    args["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    sd = W.make_glow_state(args, seed=41)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(0, 130, (2, 17), generator=g)
+    xl = torch.tensor([17, 11])
+    y = torch.randn(2, 45, 80, generator=g)                  # [B, T, C] mel, odd T: the last frame is dropped
+    yl = torch.tensor([45, 31])
+
+    def cmas(value, mask):
+        return torch.from_numpy(mas.maximum_path(value.numpy(), mask.numpy(), "c")).float()
+
+    want = O.glow_inference_with_mas(sd, x, xl, y, yl, args, maximum_path=cmas)
+    m = _model(args, sd, gpu)
+    out = m.inference_with_MAS(x.to(gpu), xl.to(gpu), y.to(gpu), yl.to(gpu))
+    a = dict(O.GLOW_DEFAULTS)
+    a.update(args)
+    mask = O.sequence_mask(torch.tensor([44, 30]), 44).float()
+    z = m.decoder.forward_flow(y.transpose(1, 2)[:, :, :44].contiguous().to(gpu), mask.to(gpu))
+    assert _rel(z, want["z"]) < 1e-5
+    same = torch.equal(out["alignments"].cpu(), want["alignments"])
+    if not same:   # fp32 logp differs by reordering noise: a flipped decision must be a numerical near-tie
+        lp = want["logp"]
+        s_got = (out["alignments"].cpu().permute(0, 2, 1) * lp).sum((1, 2))
+        s_want = (want["alignments"].permute(0, 2, 1) * lp).sum((1, 2))
+        assert torch.allclose(s_got, s_want, rtol=1e-5), (s_got, s_want)
+    else:
+        assert _rel(out["y_mean"], want["y_mean"]) < 1e-5
+        assert _rel(out["model_outputs"], want["model_outputs"]) < 1e-5
+        assert _rel(out["total_durations_log"][:, :, 0], want["total_durations_log"][:, :, 0]) < 1e-6
+    assert out["alignments"].sum(2).cpu().max() <= 1.0 and out["model_outputs"].shape == (2, 44, 80)
+    rt = m.decoder_inference(y.to(gpu), yl.to(gpu))["model_outputs"]                   # forward then reverse
+    ym = y[:, :44] * mask[:, :, None]
+    assert _rel(rt, ym) < 1e-4

@@ -59,11 +59,12 @@ extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_COUPLE || a.res, "conv1d: COUPLE needs res");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_SHUFFLE || a.shuffle_u > 0, "conv1d: SHUFFLE needs shuffle_u");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_GATE || (a.c_out % 64) == 0, "conv1d: GATE needs c_out %% 64 == 0");
-    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_COUPLE_AFFINE || ((a.c_out % 64) == 0 && a.res && a.split_row > 0),
+    TTSAMD_CHECK_ARG((a.mode != TTSAMD_CONV_COUPLE_AFFINE && a.mode != TTSAMD_CONV_COUPLE_AFFINE_FWD) ||
+                         ((a.c_out % 64) == 0 && a.res && a.split_row > 0),
                      "conv1d: COUPLE_AFFINE needs c_out %% 64 == 0, res and split_row");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_RES_SKIP || (a.res && a.y2 && a.split_row > 0 && a.split_row % 32 == 0),
                      "conv1d: RES_SKIP needs res, y2 and split_row %% 32 == 0");
-    TTSAMD_CHECK_ARG(a.mode >= 0 && a.mode <= TTSAMD_CONV_COUPLE_AFFINE, "conv1d: unknown mode %d", a.mode);
+    TTSAMD_CHECK_ARG(a.mode >= 0 && a.mode <= TTSAMD_CONV_COUPLE_AFFINE_FWD, "conv1d: unknown mode %d", a.mode);
     if (a.batch == 0 || a.t_out == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(a.batch <= 65535, "conv1d: batch > 65535");
     {   // the kernel addresses every per-item slab with 32-bit byte offsets (buffer resources)

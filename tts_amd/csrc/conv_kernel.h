@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
     const float *res = ep->res ? ep->res + (long)b * ep->res_bstride : nullptr;
     const long res_rs = ep->res_rstride;
 
-    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE) {
+    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
         static_assert(MI == 2, "paired-row epilogues need MI == 2");
         const long pair = (long)blockIdx.y * WM + wm;
         constexpr bool gate = (MODE == TTSAMD_CONV_GATE);
@@ -268,9 +268,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
                     float o;
                     if constexpr (gate) {
                         o = tanhf(v0) * (1.f / (1.f + expf(-v1)));
-                    } else {
+                    } else if constexpr (MODE == TTSAMD_CONV_COUPLE_AFFINE) {
                         const float m = omask ? omask[t] : 1.f;
                         o = (res[oc * res_rs + t] - v0) * expf(-v1) * m;
+                    } else {
+                        const float m = omask ? omask[t] : 1.f;
+                        o = (v0 + expf(v1) * res[oc * res_rs + t]) * m;
                     }
                     y[(long)b * y_bs + oc * y_rs + t] = o;
                 }
@@ -413,7 +416,7 @@ int conv1d_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     const int mtiles = (a.c_out + 31) / 32;
     if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
-    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE) {
+    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
         return conv1d_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
     } else {
         if (mtiles % 2 == 0) return conv1d_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
@@ -448,6 +451,9 @@ int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
             break;
         case TTSAMD_CONV_COUPLE_AFFINE:
             if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_COUPLE_AFFINE>(a, st);
+            break;
+        case TTSAMD_CONV_COUPLE_AFFINE_FWD:
+            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_COUPLE_AFFINE_FWD>(a, st);
             break;
     }
     return conv1d_mode_unsupported(a);

@@ -41,10 +41,12 @@ __global__ void glow_unsqueeze_kernel(float *__restrict__ y, const float *__rest
 // In place on x [B,C,T] (C = 2 * (C/ns) * (ns/2) grouping of glow.py:116-117):
 //   group g = a*(ns/2) + d  <->  channel a*(C/2) + q*(ns/2) + d,  q < C/ns
 //   z[g'] = sum_g w_inv[g'][g] * x[g];  z *= mask;  z = (z - bias[ch]) * exp(-logs[ch]) * mask   (ActNorm reverse)
+// forward == 0 (reverse flow): z = (W x) * mask;  x = (z - bias) * exp(-logs) * mask      (W = stored inverse)
+// forward == 1 (forward flow): x = (bias + exp(logs) * x) * mask;  x = (W x) * mask           (W = the weight itself)
 template <int NS>
 __global__ void glow_invconv_actnorm_kernel(float *__restrict__ x, const float *__restrict__ w_inv,
                                             const float *__restrict__ bias, const float *__restrict__ logs,
-                                            const float *__restrict__ mask, int C, int T)
+                                            const float *__restrict__ mask, int C, int T, int forward)
 {
     const int b = blockIdx.z;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,6 +67,7 @@ __global__ void glow_invconv_actnorm_kernel(float *__restrict__ x, const float *
             const int ch = a * (C / 2) + q * (NS / 2) + d;
             off[g] = ((long)b * C + ch) * T + t;
             v[g] = x[off[g]];
+            if (forward && bias) v[g] = (bias[ch] + expf(logs[ch]) * v[g]) * m;
         }
 #pragma unroll
         for (int go = 0; go < NS; ++go) {
@@ -74,7 +77,7 @@ __global__ void glow_invconv_actnorm_kernel(float *__restrict__ x, const float *
             const int a = go / (NS / 2), d = go - a * (NS / 2);
             const int ch = a * (C / 2) + q * (NS / 2) + d;
             z *= m;
-            if (bias) z = (z - bias[ch]) * expf(-logs[ch]) * m;
+            if (!forward && bias) z = (z - bias[ch]) * expf(-logs[ch]) * m;
             x[off[go]] = z;
         }
     }
@@ -93,6 +96,17 @@ __global__ void attn_durations_kernel(float *__restrict__ o, const int *__restri
     const float xm = x_mask ? x_mask[(long)b * Tx + x] : 1.f;
     const float s = (float)(hi - lo) * xm;
     o[(long)b * Tx + x] = logf(1.f + s) * xm;
+}
+
+// o[r] = sum_t x[r, t]  (durations of a MAS alignment: attn.sum(-1)); one wavefront per row
+__global__ void row_sum_kernel(float *__restrict__ o, const float *__restrict__ x, int t)
+{
+    const long r = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < t; i += 64) s += x[r * t + i];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+    if (threadIdx.x == 0) o[r] = s;
 }
 
 }  // namespace ttsamd
@@ -127,7 +141,8 @@ extern "C" int ttsamd_glow_unsqueeze(float *y, const float *x, const float *mask
 }
 
 extern "C" int ttsamd_glow_invconv_actnorm(float *x, const float *w_inv, const float *bias, const float *logs,
-                                           const float *mask, int batch, int c, int t, int num_splits, void *stream)
+                                           const float *mask, int batch, int c, int t, int num_splits, int forward,
+                                           void *stream)
 {
     TTSAMD_CHECK_ARG(x && w_inv && batch >= 0 && c > 0 && t >= 0, "glow_invconv_actnorm: bad args");
     TTSAMD_CHECK_ARG((bias == nullptr) == (logs == nullptr), "glow_invconv_actnorm: need both or neither of bias/logs");
@@ -138,7 +153,7 @@ extern "C" int ttsamd_glow_invconv_actnorm(float *x, const float *w_inv, const f
     if (batch == 0 || t == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(batch <= 65535, "glow_invconv_actnorm: batch > 65535");
     hipLaunchKernelGGL(glow_invconv_actnorm_kernel<4>, dim3(cdiv(t, 64), min(c / 4, 16), batch), dim3(64), 0,
-                       as_stream(stream), x, w_inv, bias, logs, mask, c, t);
+                       as_stream(stream), x, w_inv, bias, logs, mask, c, t, forward);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
@@ -151,6 +166,15 @@ extern "C" int ttsamd_attn_durations(float *o, const int32_t *cum, const float *
     TTSAMD_CHECK_ARG(batch <= 65535, "attn_durations: batch > 65535");
     hipLaunchKernelGGL(attn_durations_kernel, dim3(cdiv(t_x, kGlowThreads), batch), dim3(kGlowThreads), 0,
                        as_stream(stream), o, cum, x_mask, reinterpret_cast<const long *>(y_lengths), t_x);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_row_sum(float *o, const float *x, int64_t rows, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(o && x && rows >= 0 && t >= 0 && rows <= 0x7FFFFFFF, "row_sum: bad args");
+    if (rows == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)rows), dim3(64), 0, as_stream(stream), o, x, t);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

@@ -5,7 +5,7 @@ load_checkpoint, :541-557 init_from_config).  Config field names/defaults: GlowT
 """
 import torch
 
-from . import _lib, layers, ops
+from . import _lib, helpers, layers, ops
 from .vits import _Args, _get
 
 GLOW_DEFAULTS = dict(  # glow_tts_config.py:101-152
@@ -127,3 +127,54 @@ class GlowTTS:
         }
 
     __call__ = inference
+
+    def _preprocess(self, y, y_lengths):
+        """glow_tts.py:510-517: drop the frames that do not fill a squeeze group."""
+        n = self.num_squeeze
+        t = (y.shape[2] // n) * n
+        return y[:, :, :t].contiguous(), torch.div(y_lengths, n, rounding_mode="floor") * n
+
+    @torch.no_grad()
+    def decoder_inference(self, y, y_lengths=None, aux_input=None):
+        """glow_tts.py:318-339: mel [B,T,C] -> decoder forward -> decoder reverse (round trip)."""
+        _lib.require_gpu(y, "y")
+        y = y.float().transpose(1, 2).contiguous()
+        if y_lengths is None:
+            y_lengths = torch.full((y.shape[0],), y.shape[2], dtype=torch.int64, device=y.device)
+        y_mask = ops.sequence_mask(y_lengths.to(y.device), y.shape[2])
+        z = self.decoder.forward_flow(y, y_mask)
+        out = self.decoder(z, y_mask[:, : z.shape[2]].contiguous())
+        return {"model_outputs": out.transpose(1, 2), "logdet": None}
+
+    @torch.no_grad()
+    def inference_with_MAS(self, x, x_lengths, y=None, y_lengths=None, aux_input=None):
+        """glow_tts.py:262-316 ("teacher forcing"): encoder -> decoder FORWARD on the given mel -> log-likelihood matrix
+        -> monotonic alignment search (all on the device, no host round trip) -> aligned prior statistics."""
+        _lib.require_gpu(x, "x")
+        dev = x.device
+        x = x.to(torch.int64).contiguous()
+        B, T = x.shape
+        x_mask = ops.sequence_mask(x_lengths.to(dev), T)
+        o_mean, o_logs, logw = self.encoder(x, x_mask)
+        y = y.float().transpose(1, 2).contiguous()
+        y, y_lengths = self._preprocess(y, y_lengths.to(dev))
+        y_mask = ops.sequence_mask(y_lengths, y.shape[2])
+        z = self.decoder.forward_flow(y, y_mask)
+        zeros = torch.zeros_like(o_mean) if o_logs is None else o_logs        # mean_only: o_log_scale == 0
+        attn = helpers.mas_attention(z, o_mean, zeros, x_mask, y_mask, glow_order=True)          # [B, T_x, T_y]
+        dur = ops.row_sum(attn)                                                                    # attn.sum(-1)
+        _, cum, y_len2 = ops.durations(None, x_mask, 1.0, durations_in=dur)
+        t_dec = y.shape[2]
+        pri = ops.expand_prior(o_mean, o_logs, None, cum, x_mask, y_lengths, t_dec, 0.0, mask_out=True)
+        out = self.decoder(pri["z_p"], y_mask)      # the reference also decodes the aligned prior (result unused there)
+        total = ops.attn_durations(cum, x_mask, y_lengths)       # log(1 + attn.sum(-1)) * x_mask
+        return {
+            "model_outputs": pri["z_p"].transpose(1, 2),          # z = y_mean * y_mask (glow_tts.py:302,307)
+            "logdet": None,
+            "y_mean": pri["m_p"].transpose(1, 2),
+            "y_log_scale": pri["logs_p"].transpose(1, 2),
+            "alignments": attn.permute(0, 2, 1),
+            "durations_log": logw.unsqueeze(1).transpose(1, 2),
+            "total_durations_log": total.unsqueeze(1).transpose(1, 2),
+            "decoded": out.transpose(1, 2),
+        }

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import ops
-from .ops import (ACT_GELU, ACT_NONE, ACT_RELU, CONV_COUPLE, CONV_COUPLE_AFFINE, CONV_GATE, CONV_RES_SKIP,
+from .ops import (ACT_GELU, ACT_NONE, ACT_RELU, CONV_COUPLE, CONV_COUPLE_AFFINE, CONV_COUPLE_AFFINE_FWD, CONV_GATE, CONV_RES_SKIP,
                   PackedConv, fold_weight_norm)
 
 
@@ -395,6 +395,7 @@ class GlowDecoder:
                 wn=WN(sd, pc + "wn.", device, hidden, kernel_size, dilation_rate, num_coupling_layers),
                 end=PackedConv(wp, bp, device),
                 w_inv=_dev(w_inv.reshape(num_splits, num_splits), device),     # store_inverse(), glow.py:139-141
+                w_fwd=_dev(sd[pi + "weight"].float().reshape(num_splits, num_splits), device) if (pi + "weight") in sd else None,
                 an_bias=_dev(sd[pa + "bias"].reshape(-1), device), an_logs=_dev(sd[pa + "logs"].reshape(-1), device)))
 
     def __call__(self, z, y_mask):
@@ -410,6 +411,23 @@ class GlowDecoder:
             ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE, res=x, res_row_offset=self.half,
                        y_row_offset=self.half, out_mask=mq, split_row=self.half)
             ops.glow_invconv_actnorm(x, blk["w_inv"], blk["an_bias"], blk["an_logs"], mq, self.ns)
+        return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)
+
+    def forward_flow(self, y, y_mask):
+        """mel y [B,C,T] -> latent z [B,C,T'] (forward pass, decoder.py:113-137 with reverse=False; used by
+        GlowTTS.inference_with_MAS / decoder_inference): per block ActNorm, InvConvNear (the weight itself), coupling."""
+        B, C, T = y.shape
+        x, mq = ops.glow_squeeze(y, y_mask, self.nsq)
+        h = _new(x, self.hidden)
+        out = _new(x, self.hidden)
+        for blk in self.blocks:
+            if blk["w_fwd"] is None:
+                raise ops._lib.TtsAmdError("GlowDecoder.forward_flow needs flows.*.weight (only weight_inv was stored)")
+            ops.glow_invconv_actnorm(x, blk["w_fwd"], blk["an_bias"], blk["an_logs"], mq, self.ns, forward=True)
+            ops.conv1d(blk["start"], x, h, out_mask=mq)
+            blk["wn"](h, mq, out)
+            ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE_FWD, res=x, res_row_offset=self.half,
+                       y_row_offset=self.half, out_mask=mq, split_row=self.half)        # z1 = (t + exp(s) * x1) * mask
         return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)
 
 

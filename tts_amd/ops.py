@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import P, check, lib, stream_ptr
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 1, 2, 3
-CONV_NORMAL, CONV_GATE, CONV_SHUFFLE, CONV_COUPLE, CONV_RES_SKIP, CONV_COUPLE_AFFINE = 0, 1, 2, 3, 4, 5
+CONV_NORMAL, CONV_GATE, CONV_SHUFFLE, CONV_COUPLE, CONV_RES_SKIP, CONV_COUPLE_AFFINE, CONV_COUPLE_AFFINE_FWD = 0, 1, 2, 3, 4, 5, 6
 
 
 class Conv1dArgs(ctypes.Structure):
@@ -353,11 +353,20 @@ def glow_unsqueeze(x, mask_q, n, t_out):
     return y
 
 
-def glow_invconv_actnorm(x, w_inv, bias, logs, mask, num_splits=4):
+def glow_invconv_actnorm(x, w_inv, bias, logs, mask, num_splits=4, forward=False):
+    """reverse: invconv(w_inv) then actnorm^-1; forward: actnorm then invconv(w) (pass the weight itself as w_inv)."""
     B, C, T = x.shape
-    check(lib().ttsamd_glow_invconv_actnorm(P(x), P(w_inv), P(bias), P(logs), P(mask), B, C, T, num_splits,
+    check(lib().ttsamd_glow_invconv_actnorm(P(x), P(w_inv), P(bias), P(logs), P(mask), B, C, T, num_splits, int(forward),
                                             stream_ptr()), "glow_invconv_actnorm")
     return x
+
+
+def row_sum(x):
+    """sum over the last dim of [..., T] -> [...]  (attn.sum(-1))."""
+    x = x.float().contiguous()
+    o = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    check(lib().ttsamd_row_sum(P(o), P(x), ctypes.c_int64(o.numel()), x.shape[-1], stream_ptr()), "row_sum")
+    return o
 
 
 def attn_durations(cum, x_mask, y_lengths):
