@@ -219,3 +219,30 @@ def test_vits_voice_conversion_matches_reference_golden(gpu):
         assert _errs(t, torch.from_numpy(gold[name]))[1] < 1e-5, name
     rms, rel = _errs(o, torch.from_numpy(gold["model_outputs"]))
     assert rms < 1e-4 and rel < 1e-5, (rms, rel)
+
+
+def test_vits_encoder_sample_rate_interpolates_latent(gpu):
+    """encoder_sample_rate < audio.sample_rate (vits.py:806-812,944-959): z is linearly interpolated by the rate ratio
+    before the waveform decoder and y_mask is recomputed."""
+    import torch.nn.functional as F
+
+    args = dict(upsample_initial_channel_decoder=64)
+    sd = W.make_vits_state(args, seed=90)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, 100, (2, 15), generator=g)
+    xl = torch.tensor([15, 9])
+    dur = torch.randint(1, 4, (2, 1, 15), generator=g).float()
+    dur[1, :, 9:] = 0
+    t_dec = int(dur.sum(2).max())
+    noise_z = torch.randn(2, 192, t_dec, generator=g)
+    base = O.vits_inference(sd, x, xl, args, durations=dur, noise_z=noise_z, stop_after="flow")
+    z_up = F.interpolate(base["z"], scale_factor=[2.0], mode="linear")
+    y_mask_up = O.sequence_mask(base["y_lengths"] * 2.0, None).float().unsqueeze(1)
+    want = O.hifigan_forward(sd, "waveform_decoder.", z_up * y_mask_up, O.vits_decoder_cfg(dict(O.VITS_DEFAULTS, **args)))
+    m = Vits({"model_args": dict(args, encoder_sample_rate=11025), "audio": {"sample_rate": 22050}})
+    m.load_state_dict(sd)
+    m.to(gpu)
+    out = m.inference(x.to(gpu), {"x_lengths": xl.to(gpu), "durations": dur.to(gpu), "noise_z": noise_z.to(gpu)})
+    assert out["z"].shape[2] == 2 * t_dec and out["model_outputs"].shape == want.shape
+    rms, rel = _errs(out["model_outputs"], want)
+    assert rms < 1e-4 and rel < 1e-5, (rms, rel)

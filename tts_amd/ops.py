@@ -400,12 +400,16 @@ def speaker_cond(pc: PackedConv, g):
     return out.reshape(B, pc.c_out)
 
 
-def linear_interp(x, scale_factor):
-    """F.interpolate(x, scale_factor=[s], mode="linear") on [B, C, T] (hifigan_decoder.py:688-700)."""
+def linear_interp(x, scale_factor, recompute_scale_factor=False):
+    """F.interpolate(x, scale_factor=[s], mode="linear") on [B, C, T] (hifigan_decoder.py:688-700, vits.py:952).
+    recompute_scale_factor=True maps coordinates with out_size/in_size instead of s (torch semantics; used by
+    interpolate_vocoder_input, vocoder/utils/generic_utils.py:24-26)."""
     import math
 
     B, C, T = x.shape
     t_out = int(math.floor(T * float(scale_factor)))
+    if recompute_scale_factor and T > 0:
+        scale_factor = t_out / T
     x = x.float().contiguous()
     y = torch.empty((B, C, t_out), dtype=torch.float32, device=x.device)
     check(lib().ttsamd_linear_interp(P(y), P(x), ctypes.c_int64(B * C), T, t_out, ctypes.c_double(float(scale_factor)),

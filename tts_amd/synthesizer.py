@@ -107,12 +107,22 @@ class Synthesizer:
             mel = out["model_outputs"].transpose(1, 2)                        # [B,C,T]
             sr_t = _get(_get(self.tts_config, "audio", {}), "sample_rate", 22050)
             sr_v = _get(_get(self.vocoder_config, "audio", {}), "sample_rate", 22050)
-            if sr_t != sr_v:
-                raise _lib.TtsAmdError("vocoder / tts sample-rate mismatch (interpolate_vocoder_input) is not built")
             voc_in = mel_renorm_device(mel, self.tts_model.ap, self.vocoder_ap)
             if isinstance(self.tts_model, GlowTTS):                           # squeeze drops an odd last frame
                 nsq = self.tts_model.num_squeeze
                 frames = torch.div(frames, nsq, rounding_mode="floor") * nsq
+            if sr_t != sr_v:
+                # interpolate_vocoder_input (synthesizer.py:418-424): bilinear with scale [1, sr_v/sr_t] and
+                # recompute_scale_factor=True == linear interpolation along time only
+                from . import ops as _ops
+
+                if len(ids) > 1:
+                    raise _lib.TtsAmdError("sample-rate interpolation of the vocoder input is per sentence: "
+                                           "call with one sentence at a time (split_sentences) for this model pair")
+                voc_in = _ops.linear_interp(voc_in[:, :, : int(frames[0])].contiguous(), sr_v / sr_t,
+                                            recompute_scale_factor=True)
+                frames = torch.tensor([voc_in.shape[2]], device=voc_in.device)
+                mel = voc_in
             wav = self.vocoder_model.model_g.inference(voc_in, lengths=frames)
             pad = self.vocoder_model.model_g.inference_padding
             hop_total = wav.shape[-1] // (mel.shape[-1] + 2 * pad)

@@ -70,8 +70,13 @@ class Vits:
                 raise ValueError("[!] Speaker embedding layer already initialized before d_vector settings.")
             self.embedded_speaker_dim = a.d_vector_dim
         self.emb_g = None
+        # encoder at a lower sample rate than the decoder (vits.py:806-812): the latent is interpolated before decoding
+        self.interpolate_factor = None
         if a.encoder_sample_rate:
-            raise _lib.TtsAmdError("tts_amd.Vits: encoder_sample_rate / interpolate_z is not built")
+            sr = _get(_get(config, "audio", None), "sample_rate", None)
+            if sr is None:
+                raise ValueError("encoder_sample_rate needs config.audio.sample_rate")
+            self.interpolate_factor = sr / a.encoder_sample_rate
         self.waveform_decoder = HifiganGenerator(
             a.hidden_channels, 1, a.resblock_type_decoder, a.resblock_dilation_sizes_decoder,
             a.resblock_kernel_sizes_decoder, a.upsample_kernel_sizes_decoder, a.upsample_initial_channel_decoder,
@@ -259,11 +264,19 @@ class Vits:
         attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)
         y_mask = pri["y_mask"]
         z = self.flow(pri["z_p2"], y_mask, g=g)
+        dec_lengths = y_lengths
+        if self.interpolate_factor is not None and a.interpolate_z:           # upsampling_z, vits.py:944-959
+            z = ops.linear_interp(z, self.interpolate_factor)
+            dec_lengths = torch.ceil(y_lengths.to(torch.float64) * self.interpolate_factor).to(torch.int64)
+            if int(dec_lengths.max().item()) != z.shape[2]:
+                raise _lib.TtsAmdError("interpolate_z: y_lengths * interpolate_factor does not match the interpolated "
+                                       "latent length (the reference fails on this shape mismatch too)")
+            y_mask = ops.sequence_mask(dec_lengths, z.shape[2])
         zd = z if self.max_inference_len is None else z[:, :, : self.max_inference_len].contiguous()
         md = y_mask if self.max_inference_len is None else y_mask[:, : self.max_inference_len].contiguous()
         # "ragged_exact": every decoder conv treats row b as ending at y_lengths[b] -> row b equals a B=1 run
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
-        o = self.waveform_decoder.forward(zd, g=g, in_mask=md, lengths=y_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
+        o = self.waveform_decoder.forward(zd, g=g, in_mask=md, lengths=dec_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
         outputs = {
             "model_outputs": o,
             "alignments": attn,
@@ -275,7 +288,7 @@ class Vits:
             "y_mask": y_mask.unsqueeze(1),
         }
         if ragged:
-            outputs["y_lengths"] = y_lengths
+            outputs["y_lengths"] = dec_lengths
         if aux_input and aux_input.get("return_extras"):
             # (h / logw may alias the captured front end's static buffers: hand out copies)
             outputs.update(x=h.clone(), logw=None if logw is None else logw.clone().unsqueeze(1), y_lengths=y_lengths)
