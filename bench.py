@@ -131,6 +131,61 @@ def bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel):
         dist.destroy_process_group()
 
 
+def bench_mas(args, world, rank, dev, dist):
+    """The `maximum_path` operator alone (BASELINE.md "MAS" row): randn [32,257,770] fp32, ragged t_x in [200,257],
+    t_y in [600,770], seed 0.  HBM-bound: 12 B per band cell (value read + in-place write + path write)."""
+    import numpy as np
+
+    from tts_amd import helpers
+
+    B, TX, TY = 32, 257, 770
+    rng = np.random.default_rng(rank)
+    tx = rng.integers(200, TX + 1, B)
+    ty = rng.integers(600, TY + 1, B)
+    tx[0], ty[0] = TX, TY
+    mask = ((np.arange(TX)[None, :, None] < tx[:, None, None]) & (np.arange(TY)[None, None, :] < ty[:, None, None]))
+    mask_t = torch.from_numpy(mask.astype(np.float32)).to(dev)
+    value = torch.randn(B, TX, TY, device=dev)
+    cells = float(sum(int(a) * int(b) - int(a) * (int(a) - 1) for a, b in zip(tx, ty)))   # band-limited cell count
+    for _ in range(max(args.warmup, 1)):
+        helpers.maximum_path(value, mask_t)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    e0.record()
+    for _ in range(args.steps):
+        path = helpers.maximum_path(value, mask_t)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    line = {"metric": "monotonic alignment search, DP cells/s (maximum_path on [32,257,770])", "value": cells * world / (ms * 1e-3),
+            "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32->int32", "data": "synthetic",
+            "config": {"workload": "maximum_path(value, mask), B=32, T_x<=257, T_y<=770, ragged"},
+            "roofline": {"bound": "hbm", "achieved": 12.0 * cells / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": 12.0 * cells / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "traffic": None,
+                         "note": "one workgroup per item (32 items): the DP is a serial column sweep per item, i.e. "
+                                 "latency-bound, not bandwidth-bound, at this batch size"}}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import mas as omas
+
+        v, m = value.cpu().numpy(), mask.astype(np.float32)
+        omas.maximum_path(v, m, "c")
+        t0 = time.time()
+        n = 3
+        for _ in range(n):
+            omas.maximum_path(v, m, "c")
+        dt = (time.time() - t0) / n
+        line["cpu_baseline"] = {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                                "sample": "same problem, C restatement of core.pyx (single thread, as the reference ships it)"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +197,7 @@ def main():
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the MRF resblock branches on one stream (for rocprof: per-kernel durations are then not "
                          "inflated by co-running kernels; the roofline pass always runs this way)")
-    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1"],
+    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1", "mas"],
                     help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
     ap.add_argument("--items", type=int, default=256, help="hifigan_v1: items per GPU per step")
@@ -167,6 +222,8 @@ def main():
 
     if args.workload == "hifigan_v1":
         return bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel)
+    if args.workload == "mas":
+        return bench_mas(args, world, rank, dev, dist)
 
     # rank 0 builds the weights, everyone else receives them in one RCCL broadcast
     sd = W.make_vits_state({}, seed=1234) if rank == 0 else None

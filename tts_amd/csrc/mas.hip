@@ -41,14 +41,24 @@ __device__ __forceinline__ void mas_stage_tile(float *lds, const float *in,
     const int xs = lane >> MasTile<YT>::kShift;
     const int y = tile * YT + yl;
     const int ngroups = (Tx + MasTile<YT>::kRowsPerInstr - 1) / MasTile<YT>::kRowsPerInstr;
-#pragma unroll 8
-    for (int g = mover; g < ngroups; g += kMasMovers) {
-        const int x = g * MasTile<YT>::kRowsPerInstr + xs;
-        if (x < Tx && y < Ty) {
-            const long off = base + (long)x * Ty + y;
-            float v = in[off];
-            if (mask) v *= mask[off];
-            lds[yl * XP + x] = v;
+    // batches of 16 row groups: all loads of a batch are issued before the first LDS write (clamped addresses + select,
+    // no branch between them), so a tile costs ~one HBM round trip per batch instead of one per row group
+    constexpr int kBatch = 16;
+    const bool has_mask = mask != nullptr;
+    for (int g0 = mover; g0 < ngroups; g0 += kMasMovers * kBatch) {
+        float v[kBatch], m[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const int x = (g0 + i * kMasMovers) * MasTile<YT>::kRowsPerInstr + xs;
+            const bool ok = (x < Tx) && (y < Ty);
+            const long off = ok ? base + (long)x * Ty + y : base;
+            v[i] = in[off];
+            m[i] = has_mask ? mask[off] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const int x = (g0 + i * kMasMovers) * MasTile<YT>::kRowsPerInstr + xs;
+            if ((x < Tx) && (y < Ty)) lds[yl * XP + x] = has_mask ? v[i] * m[i] : v[i];
         }
     }
 }
@@ -70,12 +80,16 @@ __device__ __forceinline__ void mas_writeback_tile(const float *lds, float *out,
 }
 
 // ---- forward DP ------------------------------------------------------------------------------
-template <int RMAX, int YT>
+template <int RMAX, int YT, bool EXACT>
 __global__ __launch_bounds__(kMasThreads) void mas_forward_kernel(
     const float *in_values /* may alias dp_values (in-place mirror) */,
     const float *__restrict__ mask, float *dp_values, unsigned long long *__restrict__ dirs,
-    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R, float neg)
+    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R_rt, float neg)
 {
+    // EXACT: the number of 64-row groups is the template constant (T_x <= 512 gets its own instantiation), so every
+    // per-group guard folds at compile time; with a runtime R hipcc turned the column step into ~600 instructions of
+    // branches and register shuffling (2100 cycles per column).
+    const int R = EXACT ? RMAX : R_rt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     const int wave = threadIdx.x >> 6;
@@ -105,17 +119,36 @@ __global__ __launch_bounds__(kMasThreads) void mas_forward_kernel(
         if (wave == 0) {
             const int y_end = min(t_y, min(Ty, (t + 1) * YT));
             if (t_x > 0) {
+                // column values are prefetched one column ahead of the DP step that consumes them (LDS latency off the
+                // serial chain); the x-1 neighbour comes from a DPP wave shift (`v_mov_b32_dpp wave_shr:1`, one VALU op)
+                // instead of `__shfl_up` (ds_bpermute: an LDS round trip per row group and column), the carry between
+                // 64-row groups from a scalar readlane.
+                float cnext[RMAX];
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    const int x = r * 64 + lane;
+                    cnext[r] = (r < R && x < Tx && t * YT < y_end) ? cur[x] : 0.f;
+                }
                 for (int y = t * YT; y < y_end; ++y) {
                     const int yl = y - t * YT;
                     const int x_lo = max(0, t_x + y - t_y);
                     const int x_hi = min(t_x, y + 1);
+                    float cval[RMAX];
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r) {
+                        cval[r] = cnext[r];
+                        const int x = r * 64 + lane;
+                        if (r < R && y + 1 < y_end) cnext[r] = (x < Tx) ? cur[(yl + 1) * XP + x] : 0.f;
+                    }
                     float up[RMAX];
 #pragma unroll
                     for (int r = 0; r < RMAX; ++r) {
                         if (r < R) {
-                            float u = __shfl_up(prev[r], 1);
+                            float u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                                                    0, __builtin_bit_cast(int, prev[r]), 0x138, 0xf, 0xf, false));
                             if (r > 0) {
-                                const float carry = __shfl(prev[r - 1], 63);
+                                const float carry = __builtin_bit_cast(
+                                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev[r - 1]), 63));
                                 if (lane == 0) u = carry;
                             }
                             up[r] = u;
@@ -130,7 +163,7 @@ __global__ __launch_bounds__(kMasThreads) void mas_forward_kernel(
                                 const unsigned long long bits = __ballot(x >= 1 && prev[r] < up[r]);
                                 if (lane == 0) dirs[((long)b * Ty + (y - 1)) * R + r] = bits;
                             }
-                            const float c = (x < Tx) ? cur[yl * XP + x] : 0.f;
+                            const float c = cval[r];
                             const float v_cur = (x == y) ? neg : prev[r];
                             const float v_prev = (x == 0) ? (y == 0 ? 0.f : neg) : up[r];
                             const float nv = fmaxf(v_cur, v_prev) + c;
@@ -241,13 +274,13 @@ __global__ void mask_lengths_kernel(int *__restrict__ t_xs, int *__restrict__ t_
     }
 }
 
-template <int RMAX, int YT>
+template <int RMAX, int YT, bool EXACT = false>
 static int launch_forward(const float *in, const float *mask, float *dp, unsigned long long *dirs,
                           const int *t_xs, const int *t_ys, int B, int Tx, int Ty, int R, float neg,
                           hipStream_t st)
 {
     const size_t lds = (size_t)2 * YT * (64 * R + 1) * sizeof(float);
-    auto kern = mas_forward_kernel<RMAX, YT>;
+    auto kern = mas_forward_kernel<RMAX, YT, EXACT>;
     TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B), dim3(kMasThreads), lds, st, in, mask, dp, dirs, t_xs, t_ys, Tx,
@@ -286,10 +319,16 @@ extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const fl
     hipStream_t st = as_stream(stream);
     auto *dirs = reinterpret_cast<unsigned long long *>(workspace);
     int rc;
-    if (R <= 1)       rc = launch_forward<1, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
-    else if (R <= 2)  rc = launch_forward<2, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
-    else if (R <= 4)  rc = launch_forward<4, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
-    else if (R <= 8)  rc = launch_forward<8, 32>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+#define TTSAMD_MAS_EXACT(n) \
+    case n: rc = launch_forward<n, 32, true>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st); break;
+    if (R <= 8) {
+        switch (R) {
+            TTSAMD_MAS_EXACT(1) TTSAMD_MAS_EXACT(2) TTSAMD_MAS_EXACT(3) TTSAMD_MAS_EXACT(4)
+            TTSAMD_MAS_EXACT(5) TTSAMD_MAS_EXACT(6) TTSAMD_MAS_EXACT(7) TTSAMD_MAS_EXACT(8)
+            default: rc = TTSAMD_ERR_INVALID;
+        }
+    }
+#undef TTSAMD_MAS_EXACT
     else if (R <= 16) rc = launch_forward<16, 16>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
     else              rc = launch_forward<32, 8>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
     if (rc != TTSAMD_OK) return rc;
