@@ -246,3 +246,25 @@ def test_vits_encoder_sample_rate_interpolates_latent(gpu):
     assert out["z"].shape[2] == 2 * t_dec and out["model_outputs"].shape == want.shape
     rms, rel = _errs(out["model_outputs"], want)
     assert rms < 1e-4 and rel < 1e-5, (rms, rel)
+
+
+def test_vits_bench_shape_parity(gpu):
+    """The benchmark's own workload shape (VitsArgs defaults, 128-char utterances = 257 ids, 770 frames, 197 120
+    samples each) at B=2 against the oracle: waveform RMS <= 1e-4 (north_star) and <= 1e-5 relative."""
+    import bench
+
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    sd = W.make_vits_state({}, seed=1234)
+    x, xl, dur = bench.synthetic_batch(2, 128, 0, "cpu")
+    g = torch.Generator().manual_seed(11)
+    noise_dp = torch.randn(2, 2, 257, generator=g)
+    noise_z = torch.randn(2, 192, 770, generator=g)
+    want = O.vits_inference(sd, x, xl, {}, noise_z=noise_z, durations=dur.view(2, 1, -1))
+    m = _model({}, sd, gpu)
+    out = m.inference(x.to(gpu), {"x_lengths": xl.to(gpu), "durations": dur.to(gpu), "noise_dp": noise_dp.to(gpu),
+                                  "noise_z": noise_z.to(gpu), "run_duration_predictor": True, "return_extras": True})
+    assert out["model_outputs"].shape == (2, 1, 197120)
+    rms, rel = _errs(out["model_outputs"], want["model_outputs"])
+    assert rms < 1e-4 and rel < 1e-5, (rms, rel)
+    lw = O.vits_inference(sd, x, xl, {}, noise_dp=noise_dp, stop_after="prior", noise_z=torch.zeros(2, 192, 1))["logw"]
+    assert _errs(out["logw"], lw)[1] < 1e-5
