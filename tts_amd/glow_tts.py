@@ -102,7 +102,11 @@ class GlowTTS:
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
         o_mean, o_logs, logw = self.encoder(x, x_mask)
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
-        w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), glow=2 if ragged else 1)
+        d_in = aux_input.get("durations") if aux_input else None
+        if d_in is not None:   # not a reference feature: lets a parity harness pin the integer durations (ceil cliff)
+            w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d_in.to(dev, torch.float32).reshape(B, T).contiguous())
+        else:
+            w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), glow=2 if ragged else 1)
         t_dec = int(y_lengths.max().item())
         noise = aux_input.get("noise") if aux_input else None
         C = a.out_channels
@@ -124,6 +128,7 @@ class GlowTTS:
             "durations_log": logw.unsqueeze(1).transpose(1, 2),
             "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
             "y_lengths": y_lengths,
+            "durations": w_ceil.unsqueeze(1),
         }
 
     __call__ = inference
