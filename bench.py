@@ -186,6 +186,97 @@ def bench_mas(args, world, rank, dev, dist):
         dist.destroy_process_group()
 
 
+def bench_xtts_stream(args, world, rank, dev, dist, W):
+    """Vocoder half of BASELINE configs[4] (XTTS-v2 streaming; the GPT-2 half is out of scope): one
+    sentence of 200 synthetic GPT latents [1024], stream_chunk_size=20, overlap 1024 (xtts.py:609-616 defaults) through
+    the XTTS-v2 HifiDecoder (1024 -> 512 ch, ups 8,8,2,2, d-vector 512).  A "step" is one streamed sentence; the metric
+    is the wall time from "chunk's last latent available" to "chunk's waveform on the host", p50 over chunks."""
+    import numpy as np
+
+    from tts_amd.xtts_decoder import HifiDecoder
+    from tts_amd.xtts_stream import XttsStreamer
+
+    sd, cfg = W.make_hifi_decoder_state(seed=31)
+    dec = HifiDecoder()
+    dec.load_state_dict(sd)
+    dec.to(dev)
+    gen = torch.Generator().manual_seed(rank)
+    lat = torch.randn(200, 1024, generator=gen).to(dev)
+    g = torch.randn(1, 512, 1, generator=gen).to(dev)
+
+    def run(windowed):
+        st = XttsStreamer(dec, stream_chunk_size=20, overlap_wav_len=1024, windowed=windowed)
+        lats, n = [], 0
+        it = st.stream(iter(lat), g)
+        torch.cuda.synchronize()
+        while True:
+            t0 = time.perf_counter()
+            try:
+                c = next(it)
+            except StopIteration:
+                break
+            c = c.cpu()
+            lats.append((time.perf_counter() - t0) * 1e3)
+            n += c.numel()
+        return lats, n, st.frames_decoded
+
+    for _ in range(max(args.warmup, 1)):
+        run(True)
+        run(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    first, rest, samples = [], [], 0
+    for _ in range(args.steps):
+        l, n, frames_w = run(True)
+        first.append(l[0])
+        rest += l[1:]
+        samples += n
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ref_first, ref_rest = [], []
+    for _ in range(args.steps):
+        l, _, frames_f = run(False)
+        ref_first.append(l[0])
+        ref_rest += l[1:]
+    line = {"metric": "XTTS-v2 streaming, vocoder half: p50 first-chunk latency (20 latents -> waveform on host)",
+            "value": float(np.median(first)), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[4] vocoder half: 200 GPT latents/sentence, stream_chunk_size=20, "
+                                   "overlap_wav_len=1024, HifiDecoder 1024->512ch, tail-window schedule",
+                       "p50_later_chunk_ms": float(np.median(rest)), "max_later_chunk_ms": float(np.max(rest)),
+                       "reference_schedule_p50_first_ms": float(np.median(ref_first)),
+                       "reference_schedule_p50_later_ms": float(np.median(ref_rest)),
+                       "reference_schedule_max_later_ms": float(np.max(ref_rest)),
+                       "frames_vocoded_window": frames_w, "frames_vocoded_reference_schedule": frames_f,
+                       "samples_per_s_per_gpu": samples / wall}}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import tts_oracle as O
+
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        cpu_sd = {k: v.float() for k, v in sd.items()}
+        with torch.no_grad():
+            O.hifi_decoder_forward(cpu_sd, lat[:20].cpu()[None], g.cpu(), cfg)
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                O.hifi_decoder_forward(cpu_sd, lat[:20].cpu()[None], g.cpu(), cfg)
+            dt = (time.perf_counter() - t0) / n
+        line["cpu_baseline"] = {"value": dt * 1e3, "unit": "ms", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": "first chunk only (20 latents) through the oracle's HifiDecoder restatement"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +288,7 @@ def main():
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the MRF resblock branches on one stream (for rocprof: per-kernel durations are then not "
                          "inflated by co-running kernels; the roofline pass always runs this way)")
-    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1", "mas"],
+    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1", "mas", "xtts_stream"],
                     help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
     ap.add_argument("--items", type=int, default=256, help="hifigan_v1: items per GPU per step")
@@ -224,6 +315,8 @@ def main():
         return bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel)
     if args.workload == "mas":
         return bench_mas(args, world, rank, dev, dist)
+    if args.workload == "xtts_stream":
+        return bench_xtts_stream(args, world, rank, dev, dist, W)
 
     # rank 0 builds the weights, everyone else receives them in one RCCL broadcast
     sd = W.make_vits_state({}, seed=1234) if rank == 0 else None

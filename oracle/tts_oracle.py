@@ -129,6 +129,47 @@ def hifi_decoder_forward(sd, latents, g, cfg, input_sample_rate=22050, output_sa
     return hifigan_forward(sd, "waveform_decoder.", z, cfg, g=g)
 
 
+def xtts_handle_chunks(wav_gen, wav_gen_prev, wav_overlap, overlap_len):
+    """Xtts.handle_chunks, TTS/tts/models/xtts.py:585-607 (pinned against the function body itself, extracted from the
+    reference file, in tests/test_oracle_pin.py)."""
+    lo = 0 if wav_gen_prev is None else wav_gen_prev.shape[0] - overlap_len
+    wav_chunk = wav_gen[lo:-overlap_len]
+    if wav_overlap is not None:
+        if overlap_len > len(wav_chunk):
+            return (wav_gen[lo:] if wav_gen_prev is not None else wav_gen[-overlap_len:]), wav_gen, None
+        up = torch.linspace(0.0, 1.0, overlap_len)
+        down = torch.linspace(1.0, 0.0, overlap_len)
+        mixed = wav_chunk[:overlap_len] * up
+        wav_chunk[:overlap_len] = wav_overlap * down
+        wav_chunk[:overlap_len] += mixed
+    return wav_chunk, wav_gen, wav_gen[-overlap_len:]
+
+
+def xtts_stream_decode(sd, latent_steps, g, cfg, stream_chunk_size=20, overlap_wav_len=1024, length_scale=1.0, **dec):
+    """Vocoder half of Xtts.inference_stream, xtts.py:653-687: every `stream_chunk_size` latents (and at the end) the
+    whole prefix is re-vocoded and `handle_chunks` cuts + cross-fades.  latent_steps: list of [C] tensors."""
+    chunks, seen, fresh = [], [], 0
+    prev, overlap = None, None
+    steps = list(latent_steps)
+    i, end = 0, False
+    while not end:
+        if i < len(steps):
+            seen.append(steps[i].reshape(1, -1))
+            fresh += 1
+            i += 1
+        else:
+            end = True
+        if end or (stream_chunk_size > 0 and fresh >= stream_chunk_size):
+            lat = torch.cat(seen, 0)[None]
+            if length_scale != 1.0:
+                lat = F.interpolate(lat.transpose(1, 2), scale_factor=length_scale, mode="linear").transpose(1, 2)
+            wav = hifi_decoder_forward(sd, lat, g, cfg, **dec)
+            chunk, prev, overlap = xtts_handle_chunks(wav.squeeze(), prev, overlap, overlap_wav_len)
+            fresh = 0
+            chunks.append(chunk)
+    return chunks
+
+
 def hifigan_inference(sd, p, c, cfg):
     """HifiganGenerator.inference, hifigan_generator.py:267-282 (replicate pad, no crop)."""
     pad = cfg.get("inference_padding", 5)

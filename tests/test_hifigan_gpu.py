@@ -91,3 +91,33 @@ def test_xtts_hifi_decoder_matches_oracle_and_reference_golden(gpu):
         ref = torch.nn.functional.interpolate(z, scale_factor=[s], mode="linear")
         out = ops.linear_interp(z.to(gpu), s)
         assert out.shape == ref.shape and float((out.cpu() - ref).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("length_scale", [1.0, 1.25])
+def test_xtts_streaming_chunker(gpu, length_scale):
+    """Vocoder half of Xtts.inference_stream (xtts.py:653-687): chunks from the tail-window streamer are bit-identical
+    to the reference schedule (re-vocode the whole prefix per chunk) on the HIP path, and both match the oracle's
+    restatement run on the CPU; the window does O(n) generator work instead of O(n^2)."""
+    from tts_amd.xtts_decoder import HifiDecoder
+    from tts_amd.xtts_stream import XttsStreamer
+
+    sd, cfg = W.make_hifi_decoder_state(decoder_input_dim=96, d_vector_dim=32, upsample_initial_channel=64, seed=31)
+    steps = list(torch.randn(47, 96, generator=torch.Generator().manual_seed(11)))
+    g = torch.randn(1, 32, 1, generator=torch.Generator().manual_seed(12))
+    want = O.xtts_stream_decode(sd, steps, g, cfg, stream_chunk_size=10, overlap_wav_len=1024, length_scale=length_scale)
+    dec = HifiDecoder(decoder_input_dim=96, upsample_initial_channel_decoder=64, d_vector_dim=32)
+    dec.load_state_dict(sd)
+    dec.cuda()
+    dev_steps = [s.to(gpu) for s in steps]
+    win = XttsStreamer(dec, stream_chunk_size=10, overlap_wav_len=1024, length_scale=length_scale, windowed=True)
+    full = XttsStreamer(dec, stream_chunk_size=10, overlap_wav_len=1024, length_scale=length_scale, windowed=False)
+    a = [c.cpu() for c in win.stream(iter(dev_steps), g.to(gpu))]
+    b = [c.cpu() for c in full.stream(iter(dev_steps), g.to(gpu))]
+    assert len(a) == len(b) == len(want) == 5            # 4 full chunks + the final flush with the 7 leftover
+    for ca, cb, cw in zip(a, b, want):
+        assert ca.shape == cb.shape == cw.shape
+        assert torch.equal(ca, cb)
+        if cw.numel():
+            rms, rel = _errs(ca, cw)
+            assert rms < 1e-4 and rel < 1e-5, (rms, rel)
+    assert win.frames_decoded < 0.6 * full.frames_decoded

@@ -70,3 +70,26 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_xtts_handle_chunks_mirror_matches_oracle():
+    """tts_amd.xtts_stream.handle_chunks (host-side slicing + cross-fade, xtts.py:585-607) against the oracle restatement,
+    over a growing prefix incl. a chunk shorter than the overlap and the final flush; plus the receptive-field bound."""
+    import torch
+
+    from oracle import tts_oracle as O
+    from tts_amd.xtts_stream import context_frames, handle_chunks
+
+    for overlap in (64, 1024):
+        g = torch.Generator().manual_seed(overlap)
+        full = torch.randn(15000, generator=g)
+        pa = oa = pb = ob = None
+        for n in (5000, 9000, 9000 + overlap // 2, 14000, 14000):
+            wa = (full[:n] + 0.01 * torch.randn(n, generator=g)).clone()
+            wb = wa.clone()
+            ca, pa, oa = handle_chunks(wa, pa, oa, overlap)
+            cb, pb, ob = O.xtts_handle_chunks(wb, pb, ob, overlap)
+            assert torch.equal(ca, cb) and torch.equal(pa, pb)
+            assert (oa is None) == (ob is None) and (oa is None or torch.equal(oa, ob))
+    # HiFiGAN v1: SURVEY §8d measured an influence span of -9.2..+11.2 frames on the reference module
+    assert 12 <= context_frames([8, 8, 2, 2], "1", [3, 7, 11], [[1, 3, 5]] * 3) <= 16

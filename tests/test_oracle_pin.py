@@ -51,3 +51,34 @@ def test_weight_factory_layout_matches_reference_state_dicts():
 
     RM.RefVits(W.make_vits_state(dict(upsample_initial_channel_decoder=32)), dict(upsample_initial_channel_decoder=32))
     RM.RefGlow(W.make_glow_state(dict(num_flow_blocks_dec=2)), dict(num_flow_blocks_dec=2))
+
+
+def _reference_handle_chunks():
+    """The body of Xtts.handle_chunks compiled straight from the reference file (the class itself cannot be imported
+    here: GPT-2/tokenizer dependencies)."""
+    import ast
+
+    src = open(os.path.join(ref_shim.REF_ROOT, "TTS/tts/models/xtts.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "handle_chunks")
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "xtts.handle_chunks", "exec"), ns)  # noqa: S102
+    return lambda *a: ns["handle_chunks"](None, *a)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree absent (GPU box)")
+@pytest.mark.parametrize("overlap", [64, 1024])
+def test_oracle_handle_chunks_matches_reference(overlap):
+    from oracle import tts_oracle as O
+
+    ref = _reference_handle_chunks()
+    g = torch.Generator().manual_seed(overlap)
+    lens = [5000, 9000, 9000 + overlap // 2, 14000, 14000]      # growing prefix, a short chunk, the final flush
+    full = torch.randn(lens[-1] + 100, generator=g)
+    pa, oa, pb, ob = None, None, None, None
+    for n in lens:
+        wa = (full[:n] + 0.01 * torch.randn(n, generator=g)).clone()    # the tail of the prefix changes as it grows
+        wb = wa.clone()
+        ca, pa, oa = ref(wa, pa, oa, overlap)
+        cb, pb, ob = O.xtts_handle_chunks(wb, pb, ob, overlap)
+        assert torch.equal(ca, cb) and torch.equal(pa, pb)
+        assert (oa is None) == (ob is None) and (oa is None or torch.equal(oa, ob))

@@ -52,6 +52,15 @@ class HifiganGenerator:
         self.concurrent_branches = True     # MRF resblocks on separate HIP streams (see forward)
         self._side_streams = []
 
+    def hop_length(self):
+        return _cumprod(self.upsample_factors)[-1]
+
+    def context_frames(self):
+        """Input frames either side that can influence one output sample (see tts_amd/xtts_stream.py)."""
+        from .xtts_stream import context_frames
+        return context_frames(self.upsample_factors, self.resblock_type, self.resblock_kernel_sizes,
+                              self.resblock_dilation_sizes)
+
     # ---- torch.nn.Module-like surface used by Synthesizer (synthesizer.py:222-225,379) -----------
     def parameters(self):
         if self._packed is None:
