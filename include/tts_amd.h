@@ -189,7 +189,8 @@ int ttsamd_channel_norm(const ttsamd_norm_args *args /* host */, void *stream);
  *   masked scores = -1e4, transformer.py:147); emb_rel_k / emb_rel_v [2*window+1, dk] shared by
  *   all heads (heads_share=True) or NULL when rel_attn_window_size is None (window ignored).
  *   out [B, H*dk, T] contiguous.  QK^T and P.V run on the fp32-input MFMA (exact fp32 products).
- * Limits: dk % 32 == 0, dk <= 128, T <= 1024 (TTSAMD_ERR_UNSUPPORTED beyond). */
+ * Limits: dk <= 128 (any value: channels are zero-padded to the next multiple of 32 inside the kernel; multilingual
+ * VITS has dk = 98), T <= 1024 (TTSAMD_ERR_UNSUPPORTED beyond). */
 int ttsamd_rel_attention(float *out, const float *q, const float *k, const float *v, int64_t qkv_bstride,
                          const float *mask, const float *emb_rel_k, const float *emb_rel_v, int window,
                          int batch, int heads, int dk, int t, void *stream);
@@ -201,6 +202,10 @@ int ttsamd_rel_attention(float *out, const float *q, const float *k, const float
  * glow_tts/encoder.py:156-160).  tokens int64 [B,T], emb [V,C], mask [B,T] or NULL. */
 int ttsamd_embed(float *y, const int64_t *tokens, const float *emb, const float *mask, float scale,
                  int batch, int c, int t, int vocab, void *stream);
+/* Multilingual text encoder input (networks.py:87-93): y [B, c + c_extra, T]; rows 0..c-1 as ttsamd_embed, rows
+ * c.. = extra[b, :] (the language embedding `emb_l(lid)`, vits.py:1119-1124) broadcast over time, unscaled, * mask. */
+int ttsamd_embed_cat(float *y, const int64_t *tokens, const float *emb, const float *mask, float scale,
+                     const float *extra, int c_extra, int batch, int c, int t, int vocab, void *stream);
 
 /* mask[b,t] = t < lengths[b] ? 1 : 0   (sequence_mask, TTS/tts/utils/helpers.py:43-57). lengths int64 [B]. */
 int ttsamd_sequence_mask(float *mask, const int64_t *lengths, int batch, int t, void *stream);

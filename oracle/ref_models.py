@@ -38,17 +38,19 @@ class RefVits:
         dp = ref_shim.ref("TTS.tts.layers.glow_tts.duration_predictor")
         h = a["hidden_channels"]
         spk = int(a.get("embedded_speaker_dim", 0) or 0)
+        lng = int(a.get("embedded_language_dim", 4)) if a.get("use_language_embedding", False) else 0
+        self.emb_l = sd.get("emb_l.weight")
         self.text_encoder = nw.TextEncoder(a["num_chars"], h, h, a["hidden_channels_ffn_text_encoder"],
                                            a["num_heads_text_encoder"], a["num_layers_text_encoder"],
-                                           a["kernel_size_text_encoder"], 0.1, language_emb_dim=0)
+                                           a["kernel_size_text_encoder"], 0.1, language_emb_dim=lng)
         self.flow = nw.ResidualCouplingBlocks(h, h, kernel_size=a["kernel_size_flow"],
                                               dilation_rate=a["dilation_rate_flow"], num_layers=a["num_layers_flow"],
                                               cond_channels=spk)
         if a["use_sdp"]:
             self.duration_predictor = sdp.StochasticDurationPredictor(h, 192, 3, 0.5, 4, cond_channels=spk,
-                                                                      language_emb_dim=0)
+                                                                      language_emb_dim=lng)
         else:
-            self.duration_predictor = dp.DurationPredictor(h, 256, 3, 0.5, cond_channels=spk, language_emb_dim=0)
+            self.duration_predictor = dp.DurationPredictor(h, 256, 3, 0.5, cond_channels=spk, language_emb_dim=lng)
         self.emb_g = sd.get("emb_g.weight")
         self.posterior_encoder = None
         if any(k.startswith("posterior_encoder.") for k in sd):
@@ -75,7 +77,7 @@ class RefVits:
             self.waveform_decoder = hifigan(sd, cfg, h, "waveform_decoder.", False, False, False, cond_channels=spk)
 
     @torch.no_grad()
-    def inference(self, x, x_lengths, seed, speaker_ids=None, d_vectors=None):
+    def inference(self, x, x_lengths, seed, speaker_ids=None, d_vectors=None, language_ids=None):
         """vits.py:1112-1173 over the real modules; RNG draws happen inside the reference modules
         (stochastic_duration_predictor.py:287, vits.py:1155) under torch.manual_seed(seed)."""
         helpers = ref_shim.ref("TTS.tts.utils.helpers")
@@ -86,12 +88,15 @@ class RefVits:
             g = torch.nn.functional.normalize(d_vectors).unsqueeze(-1)
         elif speaker_ids is not None:
             g = torch.nn.functional.embedding(speaker_ids, self.emb_g).unsqueeze(-1)
-        x, m_p, logs_p, x_mask = self.text_encoder(x, x_lengths, lang_emb=None)
+        lang_emb = None                                              # vits.py:1119-1122
+        if language_ids is not None:
+            lang_emb = torch.nn.functional.embedding(language_ids, self.emb_l).unsqueeze(-1)
+        x, m_p, logs_p, x_mask = self.text_encoder(x, x_lengths, lang_emb=lang_emb)
         if a["use_sdp"]:
             logw = self.duration_predictor(x, x_mask, g=g, reverse=True, noise_scale=a["inference_noise_scale_dp"],
-                                           lang_emb=None)
+                                           lang_emb=lang_emb)
         else:
-            logw = self.duration_predictor(x, x_mask, g=g, lang_emb=None)
+            logw = self.duration_predictor(x, x_mask, g=g, lang_emb=lang_emb)
         w = torch.exp(logw) * x_mask * a["length_scale"]
         w_ceil = torch.ceil(w)
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
@@ -144,7 +149,7 @@ class RefGlow:
         self.decoder.store_inverse()  # GlowTTS.load_checkpoint(eval=True), glow_tts.py:522-530
 
     @torch.no_grad()
-    def inference(self, x, x_lengths, seed, speaker_ids=None, d_vectors=None):
+    def inference(self, x, x_lengths, seed, speaker_ids=None, d_vectors=None, language_ids=None):
         helpers = ref_shim.ref("TTS.tts.utils.helpers")
         a = self.a
         torch.manual_seed(seed)

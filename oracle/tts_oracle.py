@@ -373,10 +373,12 @@ def rel_pos_transformer(sd, p, x, x_mask, num_layers, num_heads, kernel_size, wi
     return x * x_mask
 
 
-def text_encoder(sd, p, tokens, x_lengths, cfg):
-    """TextEncoder.forward, vits/networks.py:79-100."""
+def text_encoder(sd, p, tokens, x_lengths, cfg, lang_emb=None):
+    """TextEncoder.forward, vits/networks.py:79-100.  lang_emb [B,L,1] is concatenated as extra channels (:89-91)."""
     hidden = cfg["hidden_channels"]
     x = F.embedding(tokens, sd[p + "emb.weight"]) * math.sqrt(hidden)
+    if lang_emb is not None:
+        x = torch.cat((x, lang_emb.transpose(2, 1).expand(x.size(0), x.size(1), -1)), dim=-1)
     x = torch.transpose(x, 1, -1)
     x_mask = torch.unsqueeze(sequence_mask(x_lengths, x.size(2)), 1).to(x.dtype)
     x = rel_pos_transformer(sd, p + "encoder.", x * x_mask, x_mask, cfg["num_layers_text_encoder"],
@@ -478,13 +480,15 @@ def conv_flow_reverse(sd, p, x, x_mask, g, hidden, kernel_size, num_layers, num_
     return torch.cat([x0, x1], 1) * x_mask
 
 
-def sdp_reverse(sd, p, x, x_mask, noise, noise_scale=1.0, hidden=192, kernel_size=3, num_flows=4, g=None):
+def sdp_reverse(sd, p, x, x_mask, noise, noise_scale=1.0, hidden=192, kernel_size=3, num_flows=4, g=None, lang_emb=None):
     """StochasticDurationPredictor.forward(reverse=True), stochastic_duration_predictor.py:230-239,283-294.
 
     `noise` [B,2,T] replaces the internal torch.randn (:287) so both sides see identical draws."""
     x = conv1d(sd, p + "pre", x)
     if g is not None:
         x = x + conv1d(sd, p + "cond", g)
+    if lang_emb is not None:                                   # :235-236
+        x = x + conv1d(sd, p + "cond_lang", lang_emb)
     x = dds_conv(sd, p + "convs.", x, x_mask, kernel_size, 3)
     x = conv1d(sd, p + "proj", x) * x_mask
     order = list(reversed(range(num_flows + 1)))      # flows[4],[3],[2],[1],[0]
@@ -499,10 +503,12 @@ def sdp_reverse(sd, p, x, x_mask, noise, noise_scale=1.0, hidden=192, kernel_siz
     return z[:, :1]
 
 
-def duration_predictor(sd, p, x, x_mask, g=None):
+def duration_predictor(sd, p, x, x_mask, g=None, lang_emb=None):
     """glow_tts/duration_predictor.py:46-69 (conv -> relu -> LayerNorm(1e-4), twice, then 1x1)."""
     if g is not None:
         x = x + conv1d(sd, p + "cond", g)
+    if lang_emb is not None:                                   # :61-62
+        x = x + conv1d(sd, p + "cond_lang", lang_emb)
     k = weight(sd, p + "conv_1").shape[-1]
     x = conv1d(sd, p + "conv_1", x * x_mask, padding=k // 2)
     x = layer_norm1(sd, p + "norm_1", torch.relu(x))
@@ -542,9 +548,14 @@ def vits_speaker_g(sd, speaker_ids=None, d_vectors=None):
     return None
 
 
+def vits_language_emb(sd, language_ids):
+    """vits.py:1119-1122: lang_emb = emb_l(lid).unsqueeze(-1)."""
+    return None if language_ids is None else F.embedding(language_ids, sd["emb_l.weight"]).unsqueeze(-1)
+
+
 def vits_inference(sd, tokens, x_lengths=None, args=None, noise_dp=None, noise_z=None, durations=None,
-                   stop_after=None, g=None):
-    """Vits.inference, vits.py:1088-1173 (single speaker: g=None, lang_emb=None).
+                   stop_after=None, g=None, lang_emb=None):
+    """Vits.inference, vits.py:1088-1173 (g: speaker conditioning [B,C,1]; lang_emb: language embedding [B,L,1]).
 
     noise_dp [B,2,T_text] / noise_z [B,C,T_dec] replace the internal randn draws
     (stochastic_duration_predictor.py:287, vits.py:1155); when None they are drawn with torch.randn in
@@ -554,17 +565,17 @@ def vits_inference(sd, tokens, x_lengths=None, args=None, noise_dp=None, noise_z
     a.update(args or {})
     if x_lengths is None:
         x_lengths = torch.tensor(tokens.shape[1:2])                         # vits.py:1082-1086
-    x, m_p, logs_p, x_mask = text_encoder(sd, "text_encoder.", tokens, x_lengths, a)
+    x, m_p, logs_p, x_mask = text_encoder(sd, "text_encoder.", tokens, x_lengths, a, lang_emb=lang_emb)
     out = {"x": x, "m_p_text": m_p, "logs_p_text": logs_p, "x_mask": x_mask}
     if durations is None:
         if a["use_sdp"]:
             if noise_dp is None:
                 noise_dp = torch.randn(x.size(0), 2, x.size(2))
             logw = sdp_reverse(sd, "duration_predictor.", x, x_mask, noise_dp, a["inference_noise_scale_dp"],
-                               hidden=192, g=g if a.get("condition_dp_on_speaker", True) else None)
+                               hidden=192, g=g if a.get("condition_dp_on_speaker", True) else None, lang_emb=lang_emb)
         else:
             logw = duration_predictor(sd, "duration_predictor.", x, x_mask,
-                                      g=g if a.get("condition_dp_on_speaker", True) else None)
+                                      g=g if a.get("condition_dp_on_speaker", True) else None, lang_emb=lang_emb)
         out["logw"] = logw
         w = torch.exp(logw) * x_mask * a["length_scale"]                    # vits.py:1140
         w_ceil = torch.ceil(w)

@@ -66,6 +66,25 @@ def vits_small_speaker(impl, mode):
     return {k: out[k] for k in ["logw", "durations", "z_p", "z", "model_outputs"]}
 
 
+def vits_small_language(impl, use_sdp):
+    """Multilingual VITS (vits.py:783-803,1119-1138; networks.py:62-63,89-91): the language embedding widens the text
+    encoder to 192+4 channels (head size 98) and conditions the duration predictor next to the speaker embedding."""
+    args = dict(VITS_SMALL, embedded_speaker_dim=24, use_speaker_embedding=True, num_speakers=5, use_sdp=use_sdp,
+                use_language_embedding=True, embedded_language_dim=4, num_languages=3)
+    sd = W.make_vits_state(args, seed=777)
+    x = torch.randint(0, 100, (2, 23), generator=_g(13))
+    xl = torch.tensor([23, 17])
+    sid, lid = torch.tensor([2, 4]), torch.tensor([1, 2])
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        out = RM.RefVits(sd, args).inference(x, xl, seed=19, speaker_ids=sid, language_ids=lid)
+    else:
+        torch.manual_seed(19)
+        out = O.vits_inference(sd, x, xl, args, g=O.vits_speaker_g(sd, sid, None), lang_emb=O.vits_language_emb(sd, lid))
+    return {k: out[k] for k in ["logw", "durations", "z_p", "z", "model_outputs"]}
+
+
 VITS_VC = dict(VITS_SMALL, embedded_speaker_dim=24, use_speaker_embedding=True, num_speakers=5, out_channels=65,
                num_layers_posterior_encoder=6)
 
@@ -139,6 +158,8 @@ CASES = {
     "vits_small_dp": lambda impl: vits_small(impl, False),
     "vits_small_spk_emb": lambda impl: vits_small_speaker(impl, "emb"),
     "vits_small_spk_dvec": lambda impl: vits_small_speaker(impl, "dvec"),
+    "vits_small_lang_sdp": lambda impl: vits_small_language(impl, True),
+    "vits_small_lang_dp": lambda impl: vits_small_language(impl, False),
     "xtts_hifi_decoder": xtts_hifi_decoder,
     "vits_voice_conversion": vits_voice_conversion,
     "glow_small": lambda impl: glow_small(impl),

@@ -93,3 +93,34 @@ def test_xtts_handle_chunks_mirror_matches_oracle():
             assert (oa is None) == (ob is None) and (oa is None or torch.equal(oa, ob))
     # HiFiGAN v1: SURVEY §8d measured an influence span of -9.2..+11.2 frames on the reference module
     assert 12 <= context_frames([8, 8, 2, 2], "1", [3, 7, 11], [[1, 3, 5]] * 3) <= 16
+
+
+def test_speaker_and_language_managers(tmp_path):
+    """Known answers for the id / d-vector tables (managers.py:184-239,273-293; speakers.py:86-117; languages.py:47-100)."""
+    from tts_amd.managers import LanguageManager, SpeakerManager
+
+    ids = tmp_path / "speakers.json"
+    ids.write_text(json.dumps({"p225": 0, "p226": 1}))
+    m = SpeakerManager(speaker_id_file_path=str(ids))
+    assert m.num_speakers == 2 and m.speaker_names == ["p225", "p226"] and m.embedding_dim == 0
+    dv = tmp_path / "d.json"
+    dv.write_text(json.dumps({"b1.wav": {"name": "zed", "embedding": [1.0, 2.0, 3.0]},
+                              "a1.wav": {"name": "amy", "embedding": [0.0, 0.0, 3.0]},
+                              "b2.wav": {"name": "zed", "embedding": [3.0, 2.0, 1.0]}}))
+    m = SpeakerManager(d_vectors_file_path=str(dv))
+    assert m.name_to_id == {"amy": 0, "zed": 1} and m.embedding_dim == 3 and len(m.clip_ids) == 3
+    assert np.allclose(m.get_mean_embedding("zed"), [2.0, 2.0, 2.0])
+    assert np.allclose(m.get_mean_embedding("zed", num_samples=1), [1.0, 2.0, 3.0])
+    assert m.get_embedding_by_clip("a1.wav") == [0.0, 0.0, 3.0]
+    cfg = {"model_args": {"use_d_vector_file": True, "d_vector_file": str(dv)}}
+    assert SpeakerManager.init_from_config(cfg).num_speakers == 2
+    assert SpeakerManager.init_from_config({"model_args": {}}) is None
+    assert SpeakerManager.init_from_config({"use_speaker_embedding": True, "speakers_file": str(ids)}).name_to_id["p226"] == 1
+    lf = tmp_path / "language_ids.json"
+    lf.write_text(json.dumps({"en": 0, "pt-br": 1}))
+    lm = LanguageManager.init_from_config({"model_args": {"use_language_embedding": True, "language_ids_file": str(lf)}})
+    assert lm.num_languages == 2 and lm.language_names == ["en", "pt-br"]
+    lm = LanguageManager.init_from_config({"use_language_embedding": True,
+                                           "datasets": [{"name": "a", "language": "fr"}, {"name": "b", "language": "de"}]})
+    assert lm.name_to_id == {"de": 0, "fr": 1}
+    assert LanguageManager.init_from_config({"model_args": {"use_language_embedding": False}}) is None

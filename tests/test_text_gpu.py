@@ -61,9 +61,12 @@ def test_dds_conv_matches_oracle(gpu):
     assert _rel(got, want) < TOL
 
 
-@pytest.mark.parametrize("window,T,lens", [(4, 257, [257, 200]), (None, 64, [64, 31]), (4, 3, [3, 2]), (4, 40, [40, 1])])
-def test_rel_attention_matches_oracle(gpu, window, T, lens):
-    H, heads, B = 192, 2, 2
+@pytest.mark.parametrize("window,T,lens,H", [(4, 257, [257, 200], 192), (None, 64, [64, 31], 192), (4, 3, [3, 2], 192),
+                                             (4, 40, [40, 1], 192), (4, 70, [70, 33], 196), (None, 50, [50, 9], 20)])
+def test_rel_attention_matches_oracle(gpu, window, T, lens, H):
+    """H=196 -> head size 98 (multilingual VITS: 192 + 4 language channels), H=20 -> head size 10: sizes that are not
+    multiples of the 32-wide MFMA tile run zero-padded inside the kernel."""
+    heads, B = 2, 2
     f = W._F(T)
     W._transformer(f, "t.", H, 768, 1, heads, 3, window, False)
     sd = f.sd

@@ -38,11 +38,11 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <int DK>
+template <int DK>  // dk rounded up to a multiple of 32; channels dk..DK-1 are treated as zeros
 __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
     float *__restrict__ out, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, long qkv_bstride, const float *__restrict__ mask,
-    const float *__restrict__ emb_k, const float *__restrict__ emb_v, int window, int heads, int T, int pitch)
+    const float *__restrict__ emb_k, const float *__restrict__ emb_v, int window, int heads, int dk, int T, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *S = smem;                            // [32][pitch]
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
     const int t0 = blockIdx.x * kAttRows;
     const int head = blockIdx.y;
     const int b = blockIdx.z;
-    const long hoff = (long)b * qkv_bstride + (long)head * DK * T;
+    const long hoff = (long)b * qkv_bstride + (long)head * dk * T;
     const float *qh = q + hoff, *kh = k + hoff, *vh = v + hoff;
     const float *mrow = mask ? mask + (long)b * T : nullptr;
-    const float scale = sqrtf((float)DK);
+    const float scale = sqrtf((float)dk);
     const int ntiles = (T + 31) / 32;
 
     // ---- 1. S = Q K^T / sqrt(dk) ------------------------------------------------------------
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
         float aq[DK / 2];
         const bool qv = (t0 + j) < T;
 #pragma unroll
-        for (int ks = 0; ks < DK / 2; ++ks) aq[ks] = qv ? qh[(long)(2 * ks + hh) * T + t0 + j] : 0.f;
+        for (int ks = 0; ks < DK / 2; ++ks) aq[ks] = (qv && 2 * ks + hh < dk) ? qh[(long)(2 * ks + hh) * T + t0 + j] : 0.f;
         for (int jt = wave; jt < ntiles; jt += 4) {
             f32x16 acc;
 #pragma unroll
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
             const bool kv = col < T;
 #pragma unroll
             for (int ks = 0; ks < DK / 2; ++ks) {
-                const float bv = kv ? kh[(long)(2 * ks + hh) * T + col] : 0.f;
+                const float bv = (kv && 2 * ks + hh < dk) ? kh[(long)(2 * ks + hh) * T + col] : 0.f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ks], bv, acc, 0, 0, 0);
             }
 #pragma unroll
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
             const int tj = ti + r - window;
             if (ti < T && tj >= 0 && tj < T) {
                 float dot = 0.f;
-                for (int c = 0; c < DK; ++c) dot += qh[(long)c * T + ti] * emb_k[r * DK + c];
+                for (int c = 0; c < dk; ++c) dot += qh[(long)c * T + ti] * emb_k[r * dk + c];
                 S[i * pitch + tj] += dot / scale;
             }
         }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
         for (int e = tid; e < DK * 32; e += kAttThreads) {
             const int n = e >> 5, c = e & 31;
             const int tt = kt * 32 + c;
-            Vs[n * kAttVPitch + c] = (tt < T) ? vh[(long)n * T + tt] : 0.f;
+            Vs[n * kAttVPitch + c] = (tt < T && n < dk) ? vh[(long)n * T + tt] : 0.f;
         }
         __syncthreads();
         if (mma_wave) {
@@ -164,16 +164,17 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (n >= dk) continue;
                 float o = acc[r];
                 if (emb_v) {
                     float rel = 0.f;
                     for (int d = 0; d <= 2 * window; ++d) {
                         const int tj = ti + d - window;
-                        if (tj >= 0 && tj < T) rel += S[j * pitch + tj] * emb_v[d * DK + n];
+                        if (tj >= 0 && tj < T) rel += S[j * pitch + tj] * emb_v[d * dk + n];
                     }
                     o += rel;
                 }
-                out[((long)b * heads * DK + (long)head * DK + n) * T + ti] = o;
+                out[((long)b * heads * dk + (long)head * dk + n) * T + ti] = o;
             }
         }
     }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
 
 template <int DK>
 static int launch_att(float *out, const float *q, const float *k, const float *v, long bstride, const float *mask,
-                      const float *ek, const float *ev, int window, int batch, int heads, int T, hipStream_t st)
+                      const float *ek, const float *ev, int window, int batch, int heads, int dk, int T, hipStream_t st)
 {
     const int ntiles = (T + 31) / 32;
     const int pitch = ntiles * 32 + 1;
@@ -194,7 +195,7 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
         lds_set = 160 * 1024;
     }
     hipLaunchKernelGGL(kern, dim3(ntiles, heads, batch), dim3(kAttThreads), lds, st, out, q, k, v, bstride, mask,
-                       ek, ev, window, heads, T, pitch);
+                       ek, ev, window, heads, dk, T, pitch);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
@@ -211,15 +212,15 @@ extern "C" int ttsamd_rel_attention(float *out, const float *q, const float *k, 
     TTSAMD_CHECK_ARG((emb_rel_k == nullptr) == (emb_rel_v == nullptr), "rel_attention: need both or neither rel embeddings");
     TTSAMD_CHECK_ARG(!emb_rel_k || window >= 0, "rel_attention: bad window");
     if (batch == 0 || t == 0) return TTSAMD_OK;
-    if (t > 1024 || (dk != 32 && dk != 64 && dk != 96 && dk != 128) || batch > 65535 || heads > 65535) {
-        set_error("rel_attention: unsupported shape (dk=%d must be 32/64/96/128, T=%d <= 1024)", dk, t);
+    if (t > 1024 || dk > 128 || batch > 65535 || heads > 65535) {
+        set_error("rel_attention: unsupported shape (dk=%d <= 128, T=%d <= 1024)", dk, t);
         return TTSAMD_ERR_UNSUPPORTED;
     }
     hipStream_t st = as_stream(stream);
-    switch (dk) {
-        case 32: return launch_att<32>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, t, st);
-        case 64: return launch_att<64>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, t, st);
-        case 96: return launch_att<96>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, t, st);
-        default: return launch_att<128>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, t, st);
+    switch ((dk + 31) / 32) {   // e.g. dk = 98: multilingual VITS, (192 + 4 language channels) / 2 heads
+        case 1: return launch_att<32>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, dk, t, st);
+        case 2: return launch_att<64>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, dk, t, st);
+        case 3: return launch_att<96>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, dk, t, st);
+        default: return launch_att<128>(out, q, k, v, qkv_bstride, mask, emb_rel_k, emb_rel_v, window, batch, heads, dk, t, st);
     }
 }

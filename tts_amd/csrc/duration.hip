@@ -11,7 +11,8 @@ constexpr int kTxtThreads = 256;
 
 // ---- embedding ------------------------------------------------------------------------------
 __global__ void embed_kernel(float *__restrict__ y, const long *__restrict__ tokens, const float *__restrict__ emb,
-                             const float *__restrict__ mask, float scale, int C, int T, int V)
+                             const float *__restrict__ mask, float scale, int C, int T, int V,
+                             const float *__restrict__ extra, int CE)
 {
     const int b = blockIdx.z;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -22,7 +23,12 @@ __global__ void embed_kernel(float *__restrict__ y, const long *__restrict__ tok
     for (int c = blockIdx.y; c < C; c += gridDim.y) {
         float v = emb[tok * C + c] * scale;
         if (mask) v *= m;
-        y[((long)b * C + c) * T + t] = v;
+        y[((long)b * (C + CE) + c) * T + t] = v;
+    }
+    for (int c = blockIdx.y; c < CE; c += gridDim.y) {   // per-item channels appended unscaled (language embedding)
+        float v = extra[(long)b * CE + c];
+        if (mask) v *= m;
+        y[((long)b * (C + CE) + C + c) * T + t] = v;
     }
 }
 
@@ -284,7 +290,20 @@ extern "C" int ttsamd_embed(float *y, const int64_t *tokens, const float *emb, c
     if (batch == 0 || t == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(batch <= 65535, "embed: batch > 65535");
     hipLaunchKernelGGL(embed_kernel, dim3(cdiv(t, 64), min(c, 16), batch), dim3(64), 0, as_stream(stream), y,
-                       reinterpret_cast<const long *>(tokens), emb, mask, scale, c, t, vocab);
+                       reinterpret_cast<const long *>(tokens), emb, mask, scale, c, t, vocab, nullptr, 0);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_embed_cat(float *y, const int64_t *tokens, const float *emb, const float *mask, float scale,
+                                const float *extra, int c_extra, int batch, int c, int t, int vocab, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && tokens && emb && batch >= 0 && c > 0 && t >= 0 && vocab > 0, "embed_cat: bad args");
+    TTSAMD_CHECK_ARG(c_extra >= 0 && (c_extra == 0 || extra), "embed_cat: extra channels without a table");
+    if (batch == 0 || t == 0) return TTSAMD_OK;
+    TTSAMD_CHECK_ARG(batch <= 65535, "embed_cat: batch > 65535");
+    hipLaunchKernelGGL(embed_kernel, dim3(cdiv(t, 64), min(c, 16), batch), dim3(64), 0, as_stream(stream), y,
+                       reinterpret_cast<const long *>(tokens), emb, mask, scale, c, t, vocab, extra, c_extra);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

@@ -104,13 +104,19 @@ class TextEncoder:
         self.encoder = RelativePositionTransformer(sd, p + "encoder.", device, num_layers, num_heads, kernel_size, 4, "2")
         self.proj = PackedConv(sd[p + "proj.weight"], sd[p + "proj.bias"], device)
 
-    def __call__(self, tokens, x_mask):
-        """tokens int64 [B,T], x_mask [B,T] -> x [B,H,T], stats [B,2H,T] (m | logs), networks.py:79-100."""
+    def __call__(self, tokens, x_mask, lang=None):
+        """tokens int64 [B,T], x_mask [B,T] -> x [B,H,T], stats [B,2H,T] (m | logs), networks.py:79-100.
+        lang [B,L] (language embedding, multilingual models): appended as L extra channels, so the encoder runs at
+        H+L channels and x is [B,H+L,T] (networks.py:62-63,89-91)."""
         B, T = tokens.shape
-        x = torch.empty((B, self.hidden, T), dtype=torch.float32, device=tokens.device)
-        ops.embed(tokens, self.emb, x_mask, math.sqrt(self.hidden), x)
+        if lang is None:
+            x = torch.empty((B, self.hidden, T), dtype=torch.float32, device=tokens.device)
+            ops.embed(tokens, self.emb, x_mask, math.sqrt(self.hidden), x)
+        else:
+            x = torch.empty((B, self.hidden + lang.shape[1], T), dtype=torch.float32, device=tokens.device)
+            ops.embed_cat(tokens, self.emb, x_mask, math.sqrt(self.hidden), lang, x)
         x = self.encoder(x, x_mask)
-        stats = _new(x, 2 * self.hidden)
+        stats = _new(x, self.proj.c_out)
         ops.conv1d(self.proj, x, stats, out_mask=x_mask)
         return x, stats
 
@@ -141,6 +147,31 @@ class DDSConv:
         return x
 
 
+def _lang_cond(sd, p, device, has_speaker_cond):
+    """`cond_lang` 1x1 (language embedding -> channel offsets); when a speaker `cond` exists too the pair is also packed
+    as ONE 1x1 over the concatenated [g ; lang] vector, so both offsets cost a single launch."""
+    if (p + "cond_lang.weight") not in sd:
+        return None, None
+    wl, bl = sd[p + "cond_lang.weight"].float(), sd[p + "cond_lang.bias"].float()
+    both = None
+    if has_speaker_cond:
+        both = PackedConv(torch.cat([sd[p + "cond.weight"].float(), wl], 1), sd[p + "cond.bias"].float() + bl, device)
+    return PackedConv(wl, bl, device), both
+
+
+def _cond_offsets(mod, g, lang):
+    """Per-(item, channel) conditioning offsets cond(g) + cond_lang(lang) as one [B, C] row_bias operand, or None."""
+    use_g = g is not None and mod.cond is not None
+    use_l = lang is not None and mod.cond_lang is not None
+    if use_g and use_l:
+        return ops.speaker_cond(mod.cond_both, torch.cat([g, lang], 1))
+    if use_g:
+        return ops.speaker_cond(mod.cond, g)
+    if use_l:
+        return ops.speaker_cond(mod.cond_lang, lang)
+    return None
+
+
 # ------------------------------------------------------------------------------------------------
 # StochasticDurationPredictor (reverse) — stochastic_duration_predictor.py:150-294
 # ------------------------------------------------------------------------------------------------
@@ -153,6 +184,7 @@ class StochasticDurationPredictor:
         self.cond = None
         if cond_channels and (p + "cond.weight") in sd:
             self.cond = PackedConv(sd[p + "cond.weight"], sd[p + "cond.bias"], device)
+        self.cond_lang, self.cond_both = _lang_cond(sd, p, device, self.cond is not None)
         self.ea_m = _dev(sd[p + "flows.0.translation"].reshape(-1), device)
         self.ea_logs = _dev(sd[p + "flows.0.log_scale"].reshape(-1), device)
         self.flows = {}
@@ -164,11 +196,12 @@ class StochasticDurationPredictor:
                 proj=PackedConv(sd[q + "proj.weight"], sd[q + "proj.bias"], device))
             self.num_bins = (sd[q + "proj.weight"].shape[0] + 1) // 3
 
-    def __call__(self, x, mask, noise, noise_scale=1.0, g=None):
-        """x [B,C,T] (text-encoder hidden), mask [B,T], noise [B,2,T] -> logw [B,T] view of z[:,0]."""
+    def __call__(self, x, mask, noise, noise_scale=1.0, g=None, lang=None):
+        """x [B,C,T] (text-encoder hidden), mask [B,T], noise [B,2,T] -> logw [B,T] view of z[:,0].
+        lang [B,L,1]: language embedding, `x + cond_lang(lang_emb)` (:235-236)."""
         h = _new(x, self.hidden)
-        row_bias = ops.speaker_cond(self.cond, g) if (g is not None and self.cond is not None) else None
-        ops.conv1d(self.pre, x, h, row_bias=row_bias)          # pre(x) + cond(g)  (:230-233)
+        row_bias = _cond_offsets(self, g, lang)
+        ops.conv1d(self.pre, x, h, row_bias=row_bias)          # pre(x) + cond(g) + cond_lang(l)  (:230-236)
         h = self.convs(h, mask)
         cond = _new(h)
         ops.conv1d(self.proj, h, cond, out_mask=mask)
@@ -197,16 +230,18 @@ class StochasticDurationPredictor:
 class DurationPredictor:
     def __init__(self, sd, p, device):
         self.cond = PackedConv(sd[p + "cond.weight"], sd[p + "cond.bias"], device) if (p + "cond.weight") in sd else None
+        self.cond_lang, self.cond_both = _lang_cond(sd, p, device, self.cond is not None)
         self.c1 = PackedConv(sd[p + "conv_1.weight"], sd[p + "conv_1.bias"], device)
         self.c2 = PackedConv(sd[p + "conv_2.weight"], sd[p + "conv_2.bias"], device)
         self.n1 = _Norm(sd, p + "norm_1", device, 1e-4)
         self.n2 = _Norm(sd, p + "norm_2", device, 1e-4)
         self.proj = PackedConv(sd[p + "proj.weight"], sd[p + "proj.bias"], device)
 
-    def __call__(self, x, mask, g=None):
+    def __call__(self, x, mask, g=None, lang=None):
         """x [B,C,T] -> logw [B,T]   (conv -> relu -> LayerNorm twice, then 1x1; dropout is off in eval)."""
-        if g is not None and self.cond is not None:
-            x = ops.add_row_bias(x, ops.speaker_cond(self.cond, g))     # x + cond(g)
+        rb = _cond_offsets(self, g, lang)
+        if rb is not None:
+            x = ops.add_row_bias(x, rb)                                 # x + cond(g) + cond_lang(l)  (:58-62)
         h = _new(x, self.c1.c_out)
         ops.conv1d(self.c1, x, h, in_mask=mask, out_act=ACT_RELU)
         h = ops.channel_norm(h, _new(h), self.n1.gamma, self.n1.beta, self.n1.eps)

@@ -259,6 +259,17 @@ def embed(tokens, emb, mask, scale, y):
     return y
 
 
+def embed_cat(tokens, emb, mask, scale, extra, y):
+    """y [B, C+E, T]: embedding rows then extra[b] ([B,E], e.g. the language embedding) broadcast over time."""
+    B, T = tokens.shape
+    V, C = emb.shape
+    E = extra.shape[1]
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and y.shape == (B, C + E, T)
+    check(lib().ttsamd_embed_cat(P(y), P(tokens), P(emb), P(mask), ctypes.c_float(scale), P(extra.contiguous().float()), E,
+                                 B, C, T, V, stream_ptr()), "embed_cat")
+    return y
+
+
 def sequence_mask(lengths, t):
     """helpers.py:43-57 on the device; returns float [B, t]."""
     lengths = lengths.to(torch.int64).contiguous()

@@ -19,6 +19,7 @@ from . import _lib
 from .audio import AudioProcessor, mel_renorm_device
 from .gan import GAN
 from .glow_tts import GlowTTS
+from .managers import LanguageManager, SpeakerManager
 from .text import TTSTokenizer
 from .vits import Vits, _get
 
@@ -45,7 +46,8 @@ def setup_tts_model(config):
     ap = AudioProcessor.init_from_config(cfg)
     tok, _ = TTSTokenizer.init_from_config(cfg)
     if isinstance(cfg, dict):
-        cfg = dict(cfg, _ap=ap, _tokenizer=tok)
+        cfg = dict(cfg, _ap=ap, _tokenizer=tok, _speaker_manager=SpeakerManager.init_from_config(cfg),
+                   _language_manager=LanguageManager.init_from_config(cfg))
         if name == "glow_tts" and cfg.get("num_chars") is None:
             cfg["num_chars"] = tok.characters.num_chars
     return _MODELS[name].init_from_config(cfg)
@@ -58,7 +60,20 @@ class Synthesizer:
         if not use_cuda or not torch.cuda.is_available():
             raise _lib.TtsAmdError("tts_amd.Synthesizer needs a GPU (use_cuda=True): there is no CPU path")
         self.use_cuda = True
+        self.tts_speakers_file, self.tts_languages_file = tts_speakers_file, tts_languages_file
+        self.voice_dir = voice_dir
         self.tts_config = load_config(tts_config_path) if isinstance(tts_config_path, str) else tts_config_path
+        if isinstance(self.tts_config, dict) and (tts_speakers_file or tts_languages_file):
+            # what ModelManager._update_paths does to a downloaded config (utils/manage.py:455-500): point the config's
+            # speaker / language files at the ones given here, so the managers built from the config read them
+            self.tts_config = dict(self.tts_config)
+            margs = dict(self.tts_config.get("model_args") or {})
+            look = lambda k: margs.get(k, self.tts_config.get(k))  # noqa: E731
+            if tts_speakers_file:
+                margs["d_vector_file" if look("use_d_vector_file") else "speakers_file"] = tts_speakers_file
+            if tts_languages_file:
+                margs["language_ids_file"] = tts_languages_file
+            self.tts_config["model_args"] = margs
         self.tts_model = setup_tts_model(self.tts_config)
         if tts_checkpoint:
             self.tts_model.load_checkpoint(self.tts_config, tts_checkpoint, eval=True)
@@ -85,8 +100,9 @@ class Synthesizer:
         AudioProcessor.save_wav(np.asarray(wav), path, self.output_sample_rate, pipe_out)
 
     @torch.no_grad()
-    def tts_batch(self, sentences, trim=True):
-        """Synthesize a list of sentences as one padded batch -> list of float32 waveforms (numpy)."""
+    def tts_batch(self, sentences, trim=True, speaker_id=None, d_vector=None, language_id=None):
+        """Synthesize a list of sentences as one padded batch -> list of float32 waveforms (numpy).
+        speaker_id / d_vector [D] / language_id apply to every sentence (synthesis.py:166-215 per sentence)."""
         tok = self.tts_model.tokenizer
         ids = [tok.text_to_ids(s) for s in sentences]
         if any(len(i) == 0 for i in ids):
@@ -98,7 +114,15 @@ class Synthesizer:
         xl = torch.tensor([len(i) for i in ids], dtype=torch.int64)
         dev = self.device
         # ragged_exact: every sentence of the padded batch gets the result of a B=1 run on it (reference semantics)
-        out = self.tts_model.inference(x.to(dev), {"x_lengths": xl.to(dev), "ragged_exact": True})
+        aux = {"x_lengths": xl.to(dev), "ragged_exact": True}
+        if speaker_id is not None:
+            aux["speaker_ids"] = torch.full((len(ids),), int(speaker_id), dtype=torch.int64, device=dev)
+        if d_vector is not None:
+            dv = torch.as_tensor(np.asarray(d_vector), dtype=torch.float32).reshape(1, -1)
+            aux["d_vectors"] = dv.expand(len(ids), -1).contiguous().to(dev)
+        if language_id is not None:
+            aux["language_ids"] = torch.full((len(ids),), int(language_id), dtype=torch.int64, device=dev)
+        out = self.tts_model.inference(x.to(dev), aux)
         frames = out["y_lengths"]
         if self.vocoder_model is None:
             wav = out["model_outputs"]                                        # VITS: [B,1,T_wav]
@@ -139,16 +163,50 @@ class Synthesizer:
 
     def tts(self, text="", speaker_name=None, language_name=None, speaker_wav=None, style_wav=None, style_text=None,
             reference_wav=None, reference_speaker_name=None, split_sentences=True, **kwargs):
-        """synthesizer.py:257-505 for single-speaker models: returns a flat list of samples, sentences separated by
-        10000 zeros (synthesizer.py:441)."""
+        """synthesizer.py:257-505: returns a flat list of samples, sentences separated by 10000 zeros (:441).
+        Multi-speaker (speaker id table or d-vector file) and multilingual requests resolve names through the model's
+        managers with the reference's error behaviour (:301-365); computing a d-vector from `speaker_wav` and
+        voice conversion from `reference_wav` need the speaker-encoder network, which is not built."""
         start = time.time()
         if not text:
             raise ValueError("You need to define either `text` (for sythesis) or a `reference_wav` (for voice conversion) to use the Coqui TTS API.")
-        if speaker_name or language_name or speaker_wav or reference_wav:
-            raise _lib.TtsAmdError("multi-speaker / multi-lingual / voice-conversion requests are not built")
+        if speaker_wav or reference_wav:
+            raise _lib.TtsAmdError("speaker_wav / reference_wav requests need the speaker encoder, which is not built")
         sens = self.split_into_sentences(text) if split_sentences else [text]
+        spk_mgr = getattr(self.tts_model, "speaker_manager", None)
+        speaker_id = d_vector = None
+        if self.tts_speakers_file or hasattr(spk_mgr, "name_to_id"):                       # synthesizer.py:307-330
+            if speaker_name and isinstance(speaker_name, str):
+                if _get(_get(self.tts_config, "model_args", self.tts_config), "use_d_vector_file", False) or \
+                        _get(self.tts_config, "use_d_vector_file", False):
+                    d_vector = np.array(spk_mgr.get_mean_embedding(speaker_name, num_samples=None, randomize=False))[None, :]
+                else:
+                    speaker_id = spk_mgr.name_to_id[speaker_name]
+            elif len(spk_mgr.name_to_id) == 1:
+                speaker_id = list(spk_mgr.name_to_id.values())[0]
+            elif not speaker_name:
+                raise ValueError(" [!] Looks like you are using a multi-speaker model. You need to define either a "
+                                 "`speaker_idx` or a `speaker_wav` to use a multi-speaker model.")
+        elif speaker_name and self.voice_dir is None:                                      # :331-336
+            raise ValueError(" [!] Missing speakers.json file path for selecting speaker %s."
+                             "Define path for speaker.json if it is a multi-speaker model or remove defined speaker idx. "
+                             % speaker_name)
+        lang_mgr = getattr(self.tts_model, "language_manager", None)
+        language_id = None
+        if self.tts_languages_file or lang_mgr is not None:                                # :337-365
+            if len(lang_mgr.name_to_id) == 1:
+                language_id = list(lang_mgr.name_to_id.values())[0]
+            elif language_name and isinstance(language_name, str):
+                try:
+                    language_id = lang_mgr.name_to_id[language_name]
+                except KeyError as e:
+                    raise ValueError(" [!] Looks like you use a multi-lingual model. Language %s is not in the available "
+                                     "languages: %s." % (language_name, lang_mgr.name_to_id.keys())) from e
+            elif not language_name:
+                raise ValueError(" [!] Look like you use a multi-lingual model. You need to define either a "
+                                 "`language_name` or a `style_wav` to use a multi-lingual model.")
         wavs = []
-        for w in self.tts_batch(sens):
+        for w in self.tts_batch(sens, speaker_id=speaker_id, d_vector=d_vector, language_id=language_id):
             wavs.append(w)
             wavs.append(np.zeros(10000, np.float32))
         flat = np.concatenate(wavs)

@@ -158,17 +158,24 @@ def make_vits_state(args=None, seed=1234, with_decoder=True, with_posterior=Fals
     f = _F(seed)
     p = "text_encoder."
     f.sd[p + "emb.weight"] = f.randn(a["num_chars"], h, std=h ** -0.5)
-    _transformer(f, p + "encoder.", h, a["hidden_channels_ffn_text_encoder"], a["num_layers_text_encoder"],
+    # multilingual models: the language embedding rides as extra encoder channels (networks.py:62-63, vits.py:783-803)
+    lng = int(a.get("embedded_language_dim", 4)) if a.get("use_language_embedding", False) else 0
+    he = h + lng
+    _transformer(f, p + "encoder.", he, a["hidden_channels_ffn_text_encoder"], a["num_layers_text_encoder"],
                  a["num_heads_text_encoder"], a["kernel_size_text_encoder"], 4, False)
-    f.conv(p + "proj", 2 * h, h, 1, gain=0.5)
+    f.conv(p + "proj", 2 * h, he, 1, gain=0.5)
+    if lng:
+        f.sd["emb_l.weight"] = f.randn(int(a.get("num_languages", 3)), lng, std=1.0)
     spk = int(a.get("embedded_speaker_dim", 0) or 0)   # speaker_embedding_channels or d_vector_dim (vits.py:729-778)
     if spk and a.get("use_speaker_embedding", False):
         f.sd["emb_g.weight"] = f.randn(int(a.get("num_speakers", 4)), spk, std=0.5)
     p = "duration_predictor."
     if spk:
-        f.conv(p + "cond", 192 if a["use_sdp"] else h, spk, 1, gain=0.5)
+        f.conv(p + "cond", 192 if a["use_sdp"] else he, spk, 1, gain=0.5)
+    if lng:
+        f.conv(p + "cond_lang", 192 if a["use_sdp"] else he, lng, 1, gain=0.5)
     if a["use_sdp"]:
-        f.conv(p + "pre", 192, h, 1)
+        f.conv(p + "pre", 192, he, 1)
         _dds(f, p + "convs.", 192, 3, 3)
         f.conv(p + "proj", 192, 192, 1)
         _flows(f, p + "flows.", 192, 3, 4)
@@ -177,7 +184,7 @@ def make_vits_state(args=None, seed=1234, with_decoder=True, with_posterior=Fals
         f.conv(p + "post_proj", 192, 192, 1)
         _flows(f, p + "post_flows.", 192, 3, 4)
     else:
-        f.conv(p + "conv_1", 256, h, 3)
+        f.conv(p + "conv_1", 256, he, 3)
         f.norm(p + "norm_1", 256, True, 0.1)
         f.conv(p + "conv_2", 256, 256, 3)
         f.norm(p + "norm_2", 256, True, 0.1)

@@ -59,11 +59,16 @@ class Vits:
         self.inference_noise_scale = a.inference_noise_scale
         self.inference_noise_scale_dp = a.inference_noise_scale_dp
         self.max_inference_len = a.max_inference_len
-        if a.use_language_embedding:
-            raise _lib.TtsAmdError("tts_amd.Vits: language embeddings (multi-lingual models) are not built")
+        # init_multilingual (vits.py:783-803).  The reference takes num_languages from the LanguageManager; without one
+        # (checkpoint-only deployment) args.num_languages / the emb_l table in the checkpoint decide.
+        self.embedded_language_dim = 0
+        if a.use_language_embedding and (language_manager or a.num_languages > 0):
+            self.embedded_language_dim = a.embedded_language_dim
+        self.emb_l = None
         # init_multispeaker (vits.py:729-778): learned table or external d-vectors
         self.embedded_speaker_dim = 0
-        if a.use_speaker_embedding and a.num_speakers > 0:
+        num_speakers = speaker_manager.num_speakers if speaker_manager else a.num_speakers      # vits.py:741-745
+        if a.use_speaker_embedding and num_speakers > 0:
             self.embedded_speaker_dim = a.speaker_embedding_channels
         if a.use_d_vector_file:
             if self.embedded_speaker_dim:
@@ -101,7 +106,9 @@ class Vits:
             for u in up:
                 prod *= u
             assert prod == hop, " [!] Product of upsample rates must be equal to the hop length - %d vs %d" % (prod, hop)
-        return Vits(config, ap=_get(config, "_ap", None), tokenizer=_get(config, "_tokenizer", None))
+        return Vits(config, ap=_get(config, "_ap", None), tokenizer=_get(config, "_tokenizer", None),
+                    speaker_manager=_get(config, "_speaker_manager", None),
+                    language_manager=_get(config, "_language_manager", None))
 
     def parameters(self):
         return iter([self.text_encoder.emb] if self.text_encoder is not None else [])
@@ -137,6 +144,11 @@ class Vits:
                                                a.num_heads_text_encoder, a.kernel_size_text_encoder)
         spk = self.embedded_speaker_dim
         self.emb_g = sd["emb_g.weight"].to(dev, torch.float32).contiguous() if (spk and "emb_g.weight" in sd) else None
+        self.emb_l = None
+        if self.embedded_language_dim:
+            if "emb_l.weight" not in sd:
+                raise _lib.TtsAmdError("use_language_embedding is set but the checkpoint has no emb_l.weight")
+            self.emb_l = sd["emb_l.weight"].to(dev, torch.float32).contiguous()
         if a.use_sdp:
             self.duration_predictor = layers.StochasticDurationPredictor(sd, "duration_predictor.", dev, a.hidden_channels,
                                                                          192, 3, 4, cond_channels=spk)
@@ -156,14 +168,16 @@ class Vits:
     def weight_bytes(self):
         return sum(v.numel() * 4 for v in self._sd.values())
 
-    def _front_eager(self, x, x_mask, noise_dp, g_dp):
-        """Text encoder + duration predictor: tokens -> (hidden, prior stats, logw).  g_dp [B,C,1] or an empty tensor."""
-        h, stats = self.text_encoder(x, x_mask)
+    def _front_eager(self, x, x_mask, noise_dp, g_dp, lang):
+        """Text encoder + duration predictor: tokens -> (hidden, prior stats, logw).  g_dp [B,C,1] / lang [B,L,1] or
+        empty tensors."""
         g = g_dp if g_dp.numel() else None
+        lang = lang if lang.numel() else None
+        h, stats = self.text_encoder(x, x_mask, lang=None if lang is None else lang[:, :, 0])
         if self.args.use_sdp:
-            logw = self.duration_predictor(h, x_mask, noise_dp, self.inference_noise_scale_dp, g=g)
+            logw = self.duration_predictor(h, x_mask, noise_dp, self.inference_noise_scale_dp, g=g, lang=lang)
         else:
-            logw = self.duration_predictor(h, x_mask, g=g)
+            logw = self.duration_predictor(h, x_mask, g=g, lang=lang)
         return h, stats, logw.contiguous()
 
     def _speaker_g(self, aux_input, B, dev):
@@ -213,6 +227,19 @@ class Vits:
         return o_hat, mask.unsqueeze(1), (z, z_p, z_hat)
 
     # ---- inference (vits.py:1088-1173) ---------------------------------------------------------------
+    def _language_emb(self, aux_input, B, dev):
+        """vits.py:886-887,1119-1122: lang_emb = emb_l(language_ids).unsqueeze(-1) -> [B, L, 1] or None."""
+        lid = (aux_input or {}).get("language_ids")
+        if lid is None or not self.args.use_language_embedding:
+            return None
+        if self.emb_l is None:
+            raise ValueError("[!] language_ids given to a model without a language embedding table.")
+        lid = torch.as_tensor(lid).to(dev, torch.int64).reshape(-1, 1).contiguous()
+        if lid.shape[0] == 1 and B > 1:
+            lid = lid.expand(B, 1).contiguous()
+        out = torch.empty((lid.shape[0], self.emb_l.shape[1], 1), dtype=torch.float32, device=dev)
+        return ops.embed(lid, self.emb_l, None, 1.0, out)
+
     @torch.no_grad()
     def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None,  # noqa: B006
                                       "language_ids": None, "durations": None}):
@@ -232,6 +259,7 @@ class Vits:
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
         g = self._speaker_g(aux_input, B, dev)
         g_dp = g if a.condition_dp_on_speaker else None
+        lang = self._language_emb(aux_input, B, dev)
         H = a.hidden_channels
         durations = aux_input.get("durations") if aux_input else None
         # the reference skips the duration predictor when durations are injected (vits.py:1124-1143);
@@ -245,9 +273,10 @@ class Vits:
             noise_dp = noise_dp.to(dev, torch.float32).contiguous()
             gd = g_dp if g_dp is not None else torch.empty(0, device=dev)
             self._front.enabled = bool(self.use_graphs) and not (aux_input or {}).get("no_graph", False)
-            h, stats, logw = self._front(x, x_mask, noise_dp, gd, key=float(self.inference_noise_scale_dp))
+            ld = lang if lang is not None else torch.empty(0, device=dev)
+            h, stats, logw = self._front(x, x_mask, noise_dp, gd, ld, key=float(self.inference_noise_scale_dp))
         else:
-            h, stats = self.text_encoder(x, x_mask)
+            h, stats = self.text_encoder(x, x_mask, lang=None if lang is None else lang[:, :, 0])
         if durations is None:
             w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale))
         else:
