@@ -133,6 +133,10 @@ typedef struct ttsamd_conv1d_args {
     int64_t y2_bstride, y2_rstride;
     int32_t split_row;
     const float *row_bias; /* [batch, c_out] per-(b,row) additive term (speaker conditioning), or NULL */
+    const void *w_split;   /* from ttsamd_conv1d_pack_weights_split, or NULL.  Non-NULL selects the split-bf16 kernels:
+                            * both fp32 operands are split three ways into bf16 and the six leading products are
+                            * accumulated in fp32 on the bf16 matrix pipe (every product is more accurate than one
+                            * fp32 rounding of it); NULL = fp32-input MFMA kernels reading w_packed. */
 } ttsamd_conv1d_args;
 
 int ttsamd_conv1d(const ttsamd_conv1d_args *args /* host */, void *stream);
@@ -142,6 +146,11 @@ size_t ttsamd_conv1d_packed_floats(int c_out, int c_in, int kernel);
 /* HOST-side repack (load time): w [c_out, c_in, kernel] row-major (host) -> MFMA fragment order
  * dst (host) = [ceil(c_out/32)][k-step groups][64 lanes][4]; zero padded. */
 int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, int kernel);
+/* Split-bf16 weight image (see ttsamd_conv1d_args.w_split): bytes, and the HOST-side repack
+ * w [c_out, c_in, kernel] fp32 -> [ceil(c_out/32)][ceil(c_in/16)][kernel][3 parts][64 lanes][8 bf16] (+ one zero
+ * group of prefetch slack); part q of a weight = round-to-nearest bf16 of what parts < q left of it. */
+size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kernel);
+int ttsamd_conv1d_pack_weights_split(void *dst, const float *w, int c_out, int c_in, int kernel);
 /* 1 if (kernel, dilation) has a tuned instantiation. */
 int ttsamd_conv1d_supported(int kernel, int dilation);
 

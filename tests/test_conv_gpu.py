@@ -11,6 +11,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+@pytest.fixture(params=["x3", "f32"], autouse=True)
+def conv_precision(request):
+    """Every conv test runs on both arithmetic paths: the split-bf16 kernels (default) and the fp32-input MFMA kernels,
+    at the SAME tolerance."""
+    before = ops.conv_precision()
+    ops.set_conv_precision(request.param)
+    yield request.param
+    ops.set_conv_precision(before)
+
+
 def _rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))

@@ -1,5 +1,5 @@
 // Conv1d dispatcher + host-side weight packing (see conv_kernel.h for the kernel design).
-#include "conv_kernel.h"
+#include "conv_dispatch.h"
 
 #include <cstring>
 
@@ -47,6 +47,63 @@ extern "C" int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out,
                             dst[((mt * ksg + g) * 64 + l) * 4 + s] = w[((long)row * c_in + ci) * kernel + tap];
                     }
                 }
+    return TTSAMD_OK;
+}
+
+// ---- split-bf16 image ---------------------------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+extern "C" size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kernel)
+{
+    if (c_out <= 0 || c_in <= 0 || kernel <= 0) return 0;
+    const size_t mtiles = (size_t)(c_out + 31) / 32;
+    const size_t nchunks = (size_t)(c_in + kConvCK - 1) / kConvCK;
+    return (mtiles * nchunks * kernel + 1) * 3 * 64 * 16;   // + one zero group of prefetch slack
+}
+
+extern "C" int ttsamd_conv1d_pack_weights_split(void *dst_, const float *w, int c_out, int c_in, int kernel)
+{
+    TTSAMD_CHECK_ARG(dst_ && w && c_out > 0 && c_in > 0 && kernel > 0, "conv1d_pack_weights_split: bad args");
+    uint16_t *dst = static_cast<uint16_t *>(dst_);
+    memset(dst, 0, ttsamd_conv1d_packed_split_bytes(c_out, c_in, kernel));
+    const int mtiles = (c_out + 31) / 32;
+    const int nchunks = (c_in + kConvCK - 1) / kConvCK;
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int c = 0; c < nchunks; ++c)
+            for (int tap = 0; tap < kernel; ++tap) {
+                uint16_t *grp = dst + (((size_t)mt * nchunks + c) * kernel + tap) * (3 * 64 * 8);
+                for (int l = 0; l < 64; ++l) {
+                    const int row = mt * 32 + (l & 31);
+                    if (row >= c_out) continue;
+                    for (int i = 0; i < 8; ++i) {
+                        const int ci = c * kConvCK + 8 * (l >> 5) + i;
+                        if (ci >= c_in) continue;
+                        const float v = w[((long)row * c_in + ci) * kernel + tap];
+                        const uint16_t p1 = f32_to_bf16_rne(v);
+                        const float r1 = v - bf16_to_f32(p1);
+                        const uint16_t p2 = f32_to_bf16_rne(r1);
+                        const float r2 = r1 - bf16_to_f32(p2);
+                        const uint16_t p3 = f32_to_bf16_rne(r2);
+                        grp[(0 * 64 + l) * 8 + i] = p1;
+                        grp[(1 * 64 + l) * 8 + i] = p2;
+                        grp[(2 * 64 + l) * 8 + i] = p3;
+                    }
+                }
+            }
     return TTSAMD_OK;
 }
 

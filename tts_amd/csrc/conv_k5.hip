@@ -1,4 +1,4 @@
-#include "conv_kernel.h"
+#include "conv_dispatch.h"
 namespace ttsamd {
 int conv1d_launch_k5(const ttsamd_conv1d_args &a, hipStream_t st) { return conv1d_launch_kd<5, 1>(a, st); }
 }  // namespace ttsamd

@@ -28,6 +28,7 @@ namespace ttsamd {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kConvCK = 16;  // input channels per LDS chunk (8 channel pairs)
+constexpr int kConvOob = 0x7FFFFFF0;  // buffer offset of an invalid lane: the hardware range check drops it
 
 struct ConvTileCfg {
     int mi, ni, wm, wn;
@@ -65,88 +66,12 @@ __device__ __forceinline__ float conv_in_act(float v, int act, float slope)
     return (act == TTSAMD_ACT_LRELU) ? (v > 0.f ? v : v * slope) : v;
 }
 
-template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_mfma_kernel(const ttsamd_conv1d_args a)
+// Accumulator initial value, shared by the fp32-MFMA and the split-bf16 kernels.
+template <int MODE, int MI, int NI, int WM, int WN>
+__device__ __forceinline__ bool conv_acc_init(f32x16 (&acc)[MI][NI], const ttsamd_conv1d_args &a, int b, int t0, int wm, int wn,
+                                              int h, int j)
 {
-    using G = ConvGeom<K, D, MI, NI, WM, WN>;
-    static_assert(((kConvCK / 2) * K) % 4 == 0, "k-steps per chunk must be a multiple of 4");
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][CK][XW]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int h = lane >> 5;   // which channel of the pair / which row group of D
-    const int j = lane & 31;   // column inside a 32-wide N tile
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.x * G::kBN;
-    const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
-    const long ksg_total = (long)nchunks * G::kGroupsPerChunk;  // groups per m-tile
-
-    // ---- global memory goes through buffer resources (SRSRC + 32-bit offsets): one VGPR offset per access, no
-    // 64-bit address arithmetic, and out-of-range lanes are dropped / read as 0 by the hardware range check
-    // (invalid lanes get kOob as their offset).  One resource per (tensor, batch item) slab; slabs are < 2 GiB
-    // (checked on the host).
-    constexpr int kOob = 0x7FFFFFF0;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * a.x_bstride, ((long)(a.c_in - 1) * a.x_rstride + a.t_in) * 4);
-
-    // Staged element i of this thread: row = channel inside the chunk, col = column of the [BN + halo] strip.
-    // Everything but the chunk's channel offset is chunk-independent and computed ONCE: byte offset (kOob when the
-    // column is outside [0, t_in) or the slot is padding) and the input-mask value.
-    int soff[G::kNStage];
-    float smask[G::kNStage];
-#pragma unroll
-    for (int i = 0; i < G::kNStage; ++i) {
-        const int e = tid + i * G::kThreads;
-        const int row = e / G::kXW;
-        const int col = e - row * G::kXW;
-        const int gt = t0 - a.pad_left + col;
-        const bool ok = (e < G::kStageElems) && (gt >= 0) && (gt < a.t_in);
-        soff[i] = ok ? (int)(((long)row * a.x_rstride + gt) * 4) : kOob;
-        smask[i] = 1.f;
-    }
-    if (a.in_mask) {
-        const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.in_mask + (long)b * a.t_in, (long)a.t_in * 4);
-#pragma unroll
-        for (int i = 0; i < G::kNStage; ++i) {
-            const int e = tid + i * G::kThreads;
-            const int col = e - (e / G::kXW) * G::kXW;
-            const int gt = t0 - a.pad_left + col;
-            smask[i] = ld_buf(rm, (gt >= 0 && gt < a.t_in) ? gt * 4 : kOob, 0);
-        }
-    }
-    const int chunk_bytes = kConvCK * (int)a.x_rstride * 4;   // channel offset of one chunk (slab < 2 GiB)
-    float st[G::kNStage];
-    auto stage_load = [&](int chunk) {
-        const int cb = chunk * chunk_bytes;
-#pragma unroll
-        for (int i = 0; i < G::kNStage; ++i)   // channels >= c_in fall outside the slab -> 0
-            st[i] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb, 0);
-    };
-    auto stage_store = [&](float *buf) {
-#pragma unroll
-        for (int i = 0; i < G::kNStage; ++i) {
-            const int e = tid + i * G::kThreads;
-            if (e < G::kStageElems) buf[e] = conv_in_act(st[i] * smask[i], a.in_act, a.in_slope);
-        }
-    };
-
-    // ---- accumulators ----------------------------------------------------------------------
-    f32x16 acc[MI][NI];
-
-    // A fragment stream of this wave: m-tile (blockIdx.y*WM + wm)*MI + mi
-    const float4 *wp[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
-        wp[mi] = reinterpret_cast<const float4 *>(a.w_packed) + (mtile * ksg_total) * 64 + lane;
-    }
-    float4 a_cur[MI], a_nxt[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a_cur[mi] = wp[mi][0];
-
-    stage_load(0);
+    constexpr int kOob = kConvOob;
     // NORMAL mode without an output activation: the residual operand is folded into the
     // accumulators' INITIAL value (D = A.B + C with C = res).  Their HBM latency then overlaps the
     // prologue's weight / activation fetches instead of being exposed after the main loop, at zero register cost
@@ -180,58 +105,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     }
 
-    // materialise the accumulators in AGPRs here: the residual loads' temporaries must not stay live in the loop
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+a"(acc[mi][ni]));
-    stage_store(xs);
-    __syncthreads();
+    return folded;
+}
 
-    const int bcol = h * G::kXW + wn * (32 * NI) + j;  // base LDS index of this lane's B reads
-    for (int c = 0; c < nchunks; ++c) {
-        const float *cur = xs + (c & 1) * G::kStageElems;
-        if (c + 1 < nchunks) stage_load(c + 1);
-        const float *bbase = cur + bcol;
-        constexpr int kSteps = G::kGroupsPerChunk * 4;
-        // B fragments are register double-buffered one k-step ahead of the MFMAs that use them.
-        float bf[2][NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[0][ni] = bbase[ni * 32];
-#pragma unroll
-        for (int gl = 0; gl < G::kGroupsPerChunk; ++gl) {
-            const long g = (long)c * G::kGroupsPerChunk + gl;
-            // prefetch the next group's A fragments (the packed image has one zero group of slack)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a_nxt[mi] = wp[mi][(g + 1) * 64];
-            // pin the prefetch a full group (4 k-steps of MFMAs) ahead of its first use; hipcc
-            // otherwise sinks the loads down to their consumer and exposes the L2 latency.
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ks = gl * 4 + s;       // compile-time after unrolling
-                if (ks + 1 < kSteps) {
-                    const int p1 = (ks + 1) / K;
-                    const int tap1 = (ks + 1) - p1 * K;
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        bf[(ks + 1) & 1][ni] = bbase[(2 * p1) * G::kXW + ni * 32 + tap1 * D];
-                }
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float av = (s == 0) ? a_cur[mi].x : (s == 1) ? a_cur[mi].y : (s == 2) ? a_cur[mi].z : a_cur[mi].w;
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[ks & 1][ni], acc[mi][ni], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a_cur[mi] = a_nxt[mi];
-        }
-        if (c + 1 < nchunks) stage_store(xs + ((c + 1) & 1) * G::kStageElems);
-        __syncthreads();
-    }
-
+// Fused epilogue (bias, activation, residual, MRF accumulate, masks, gate, couplings, polyphase shuffle), shared by the
+// fp32-MFMA and the split-bf16 kernels: the 32x32 accumulator layout of every gfx950 MFMA is the same.
+template <int MODE, int MI, int NI, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int t0, int wm, int wn, int h, int j, bool folded)
+{
+    constexpr int kOob = kConvOob;
     // ---- epilogue --------------------------------------------------------------------------
     // MODE is a template parameter (each fusion gets its own lean kernel), and the epilogue-only
     // arguments are read from the kernarg segment HERE, behind an opaque barrier, so that they do
@@ -392,6 +274,144 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
 }
 
 template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_mfma_kernel(const ttsamd_conv1d_args a)
+{
+    using G = ConvGeom<K, D, MI, NI, WM, WN>;
+    static_assert(((kConvCK / 2) * K) % 4 == 0, "k-steps per chunk must be a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][CK][XW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int h = lane >> 5;   // which channel of the pair / which row group of D
+    const int j = lane & 31;   // column inside a 32-wide N tile
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * G::kBN;
+    const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
+    const long ksg_total = (long)nchunks * G::kGroupsPerChunk;  // groups per m-tile
+
+    // ---- global memory goes through buffer resources (SRSRC + 32-bit offsets): one VGPR offset per access, no
+    // 64-bit address arithmetic, and out-of-range lanes are dropped / read as 0 by the hardware range check
+    // (invalid lanes get kOob as their offset).  One resource per (tensor, batch item) slab; slabs are < 2 GiB
+    // (checked on the host).
+    constexpr int kOob = kConvOob;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * a.x_bstride, ((long)(a.c_in - 1) * a.x_rstride + a.t_in) * 4);
+
+    // Staged element i of this thread: row = channel inside the chunk, col = column of the [BN + halo] strip.
+    // Everything but the chunk's channel offset is chunk-independent and computed ONCE: byte offset (kOob when the
+    // column is outside [0, t_in) or the slot is padding) and the input-mask value.
+    int soff[G::kNStage];
+    float smask[G::kNStage];
+#pragma unroll
+    for (int i = 0; i < G::kNStage; ++i) {
+        const int e = tid + i * G::kThreads;
+        const int row = e / G::kXW;
+        const int col = e - row * G::kXW;
+        const int gt = t0 - a.pad_left + col;
+        const bool ok = (e < G::kStageElems) && (gt >= 0) && (gt < a.t_in);
+        soff[i] = ok ? (int)(((long)row * a.x_rstride + gt) * 4) : kOob;
+        smask[i] = 1.f;
+    }
+    if (a.in_mask) {
+        const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.in_mask + (long)b * a.t_in, (long)a.t_in * 4);
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) {
+            const int e = tid + i * G::kThreads;
+            const int col = e - (e / G::kXW) * G::kXW;
+            const int gt = t0 - a.pad_left + col;
+            smask[i] = ld_buf(rm, (gt >= 0 && gt < a.t_in) ? gt * 4 : kOob, 0);
+        }
+    }
+    const int chunk_bytes = kConvCK * (int)a.x_rstride * 4;   // channel offset of one chunk (slab < 2 GiB)
+    float st[G::kNStage];
+    auto stage_load = [&](int chunk) {
+        const int cb = chunk * chunk_bytes;
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i)   // channels >= c_in fall outside the slab -> 0
+            st[i] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb, 0);
+    };
+    auto stage_store = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) {
+            const int e = tid + i * G::kThreads;
+            if (e < G::kStageElems) buf[e] = conv_in_act(st[i] * smask[i], a.in_act, a.in_slope);
+        }
+    };
+
+    // ---- accumulators ----------------------------------------------------------------------
+    f32x16 acc[MI][NI];
+
+    // A fragment stream of this wave: m-tile (blockIdx.y*WM + wm)*MI + mi
+    const float4 *wp[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+        wp[mi] = reinterpret_cast<const float4 *>(a.w_packed) + (mtile * ksg_total) * 64 + lane;
+    }
+    float4 a_cur[MI], a_nxt[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a_cur[mi] = wp[mi][0];
+
+    stage_load(0);
+    const bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, t0, wm, wn, h, j);
+    // materialise the accumulators in AGPRs here: the residual loads' temporaries must not stay live in the loop
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+a"(acc[mi][ni]));
+    stage_store(xs);
+    __syncthreads();
+
+    const int bcol = h * G::kXW + wn * (32 * NI) + j;  // base LDS index of this lane's B reads
+    for (int c = 0; c < nchunks; ++c) {
+        const float *cur = xs + (c & 1) * G::kStageElems;
+        if (c + 1 < nchunks) stage_load(c + 1);
+        const float *bbase = cur + bcol;
+        constexpr int kSteps = G::kGroupsPerChunk * 4;
+        // B fragments are register double-buffered one k-step ahead of the MFMAs that use them.
+        float bf[2][NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[0][ni] = bbase[ni * 32];
+#pragma unroll
+        for (int gl = 0; gl < G::kGroupsPerChunk; ++gl) {
+            const long g = (long)c * G::kGroupsPerChunk + gl;
+            // prefetch the next group's A fragments (the packed image has one zero group of slack)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a_nxt[mi] = wp[mi][(g + 1) * 64];
+            // pin the prefetch a full group (4 k-steps of MFMAs) ahead of its first use; hipcc
+            // otherwise sinks the loads down to their consumer and exposes the L2 latency.
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ks = gl * 4 + s;       // compile-time after unrolling
+                if (ks + 1 < kSteps) {
+                    const int p1 = (ks + 1) / K;
+                    const int tap1 = (ks + 1) - p1 * K;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        bf[(ks + 1) & 1][ni] = bbase[(2 * p1) * G::kXW + ni * 32 + tap1 * D];
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float av = (s == 0) ? a_cur[mi].x : (s == 1) ? a_cur[mi].y : (s == 2) ? a_cur[mi].z : a_cur[mi].w;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a_cur[mi] = a_nxt[mi];
+        }
+        if (c + 1 < nchunks) stage_store(xs + ((c + 1) & 1) * G::kStageElems);
+        __syncthreads();
+    }
+
+    conv_epilogue<MODE, MI, NI, WM, WN>(acc, b, t0, wm, wn, h, j, folded);
+}
+
+template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
 int conv1d_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     using G = ConvGeom<K, D, MI, NI, WM, WN>;
@@ -423,48 +443,5 @@ int conv1d_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
         return conv1d_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
     }
 }
-
-inline int conv1d_mode_unsupported(const ttsamd_conv1d_args &a)
-{
-    set_error("conv1d: mode %d has no instantiation for kernel=%d dilation=%d", a.mode, a.kernel, a.dilation);
-    return TTSAMD_ERR_UNSUPPORTED;
-}
-
-// Fused epilogues exist where the models use them: GATE on the WaveNet in_layers (k=3/5, d=1), SHUFFLE on the
-// polyphase transposed conv (k=2), COUPLE / RES_SKIP / COUPLE_AFFINE on 1x1 convs.
-template <int K, int D>
-int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
-{
-    switch (a.mode) {
-        case TTSAMD_CONV_NORMAL: return conv1d_launch_tiles<K, D, TTSAMD_CONV_NORMAL>(a, st);
-        case TTSAMD_CONV_GATE:
-            if constexpr ((K == 3 || K == 5) && D == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_GATE>(a, st);
-            break;
-        case TTSAMD_CONV_SHUFFLE:
-            if constexpr (K == 2) return conv1d_launch_tiles<K, D, TTSAMD_CONV_SHUFFLE>(a, st);
-            break;
-        case TTSAMD_CONV_COUPLE:
-            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_COUPLE>(a, st);
-            break;
-        case TTSAMD_CONV_RES_SKIP:
-            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_RES_SKIP>(a, st);
-            break;
-        case TTSAMD_CONV_COUPLE_AFFINE:
-            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_COUPLE_AFFINE>(a, st);
-            break;
-        case TTSAMD_CONV_COUPLE_AFFINE_FWD:
-            if constexpr (K == 1) return conv1d_launch_tiles<K, D, TTSAMD_CONV_COUPLE_AFFINE_FWD>(a, st);
-            break;
-    }
-    return conv1d_mode_unsupported(a);
-}
-
-// one translation unit per kernel size (conv_k*.hip) so hipcc compiles them in parallel
-int conv1d_launch_k1(const ttsamd_conv1d_args &a, hipStream_t st);
-int conv1d_launch_k2(const ttsamd_conv1d_args &a, hipStream_t st);
-int conv1d_launch_k3(const ttsamd_conv1d_args &a, hipStream_t st);
-int conv1d_launch_k5(const ttsamd_conv1d_args &a, hipStream_t st);
-int conv1d_launch_k7(const ttsamd_conv1d_args &a, hipStream_t st);
-int conv1d_launch_k11(const ttsamd_conv1d_args &a, hipStream_t st);
 
 }  // namespace ttsamd

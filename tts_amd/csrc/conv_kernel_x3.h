@@ -1,0 +1,226 @@
+// Conv1d as implicit GEMM on the bf16 MFMA of gfx950 (v_mfma_f32_32x32x16_bf16) with BOTH fp32 operands split three
+// ways into bf16 (x = x1 + x2 + x3, each part the round-to-nearest bf16 of what is left) and the six products whose
+// magnitude is >= 2^-16 |w x| accumulated in fp32:
+//
+//     w x  ~=  w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1)
+//
+// The three dropped products sum to < 2^-26 |w x|, and w1+w2+w3 / x1+x2+x3 reproduce the fp32 values to < 2^-27
+// relative — i.e. every product is MORE accurate than one fp32 rounding of it (2^-24), and accumulation is fp32 as in
+// the fp32-input MFMA path (conv_kernel.h).  Same arithmetic class, same parity tolerances, but the bf16 matrix pipe
+// runs 16x the fp32-input rate, so six of its instructions cost 6/16 of the one they replace.
+//
+//   * A (weights): split and packed at load time as [m-tile][chunk][tap][part][64 lanes][8 bf16]: one 16-byte load per
+//     lane per (tap, part) straight from L2, prefetched one tap ahead.  Lane l holds row l%32, channels 8*(l/32)..+7.
+//   * B (activations): staged per 16-channel chunk; a thread owns (column, 8-channel half): 8 coalesced fp32 loads,
+//     activation / mask, split, three ds_write_b128 into [part][column][16 ch] bf16.  A fragment is then ONE
+//     ds_read_b128 (lane -> column, half-wave -> 8 channels): 32 consecutive 32-byte rows per half-wave, conflict free,
+//     and tap / dilation are immediates on the column index.
+//   * one MFMA K-step = 16 channels of one tap; any kernel size works (no pairing constraint).
+//   * accumulators, residual folding and the fused epilogues are the fp32 path's (conv_acc_init / conv_epilogue).
+#pragma once
+#include "conv_kernel.h"
+
+namespace ttsamd {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int K, int D, int MI, int NI, int WM, int WN>
+struct ConvGeomX3 {
+    static constexpr int kThreads = 64 * WM * WN;
+    static constexpr int kBM = 32 * MI * WM;
+    static constexpr int kBN = 32 * NI * WN;
+    static constexpr int kHalo = (K - 1) * D;
+    static constexpr int kXW = kBN + kHalo;                  // staged columns
+    static constexpr int kPartBytes = kXW * 32;              // [column][16 ch] bf16
+    static constexpr int kBufBytes = 3 * kPartBytes;
+    static constexpr int kItems = 2 * kXW;                   // (column, 8-channel half) work items per chunk
+    static constexpr int kNStage = (kItems + kThreads - 1) / kThreads;
+    static constexpr size_t kLdsBytes = (size_t)2 * kBufBytes;
+    static constexpr int kOcc = (MI * NI >= 8) ? 1 : 2;
+};
+
+__device__ __forceinline__ void conv_split3(float x, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    const __bf16 a1 = (__bf16)x;                 // v_cvt_pk_bf16_f32: round to nearest even
+    const float r1 = x - (float)a1;              // exact
+    const __bf16 a2 = (__bf16)r1;
+    const float r2 = r1 - (float)a2;             // exact
+    const __bf16 a3 = (__bf16)r2;
+    p1 = __builtin_bit_cast(unsigned short, a1);
+    p2 = __builtin_bit_cast(unsigned short, a2);
+    p3 = __builtin_bit_cast(unsigned short, a3);
+}
+
+template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kOcc)) void conv1d_x3_kernel(const ttsamd_conv1d_args a)
+{
+    using G = ConvGeomX3<K, D, MI, NI, WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs3[];  // [2][3 parts][XW][16 ch] bf16
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int h = lane >> 5;   // 8-channel half of the K-step / row group of D
+    const int j = lane & 31;   // column inside a 32-wide N tile
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * G::kBN;
+    const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
+
+    constexpr int kOob = kConvOob;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * a.x_bstride, ((long)(a.c_in - 1) * a.x_rstride + a.t_in) * 4);
+
+    // staged item i of this thread: (column, half); offset of its first channel inside a chunk, kOob when the column is
+    // outside [0, t_in) or the slot is padding; channels >= c_in fall outside the slab and read as 0
+    int soff[G::kNStage];
+    float smask[G::kNStage];
+#pragma unroll
+    for (int i = 0; i < G::kNStage; ++i) {
+        const int e = tid + i * G::kThreads;
+        const int half = e / G::kXW;
+        const int col = e - half * G::kXW;
+        const int gt = t0 - a.pad_left + col;
+        const bool ok = (e < G::kItems) && (gt >= 0) && (gt < a.t_in);
+        soff[i] = ok ? (int)(((long)(half * 8) * a.x_rstride + gt) * 4) : kOob;
+        smask[i] = 1.f;
+    }
+    if (a.in_mask) {
+        const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.in_mask + (long)b * a.t_in, (long)a.t_in * 4);
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) {
+            const int e = tid + i * G::kThreads;
+            const int col = e - (e / G::kXW) * G::kXW;
+            const int gt = t0 - a.pad_left + col;
+            smask[i] = ld_buf(rm, (gt >= 0 && gt < a.t_in) ? gt * 4 : kOob, 0);
+        }
+    }
+    const int row_bytes = (int)a.x_rstride * 4;
+    float st[G::kNStage][8];
+    auto stage_load = [&](int chunk) {
+        const int cb = chunk * kConvCK * row_bytes;
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) st[i][c] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb + c * row_bytes, 0);
+    };
+    auto stage_store = [&](unsigned char *buf) {
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) {
+            const int e = tid + i * G::kThreads;
+            const int half = e / G::kXW;
+            const int col = e - half * G::kXW;
+            if (e < G::kItems) {
+                unsigned p[3][8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    conv_split3(conv_in_act(st[i][c] * smask[i], a.in_act, a.in_slope), p[0][c], p[1][c], p[2][c]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    u32x4 w;
+                    w.x = p[q][0] | (p[q][1] << 16);
+                    w.y = p[q][2] | (p[q][3] << 16);
+                    w.z = p[q][4] | (p[q][5] << 16);
+                    w.w = p[q][6] | (p[q][7] << 16);
+                    *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + col * 32 + half * 16) = w;
+                }
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+
+    // A stream of this wave: m-tile (blockIdx.y*WM + wm)*MI + mi, [chunk][tap][part][64 lanes] x 16 bytes
+    const u32x4 *wp[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+        wp[mi] = reinterpret_cast<const u32x4 *>(a.w_split) + mtile * ((long)nchunks * K * 3 * 64) + lane;
+    }
+    u32x4 a_cur[MI][3], a_nxt[MI][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp[mi][q * 64];
+
+    stage_load(0);
+    const bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, t0, wm, wn, h, j);
+    stage_store(xs3);
+    __syncthreads();
+
+    const int bbyte = (wn * (32 * NI) + j) * 32 + h * 16;   // this lane's fragment inside a part, tap 0, ni 0
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned char *cur = xs3 + (c & 1) * G::kBufBytes + bbyte;
+        if (c + 1 < nchunks) stage_load(c + 1);
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap) {
+            // next tap's weights (the packed image ends with one group of slack)
+            const long g = ((long)c * K + tap + 1) * (3 * 64);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a_nxt[mi][q] = wp[mi][g + q * 64];
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                u32x4 bq[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * 32);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    constexpr int pa[6] = {2, 1, 0, 1, 0, 0};   // smallest products first
+                    constexpr int pb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[mi][pa[t]]),
+                                                                              __builtin_bit_cast(bf16x8, bq[pb[t]]),
+                                                                              acc[mi][ni], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a_cur[mi][q] = a_nxt[mi][q];
+        }
+        if (c + 1 < nchunks) stage_store(xs3 + ((c + 1) & 1) * G::kBufBytes);
+        __syncthreads();
+    }
+
+    conv_epilogue<MODE, MI, NI, WM, WN>(acc, b, t0, wm, wn, h, j, folded);
+}
+
+template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
+int conv1d_x3_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
+{
+    using G = ConvGeomX3<K, D, MI, NI, WM, WN>;
+    auto kern = conv1d_x3_kernel<K, D, MI, NI, WM, WN, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLdsBytes));
+        attr_set = true;
+    }
+    const int mtiles = (a.c_out + 31) / 32;
+    const int mblocks = (mtiles + MI * WM - 1) / (MI * WM);
+    const int nblocks = (a.t_out + G::kBN - 1) / G::kBN;
+    hipLaunchKernelGGL(kern, dim3(nblocks, mblocks, a.batch), dim3(G::kThreads), G::kLdsBytes, st, a);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+template <int K, int D, int MODE>
+int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
+{
+    const int mtiles = (a.c_out + 31) / 32;
+    if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
+    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
+        return conv1d_x3_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
+    } else {
+        if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
+        return conv1d_x3_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
+    }
+}
+
+}  // namespace ttsamd

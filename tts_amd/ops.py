@@ -5,6 +5,7 @@ the HIP kernels of libtts_amd.so.  Weight preparation (weight-norm fold, polypha
 re-ordering, MFMA fragment packing) runs once at load time.
 """
 import ctypes
+import os
 
 import torch
 
@@ -33,7 +34,7 @@ class Conv1dArgs(ctypes.Structure):
         ("out_mask", ctypes.c_void_p), ("out_div", ctypes.c_float),
         ("shuffle_u", ctypes.c_int32), ("shuffle_pad", ctypes.c_int32), ("shuffle_t_out", ctypes.c_int32),
         ("y2", ctypes.c_void_p), ("y2_bstride", ctypes.c_int64), ("y2_rstride", ctypes.c_int64),
-        ("split_row", ctypes.c_int32), ("row_bias", ctypes.c_void_p),
+        ("split_row", ctypes.c_int32), ("row_bias", ctypes.c_void_p), ("w_split", ctypes.c_void_p),
     ]
 
 
@@ -70,8 +71,25 @@ def set_conv_timer(timer):
     _TIMER = timer
 
 
+# Conv arithmetic: "x3" = split-bf16 kernels (3-way bf16 split of both fp32 operands, six products, fp32 accumulate:
+# fp32-class accuracy on the bf16 matrix pipe), "f32" = fp32-input MFMA kernels.  TTSAMD_CONV_PRECISION overrides.
+_PRECISION = os.environ.get("TTSAMD_CONV_PRECISION", "x3")
+
+
+def set_conv_precision(p):
+    global _PRECISION
+    if p not in ("x3", "f32"):
+        raise ValueError("conv precision must be 'x3' or 'f32'")
+    _PRECISION = p
+
+
+def conv_precision():
+    return _PRECISION
+
+
 class PackedConv:
-    """A conv layer's weights in MFMA fragment order on the device (+ bias in packed-row order)."""
+    """A conv layer's weights in MFMA fragment order on the device (+ bias in packed-row order): the fp32 image and
+    the split-bf16 image."""
 
     def __init__(self, w: torch.Tensor, bias, device, dilation=1, pad_left=None):
         w = w.detach().to("cpu", torch.float32).contiguous()
@@ -87,6 +105,12 @@ class PackedConv:
         check(L.ttsamd_conv1d_pack_weights(ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(w.data_ptr()),
                                            self.c_out, self.c_in, self.kernel), "conv1d_pack_weights")
         self.w = packed.to(device)
+        L.ttsamd_conv1d_packed_split_bytes.restype = ctypes.c_size_t
+        nb = L.ttsamd_conv1d_packed_split_bytes(self.c_out, self.c_in, self.kernel)
+        split = torch.empty(nb, dtype=torch.uint8)
+        check(L.ttsamd_conv1d_pack_weights_split(ctypes.c_void_p(split.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                                 self.c_out, self.c_in, self.kernel), "conv1d_pack_weights_split")
+        self.w_split = split.to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
 
     def nbytes(self):
@@ -125,6 +149,7 @@ def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, 
     if y2 is not None:
         a.y2, a.y2_bstride, a.y2_rstride = y2.data_ptr(), y2.shape[1] * y2.shape[2], y2.shape[2]
     a.split_row, a.row_bias = split_row, _dp(row_bias)
+    a.w_split = pc.w_split.data_ptr() if _PRECISION == "x3" else None
     if _TIMER is not None:
         key = _TIMER.select(pc, a)
         if key is not None:
