@@ -31,6 +31,21 @@ if ROOT not in sys.path:
 
 SAMPLE_RATE = 22050
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
+X3_PRODUCTS = 6                 # bf16 MFMA products issued per fp32 product by the split-bf16 kernels (conv_kernel_x3.h)
+DTYPE = {"x3": "f32 (conv products: both fp32 operands split 3-way into bf16, 6 products on the bf16 MFMA, fp32 "
+               "accumulate; fp32-class accuracy, same parity tolerances as --precision f32)",
+         "f32": "f32"}
+
+
+def conv_peak(precision):
+    """Peak the conv kernels are priced against, in ALGORITHMIC (fp32-equivalent) TFLOP/s: the split-bf16 kernels issue
+    six bf16 MFMA products per fp32 product, so their ceiling is the bf16 dense peak / 6."""
+    return PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if precision == "x3" else PEAK_FP32_MFMA_TFLOPS
+
+
+def conv_kernel_name(precision, tmpl):
+    return ("ttsamd::conv1d_x3_kernel<%s>" if precision == "x3" else "ttsamd::conv1d_mfma_kernel<%s>") % tmpl
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -118,12 +133,12 @@ def bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel):
             "metric": "audio samples/sec (HiFiGAN-v1 vocoder only, 80-bin mels -> 22.05 kHz waveform)", "value": value,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": float(tt.item()) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_x": value / SAMPLE_RATE,
+            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic", "rtf_x": value / SAMPLE_RATE,
             "config": {"workload": "configs[2]: HiFiGAN-v1 vocoder only, batch=%d x %d-frame mels per GPU, slabbed"
                                    % (args.items, args.frames), "parallelism": "replicas x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "all conv1d_mfma_kernel launches of the generator",
-                         "achieved": r["flops"] / (r["ms"] * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": r["flops"] / (r["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "all conv launches of the generator (%s)" % conv_kernel_name(args.precision, "..."),
+                         "achieved": r["flops"] / (r["ms"] * 1e-3) / 1e12, "peak": conv_peak(args.precision),
+                         "unit": "TFLOP/s", "frac": r["flops"] / (r["ms"] * 1e-3) / 1e12 / conv_peak(args.precision),
                          "traffic": None, "algorithmic_gbps": r["bytes"] / (r["ms"] * 1e-3) / 1e9,
                          "launches_timed": r["launches"]}}), flush=True)
     if world > 1:
@@ -288,6 +303,9 @@ def main():
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the MRF resblock branches on one stream (for rocprof: per-kernel durations are then not "
                          "inflated by co-running kernels; the roofline pass always runs this way)")
+    ap.add_argument("--precision", default=None, choices=["x3", "f32"],
+                    help="conv arithmetic: x3 = split-bf16 kernels (default, fp32-class accuracy on the bf16 MFMA), "
+                         "f32 = fp32-input MFMA kernels (bitwise fmaf chain)")
     ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1", "mas", "xtts_stream"],
                     help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
@@ -310,6 +328,10 @@ def main():
     from tts_amd import synthetic as W         # seeded synthetic checkpoint (no network => no released weights)
     from tts_amd import ops, parallel
     from tts_amd.vits import Vits
+
+    if args.precision is None:
+        args.precision = ops.conv_precision()
+    ops.set_conv_precision(args.precision)
 
     if args.workload == "hifigan_v1":
         return bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel)
@@ -395,7 +417,7 @@ def main():
                 allc[k] += r[k]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["launches"] else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant_%s.json" % args.precision)
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
@@ -406,7 +428,7 @@ def main():
             "metric": "audio samples/sec (LJSpeech VITS -> HiFiGAN decoder, 22.05 kHz, end-to-end inference)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "rtf_x": value / SAMPLE_RATE, "rtf_x_per_gpu": value / SAMPLE_RATE / world,
             "config": {"workload": "configs[1]: LJSpeech VITS end-to-end, batch=%d random %d-char utterances per GPU "
                                    "(257 ids, 770 frames, 197120 samples each), 22.05 kHz" % (args.batch, args.chars),
@@ -414,9 +436,14 @@ def main():
                        "weights": "random-init VitsArgs defaults (29.1 M params), broadcast from rank 0 in %.3f s" % bcast_s,
                        "mrf_branch_streams": 1 if args.serial_branches else 3},
             "roofline": {
-                "bound": "mfma", "kernel": "ttsamd::conv1d_mfma_kernel<11,1,2,2,2,2,0> (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
-                "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                "bound": "mfma",
+                "kernel": conv_kernel_name(args.precision, "11,1,2,2,2,2,0") + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
+                "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
+                "frac": ach / conv_peak(args.precision), "traffic": traffic,
+                "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B per launch) / launch time; peak = bf16 dense "
+                              "MFMA peak 2500 TF / 6 bf16 products per fp32 product; on the matrix pipe itself: %.0f of "
+                              "2500 bf16 TFLOP/s" % (ach * X3_PRODUCTS)) if args.precision == "x3" else
+                             "fp32-input MFMA peak (= fp32 vector peak); exact fp32 arithmetic",
                 "launches_timed": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
                 "algorithmic_gbps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["launches"] else 0.0,
                 "all_conv_launches": {"launches": allc["launches"],

@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
 agg = collections.OrderedDict()
 for r in rows:
-    nm = re.sub(r"void ttsamd::conv1d_mfma_kernel<(.*?)>.*", r"conv<\1>", r['Kernel_Name'])
+    nm = re.sub(r"void ttsamd::conv1d_(mfma|x3)_kernel<(.*?)>.*", r"conv_\1<\2>", r['Kernel_Name'])
     nm = re.sub(r"\(.*", "", nm)[:42]
     key = (nm, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), int(r['Grid_Size_Y']), int(r['Grid_Size_Z']))
     a = agg.setdefault(key, [0, 0.0])
