@@ -63,6 +63,50 @@ def test_conv1d_epilogue_res_accum_mask_div(gpu):
     assert _rel(y, want) < TOL
 
 
+# Launches with more tiles than resident blocks: the persistent kernel walks several tiles per block and runs the previous
+# tile's epilogue inside the next tile's main loop (conv_kernel_x3p.h).  (B, Cin, Cout, K, D, T, res, accum, mask)
+MULTI_TILE = [
+    (4, 32, 32, 3, 1, 100003, True, False, False), (3, 32, 32, 11, 5, 150000, False, True, False),
+    (4, 64, 64, 7, 3, 40001, True, True, True), (4, 128, 128, 3, 1, 20011, True, False, False),
+    (5, 16, 128, 3, 1, 16500, True, True, False), (2, 256, 256, 3, 1, 17000, True, False, True),
+    (3, 48, 64, 1, 1, 50000, True, False, False), (6, 128, 128, 11, 1, 12000, False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", MULTI_TILE)
+def test_conv1d_multi_tile_pipeline(gpu, case, conv_precision):
+    B, Cin, Cout, K, D, T, has_res, has_acc, has_mask = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / np.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, T, generator=g) if has_res else None
+    acc = torch.randn(B, Cout, T, generator=g) if has_acc else None
+    lens = torch.tensor([T - 37 * i for i in range(B)])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float() if has_mask else None
+    xin = x * mask[:, None] if has_mask else x
+    want = F.conv1d(F.leaky_relu(xin, 0.1), w, b, padding=(K - 1) * D // 2, dilation=D)
+    if has_res:
+        want = want + res
+    if has_acc:
+        want = acc + want
+    if has_mask:
+        want = want * mask[:, None]
+    pc = ops.PackedConv(w, b, gpu, dilation=D)
+    dev = lambda t: None if t is None else t.to(gpu)
+    outs = []
+    for pipe in (2, 0):
+        was = ops.set_conv_pipeline(pipe)
+        y = torch.full((B, Cout, T), float("nan"), device=gpu)
+        ops.conv1d(pc, x.to(gpu), y, in_act=ops.ACT_LRELU, in_slope=0.1, res=dev(res), accum=dev(acc), in_mask=dev(mask),
+                   out_mask=dev(mask))
+        ops.set_conv_pipeline(was)
+        assert _rel(y, want) < TOL, "pipeline=%s" % pipe
+        outs.append(y)
+    # the two kernels differ only in where the bias / residual enter the fp32 sum
+    assert _rel(outs[0], outs[1]) < 1e-6
+
+
 @pytest.mark.parametrize("case", [(2, 64, 32, 8, 50), (1, 128, 64, 2, 301), (2, 32, 16, 2, 64), (1, 512, 256, 8, 20)])
 def test_conv_transpose_polyphase(gpu, case):
     B, Cin, Cout, u, T = case

@@ -61,6 +61,30 @@ __device__ __forceinline__ void st_buf(__amdgpu_buffer_rsrc_t r, float v, int vo
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voffset, soffset, 0);
 }
 
+// Block -> tile assignment.  The hardware deals workgroups to the 8 XCDs round-robin by linear id (x fastest), each XCD
+// with its own 4 MiB L2.  With the plain (x = time tile, y = m-block, z = item) order every L2 sees every m-block's
+// weight stream (4.3 MB for a 256x256 k=11 layer: it thrashes, PMC: 1.7 GB fetched per launch against 0.5 GB of
+// activations) and neighbouring time tiles — which share their halo columns — sit in different L2s.  Remapped: XCD c
+// works on m-block c % mblocks only and walks a contiguous range of (item, time tile) pairs.
+struct ConvTile {
+    int nb, mb, b;   // time tile, m-block, batch item
+};
+__device__ __forceinline__ ConvTile conv_tile_of_block()
+{
+    ConvTile t{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const unsigned total = gx * gy * gz;
+    if ((total & 7u) == 0 && (gy == 1 || gy == 2 || gy == 4 || gy == 8)) {
+        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned xcd = lin & 7u, i = lin >> 3, cnt = total >> 3;
+        t.mb = (int)(xcd % gy);
+        const unsigned u = (xcd / gy) * cnt + i;     // index among the (item, time tile) pairs of this m-block
+        t.b = (int)(u / gx);
+        t.nb = (int)(u - (unsigned)t.b * gx);
+    }
+    return t;
+}
+
 __device__ __forceinline__ float conv_in_act(float v, int act, float slope)
 {
     return (act == TTSAMD_ACT_LRELU) ? (v > 0.f ? v : v * slope) : v;
@@ -68,8 +92,8 @@ __device__ __forceinline__ float conv_in_act(float v, int act, float slope)
 
 // Accumulator initial value, shared by the fp32-MFMA and the split-bf16 kernels.
 template <int MODE, int MI, int NI, int WM, int WN>
-__device__ __forceinline__ bool conv_acc_init(f32x16 (&acc)[MI][NI], const ttsamd_conv1d_args &a, int b, int t0, int wm, int wn,
-                                              int h, int j)
+__device__ __forceinline__ bool conv_acc_init(f32x16 (&acc)[MI][NI], const ttsamd_conv1d_args &a, int b, int mb, int t0, int wm,
+                                              int wn, int h, int j)
 {
     constexpr int kOob = kConvOob;
     // NORMAL mode without an output activation: the residual operand is folded into the
@@ -83,7 +107,7 @@ __device__ __forceinline__ bool conv_acc_init(f32x16 (&acc)[MI][NI], const ttsam
                                                     ((long)(a.c_out - 1) * a.res_rstride + a.t_out) * 4);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int row0 = (((int)blockIdx.y * WM + wm) * MI + mi) * 32;
+            const int row0 = ((mb * WM + wm) * MI + mi) * 32;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int t = t0 + wn * (32 * NI) + ni * 32 + j;
@@ -111,7 +135,7 @@ __device__ __forceinline__ bool conv_acc_init(f32x16 (&acc)[MI][NI], const ttsam
 // Fused epilogue (bias, activation, residual, MRF accumulate, masks, gate, couplings, polyphase shuffle), shared by the
 // fp32-MFMA and the split-bf16 kernels: the 32x32 accumulator layout of every gfx950 MFMA is the same.
 template <int MODE, int MI, int NI, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int t0, int wm, int wn, int h, int j, bool folded)
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int mb, int t0, int wm, int wn, int h, int j, bool folded)
 {
     constexpr int kOob = kConvOob;
     // ---- epilogue --------------------------------------------------------------------------
@@ -132,7 +156,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
 
     if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
         static_assert(MI == 2, "paired-row epilogues need MI == 2");
-        const long pair = (long)blockIdx.y * WM + wm;
+        const long pair = (long)mb * WM + wm;
         constexpr bool gate = (MODE == TTSAMD_CONV_GATE);
         const int nvalid = gate ? c_out / 2 : ep->split_row;  // output channels
 #pragma unroll
@@ -183,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
         const bool has_accum = ep->accum != nullptr;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int row0 = (((int)blockIdx.y * WM + wm) * MI + mi) * 32;
+            const int row0 = ((mb * WM + wm) * MI + mi) * 32;
             const bool lower = (MODE == TTSAMD_CONV_RES_SKIP) && (row0 < split);   // res rows vs skip rows
             float radd[16];   // bias (+ per-item row bias) of this lane's 16 rows of the m-tile
 #pragma unroll
@@ -282,13 +306,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): row offsets become scalar soffsets, no waterfall loops
     const int wm = wave / WN;
     const int wn = wave % WN;
     const int h = lane >> 5;   // which channel of the pair / which row group of D
     const int j = lane & 31;   // column inside a 32-wide N tile
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.x * G::kBN;
+    const ConvTile tile = conv_tile_of_block();
+    const int b = tile.b;
+    const int mb = tile.mb;
+    const int t0 = tile.nb * G::kBN;
     const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
     const long ksg_total = (long)nchunks * G::kGroupsPerChunk;  // groups per m-tile
 
@@ -347,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
     const float4 *wp[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+        const long mtile = ((long)mb * WM + wm) * MI + mi;
         wp[mi] = reinterpret_cast<const float4 *>(a.w_packed) + (mtile * ksg_total) * 64 + lane;
     }
     float4 a_cur[MI], a_nxt[MI];
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
     for (int mi = 0; mi < MI; ++mi) a_cur[mi] = wp[mi][0];
 
     stage_load(0);
-    const bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, t0, wm, wn, h, j);
+    const bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, mb, t0, wm, wn, h, j);
     // materialise the accumulators in AGPRs here: the residual loads' temporaries must not stay live in the loop
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -408,7 +434,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MI * NI >= 4) ? 3 : 4) void conv1d_m
         __syncthreads();
     }
 
-    conv_epilogue<MODE, MI, NI, WM, WN>(acc, b, t0, wm, wn, h, j, folded);
+    conv_epilogue<MODE, MI, NI, WM, WN>(acc, b, mb, t0, wm, wn, h, j, folded);
 }
 
 template <int K, int D, int MI, int NI, int WM, int WN, int MODE>

@@ -60,14 +60,22 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): row offsets become scalar soffsets, no waterfall loops
     const int wm = wave / WN;
     const int wn = wave % WN;
     const int h = lane >> 5;   // 8-channel half of the K-step / row group of D
     const int j = lane & 31;   // column inside a 32-wide N tile
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.x * G::kBN;
+    const ConvTile tile = conv_tile_of_block();
+    const int b = tile.b;
+    const int mb = tile.mb;
+    const int t0 = tile.nb * G::kBN;
     const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
+#ifdef TTSAMD_PHASE_CLOCKS
+    // debug build only (scripts/phase_clocks.py): shader-clock stamps of one mid-grid block go to a.y2 (unused by NORMAL)
+    long long pc[5];
+    pc[0] = clock64();
+    const long long prt0 = wall_clock64();
+#endif
 
     constexpr int kOob = kConvOob;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * a.x_bstride, ((long)(a.c_in - 1) * a.x_rstride + a.t_in) * 4);
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
     const u32x4 *wp[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const long mtile = ((long)blockIdx.y * WM + wm) * MI + mi;
+        const long mtile = ((long)mb * WM + wm) * MI + mi;
         wp[mi] = reinterpret_cast<const u32x4 *>(a.w_split) + mtile * ((long)nchunks * K * 3 * 64) + lane;
     }
     u32x4 a_cur[MI][3], a_nxt[MI][3];
@@ -145,9 +153,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
         for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp[mi][q * 64];
 
     stage_load(0);
-    const bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, t0, wm, wn, h, j);
+    const bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, mb, t0, wm, wn, h, j);
     stage_store(xs3);
     __syncthreads();
+#ifdef TTSAMD_PHASE_CLOCKS
+    pc[1] = clock64();
+#endif
 
     const int bbyte = (wn * (32 * NI) + j) * 32 + h * 16;   // this lane's fragment inside a part, tap 0, ni 0
     for (int c = 0; c < nchunks; ++c) {
@@ -188,7 +199,20 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
         __syncthreads();
     }
 
-    conv_epilogue<MODE, MI, NI, WM, WN>(acc, b, t0, wm, wn, h, j, folded);
+#ifdef TTSAMD_PHASE_CLOCKS
+    pc[2] = clock64();
+#endif
+    conv_epilogue<MODE, MI, NI, WM, WN>(acc, b, mb, t0, wm, wn, h, j, folded);
+#ifdef TTSAMD_PHASE_CLOCKS
+    pc[3] = clock64();
+    __builtin_amdgcn_s_waitcnt(0);
+    pc[4] = clock64();
+    if (MODE == TTSAMD_CONV_NORMAL && a.y2 && tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2) {
+        long long *o = reinterpret_cast<long long *>(a.y2);
+        for (int i = 0; i < 5; ++i) o[i] = pc[i] - pc[0];
+        o[5] = wall_clock64() - prt0;
+    }
+#endif
 }
 
 template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
