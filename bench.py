@@ -136,11 +136,14 @@ def bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel):
             "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic", "rtf_x": value / SAMPLE_RATE,
             "config": {"workload": "configs[2]: HiFiGAN-v1 vocoder only, batch=%d x %d-frame mels per GPU, slabbed"
                                    % (args.items, args.frames), "parallelism": "replicas x%d" % world},
+            # the MRF branches run on three HIP streams here, so per-launch event times overlap; the aggregate is priced
+            # on the wall clock of the timed region instead (a lower bound on the conv kernels' own rate)
             "roofline": {"bound": "mfma", "kernel": "all conv launches of the generator (%s)" % conv_kernel_name(args.precision, "..."),
-                         "achieved": r["flops"] / (r["ms"] * 1e-3) / 1e12, "peak": conv_peak(args.precision),
-                         "unit": "TFLOP/s", "frac": r["flops"] / (r["ms"] * 1e-3) / 1e12 / conv_peak(args.precision),
-                         "traffic": None, "algorithmic_gbps": r["bytes"] / (r["ms"] * 1e-3) / 1e9,
-                         "launches_timed": r["launches"]}}), flush=True)
+                         "achieved": r["flops"] / float(tt.item()) / 1e12, "peak": conv_peak(args.precision),
+                         "unit": "TFLOP/s", "frac": r["flops"] / float(tt.item()) / 1e12 / conv_peak(args.precision),
+                         "traffic": None, "algorithmic_gbps": r["bytes"] / float(tt.item()) / 1e9,
+                         "launches_timed": r["launches"],
+                         "measured": "algorithmic conv FLOP of the timed steps / wall time of the timed region"}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
