@@ -136,12 +136,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void x3_loop(float *out, const u
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    constexpr int pa[6] = {2, 1, 0, 1, 0, 0};
-                    constexpr int pb[6] = {0, 1, 2, 0, 1, 0};
+                    constexpr int ORD = (FLAGS >> 3) & 3;
+                    constexpr int pa[3][6] = {{2, 1, 0, 1, 0, 0}, {0, 0, 0, 1, 1, 2}, {2, 1, 0, 0, 1, 0}};
+                    constexpr int pb[3][6] = {{0, 1, 2, 0, 1, 0}, {2, 1, 0, 0, 1, 0}, {0, 0, 0, 1, 1, 2}};
 #pragma unroll
                     for (int t = 0; t < 6; ++t)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[mi][pa[t]]),
-                                                                              __builtin_bit_cast(bf16x8, b[pb[t]]), acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[mi][pa[ORD][t]]),
+                                                                              __builtin_bit_cast(bf16x8, b[pb[ORD][t]]), acc[mi][ni], 0, 0, 0);
                 }
             }
             if (!NOA) {
@@ -491,6 +492,20 @@ int main(int argc, char **argv)
     for (auto &v : hx) v = (float)rand() / RAND_MAX - 0.5f;
     hipMemcpy(g_x, hx.data(), xbytes, hipMemcpyHostToDevice);
     if (argc > 1 && argv[1][0] == 's') { suite<11>(); suite<3>(); return 0; }
+    if (argc > 1 && argv[1][0] == 'o') {
+        for (int rep = 0; rep < 3; ++rep) {
+            run<11, 1, 2, 2, 2, 2, 2, 0>(128, 49280);
+            run<11, 1, 2, 2, 2, 2, 2, 8>(128, 49280);
+            run<11, 1, 2, 2, 2, 2, 2, 16>(128, 49280);
+            run<11, 1, 2, 2, 2, 2, 2, 7>(128, 49280);
+            run<11, 1, 2, 2, 2, 2, 2, 15>(128, 49280);
+            run<11, 1, 2, 2, 2, 2, 2, 23>(128, 49280);
+            run<3, 1, 2, 2, 2, 2, 2, 0>(128, 49280);
+            run<3, 1, 2, 2, 2, 2, 2, 8>(128, 49280);
+            run<3, 1, 2, 2, 2, 2, 2, 16>(128, 49280);
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'c') {
         for (int z = 0; z < 2; ++z) {
             if (z) { hipMemset(g_w, 0, wbytes); hipMemset(g_x, 0, xbytes); printf("--- all-zero operands ---\n"); }

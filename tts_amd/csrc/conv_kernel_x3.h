@@ -20,6 +20,15 @@
 #pragma once
 #include "conv_kernel.h"
 
+// Wave-tile arrangement <MI,NI,WM,WN> of the unpaired-row modes (build-time so that variants can be A/B-ed through
+// TTSAMD_LIB_PATH): 128-row blocks and 64-row blocks.  See conv1d_x3_launch_tiles for the measurements.
+#ifndef TTSAMD_X3_CFG128
+#define TTSAMD_X3_CFG128 1, 4, 4, 1
+#endif
+#ifndef TTSAMD_X3_CFG64
+#define TTSAMD_X3_CFG64 1, 4, 2, 2
+#endif
+
 namespace ttsamd {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -37,7 +46,7 @@ struct ConvGeomX3 {
     static constexpr int kItems = 2 * kXW;                   // (column, 8-channel half) work items per chunk
     static constexpr int kNStage = (kItems + kThreads - 1) / kThreads;
     static constexpr size_t kLdsBytes = (size_t)2 * kBufBytes;
-    static constexpr int kOcc = (MI * NI >= 8) ? 1 : 2;
+    static constexpr int kOcc = 2;
 };
 
 __device__ __forceinline__ void conv_split3(float x, unsigned &p1, unsigned &p2, unsigned &p3)
@@ -238,11 +247,20 @@ template <int K, int D, int MODE>
 int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     const int mtiles = (a.c_out + 31) / 32;
-    if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
+    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
+        if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
+    } else {
+        // 128x128 block as four 32x128 wave tiles: 3 weight loads (L2) + 12 LDS fragment reads per 24 MFMAs instead of
+        // 6 + 6 — LDS has 4x the L1 bandwidth (scripts/ubench/x3_tiles.hip: 0.54 -> 0.56 of peak at the throttled clock,
+        // 0.70 -> 0.79 on zero operands)
+        // measured end to end (bench.py, two runs each): <2,2,2,2> 91.1 ms/step, <1,4,4,1> 87.3
+        if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
+    }
     if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
         return conv1d_x3_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
     } else {
-        if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
+        // same bench, same box: <2,2,1,4> 90.6 ms/step, <1,4,2,2> 89.7; (<1,8,4,1> on the 128-row blocks: 93.4)
+        if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);
         return conv1d_x3_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
     }
 }
