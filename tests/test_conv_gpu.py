@@ -73,6 +73,30 @@ MULTI_TILE = [
 ]
 
 
+# Grids whose block count is a multiple of 8 take the XCD-aware block -> tile mapping (conv_tile_of_block): m-block = XCD
+# index mod m-blocks, contiguous (item, time tile) ranges per XCD.  1, 2, 4 and 8 m-blocks, and a grid that is not a
+# multiple of 8 (plain mapping).  (B, Cin, Cout, K, D, T)
+XCD_CASES = [(4, 32, 128, 3, 1, 16384), (2, 32, 256, 3, 1, 16384), (2, 16, 512, 3, 1, 4096), (1, 16, 1024, 1, 1, 1024),
+             (3, 32, 256, 3, 1, 5000), (8, 16, 64, 7, 1, 8192), (8, 16, 32, 7, 1, 16384)]
+
+
+@pytest.mark.parametrize("case", XCD_CASES)
+def test_conv1d_xcd_tile_mapping(gpu, case):
+    B, Cin, Cout, K, D, T = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / np.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, T, generator=g)
+    want = F.conv1d(x, w, b, padding=(K - 1) * D // 2, dilation=D) + res
+    y = torch.full((B, Cout, T), float("nan"), device=gpu)
+    ops.conv1d(ops.PackedConv(w, b, gpu, dilation=D), x.to(gpu), y, res=res.to(gpu))
+    assert _rel(y, want) < TOL
+    # every (item, row, column) written exactly by its own tile: per-item, per-row-block errors stay at rounding level
+    err = (y.cpu() - want).abs().amax(dim=2)
+    assert float(err.max()) < 1e-4
+
+
 @pytest.mark.parametrize("case", MULTI_TILE)
 def test_conv1d_multi_tile_pipeline(gpu, case, conv_precision):
     B, Cin, Cout, K, D, T, has_res, has_acc, has_mask = case
