@@ -11,9 +11,9 @@
 //      which is exactly the MFMA fragment lane order -> A and B fragments are coalesced 128-byte
 //      global loads, no LDS staging.  Scores land in an LDS strip S[32][T] (odd pitch).
 //   2. band of relative-key logits, mask fill (-1e4), row softmax (wavefront shuffles).
-//   3. O^T = V^T P^T               MFMA again; V chunks are staged through LDS (transposing the
-//      contracted index onto the lane's k slot), P^T fragments come from the LDS strip.
-//      Computing O^T (channels x time) makes the output stores coalesced along time.
+//   3. O^T = V^T P^T               MFMA again; the contracted index is paired with (k-step, half-wave) such that a
+//      lane's V values are consecutive in memory: V^T fragments come straight from global memory, P^T fragments from
+//      the LDS strip.  Computing O^T (channels x time) makes the output stores coalesced along time.
 //   4. band of relative-value terms added in registers, store.
 #include "common.h"
 
@@ -23,7 +23,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kAttRows = 32;
 constexpr int kAttThreads = 256;
-constexpr int kAttVPitch = 33;
+
+#ifdef TTSAMD_PHASE_CLOCKS
+__device__ long long g_att_clk[8];   // debug build: shader-clock stamps of one block (scripts/att_phase.py)
+#define ATT_STAMP(i) do { if (tid == 0 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) g_att_clk[i] = clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float wave_max(float v)
 {
@@ -39,17 +45,21 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 template <int DK>  // dk rounded up to a multiple of 32; channels dk..DK-1 are treated as zeros
-__global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
+__global__ __launch_bounds__(kAttThreads, (DK <= 96 ? 3 : 2)) void rel_attention_kernel(
     float *__restrict__ out, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, long qkv_bstride, const float *__restrict__ mask,
     const float *__restrict__ emb_k, const float *__restrict__ emb_v, int window, int heads, int dk, int T, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *S = smem;                            // [32][pitch]
-    float *Vs = smem + kAttRows * pitch;        // [DK][kAttVPitch]
+    const int ntiles = (T + 31) / 32;
+    const int nrel = emb_k ? 2 * window + 1 : 0;
+    float *S = smem;                            // [32][pitch] score / probability strip
+    float *Ms = smem + kAttRows * pitch;        // [ntiles*32] key mask (1 where absent)
+    float *EkL = Ms + ntiles * 32;              // [nrel][DK] relative-key table, zero padded to DK
+    float *EvL = EkL + nrel * DK;               // [nrel][DK] relative-value table
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
     const int j = lane & 31;
     const int t0 = blockIdx.x * kAttRows;
@@ -59,125 +69,167 @@ __global__ __launch_bounds__(kAttThreads) void rel_attention_kernel(
     const float *qh = q + hoff, *kh = k + hoff, *vh = v + hoff;
     const float *mrow = mask ? mask + (long)b * T : nullptr;
     const float scale = sqrtf((float)dk);
-    const int ntiles = (T + 31) / 32;
+    ATT_STAMP(0);
+
+    // ---- 0. small operands into LDS: key mask, relative tables (every later phase reads them from LDS: the per-element
+    //         global loads of the first version of this kernel cost a full memory latency each) -------------------------
+    for (int c = tid; c < ntiles * 32; c += kAttThreads) Ms[c] = (mrow && c < T) ? mrow[c] : 1.f;
+    for (int e = tid; e < nrel * DK; e += kAttThreads) {
+        const int r = e / DK, c = e - r * DK;
+        EkL[e] = (c < dk) ? emb_k[r * dk + c] : 0.f;
+        EvL[e] = (c < dk) ? emb_v[r * dk + c] : 0.f;
+    }
 
     // ---- 1. S = Q K^T / sqrt(dk) ------------------------------------------------------------
+    // Q fragment of this block's 32 query rows: lane (j, hh) holds Q[channel 2ks+hh][t0+j].  All loads of a tile are
+    // issued before its MFMAs (addresses clamped, invalid lanes zeroed by a select: no branch per element).
+    // Buffer loads: an invalid lane gets the out-of-range offset and reads 0 from the hardware range check — no branch,
+    // no select on the data (a plain `cond ? load : 0` makes hipcc emit a branch + full wait per element).
+    const int slab = dk * T * 4;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(qh, slab), rk = make_rsrc(kh, slab), rv = make_rsrc(vh, slab);
+    float aq[DK / 2];
     {
-        float aq[DK / 2];
         const bool qv = (t0 + j) < T;
 #pragma unroll
-        for (int ks = 0; ks < DK / 2; ++ks) aq[ks] = (qv && 2 * ks + hh < dk) ? qh[(long)(2 * ks + hh) * T + t0 + j] : 0.f;
-        for (int jt = wave; jt < ntiles; jt += 4) {
-            f32x16 acc;
+        for (int ks = 0; ks < DK / 2; ++ks) {
+            const int ch = 2 * ks + hh;
+            aq[ks] = ld_buf(rq, (qv && ch < dk) ? (ch * T + t0 + j) * 4 : kBufOob, 0);
+        }
+    }
+    for (int jt = wave; jt < ntiles; jt += 4) {
+        const int col = jt * 32 + j;
+        const bool kv = col < T;
+        float bk[DK / 2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int col = jt * 32 + j;
-            const bool kv = col < T;
+        for (int ks = 0; ks < DK / 2; ++ks) {
+            const int ch = 2 * ks + hh;
+            bk[ks] = ld_buf(rk, (kv && ch < dk) ? (ch * T + col) * 4 : kBufOob, 0);
+        }
+        f32x16 acc;
 #pragma unroll
-            for (int ks = 0; ks < DK / 2; ++ks) {
-                const float bv = (kv && 2 * ks + hh < dk) ? kh[(long)(2 * ks + hh) * T + col] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ks], bv, acc, 0, 0, 0);
-            }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                S[row * pitch + col] = acc[r] / scale;
-            }
+        for (int ks = 0; ks < DK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ks], bk[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            S[row * pitch + col] = acc[r] / scale;
         }
     }
     __syncthreads();
+    ATT_STAMP(1);
 
     // ---- 2a. relative-key band: S[i][i+d] += (Q[i] . Ek[d+w]) / sqrt(dk),  |d| <= w ----------
-    if (emb_k) {
-        const int nrel = 2 * window + 1;
-        for (int idx = tid; idx < kAttRows * nrel; idx += kAttThreads) {
-            const int i = idx & 31;
-            const int r = idx >> 5;
-            const int ti = t0 + i;
-            const int tj = ti + r - window;
-            if (ti < T && tj >= 0 && tj < T) {
-                float dot = 0.f;
-                for (int c = 0; c < dk; ++c) dot += qh[(long)c * T + ti] * emb_k[r * dk + c];
-                S[i * pitch + tj] += dot / scale;
+    // from the Q fragment already in registers: each half-wave sums its 48 channels, one shuffle joins the halves
+    for (int r = wave; r < nrel; r += 4) {
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DK / 2; ++ks) part += aq[ks] * EkL[r * DK + 2 * ks + hh];
+        const float dot = part + __shfl_xor(part, 32);
+        const int ti = t0 + j;
+        const int tj = ti + r - window;
+        if (hh == 0 && ti < T && tj >= 0 && tj < T) S[j * pitch + tj] += dot / scale;
+    }
+    if (nrel) __syncthreads();
+
+    ATT_STAMP(2);
+    // ---- 2b. mask fill + softmax: each wave owns 8 rows and walks them together (8 independent LDS chains per
+    //          column step instead of one row at a time).  Rows beyond T hold S = 0 (their Q fragment is zero): they
+    //          normalise to 1/T, stay finite and are never stored.
+    {
+        float *Sw = S + wave * 8 * pitch;
+        float mi[8], mx[8], sum[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            mi[rr] = Ms[t0 + wave * 8 + rr];
+            mx[rr] = -INFINITY;
+            sum[rr] = 0.f;
+        }
+        for (int c = lane; c < T; c += 64) {
+            const float mc = Ms[c];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                float sv = Sw[rr * pitch + c];
+                if (mrow && (mi[rr] == 0.f || mc == 0.f)) sv = -1e4f;
+                Sw[rr * pitch + c] = sv;
+                mx[rr] = fmaxf(mx[rr], sv);
             }
         }
-        __syncthreads();
-    }
-
-    // ---- 2b. mask fill + softmax (each wave owns 8 rows) --------------------------------------
-    for (int rr = 0; rr < 8; ++rr) {
-        const int i = wave * 8 + rr;
-        const int ti = t0 + i;
-        float *Srow = S + i * pitch;
-        if (ti >= T) {  // query row outside the tensor: keep the strip finite, nothing is stored from it
-            for (int c = lane; c < ntiles * 32; c += 64) Srow[c] = 0.f;
-            continue;
-        }
-        const float mi = mrow ? mrow[ti] : 1.f;
-        float mx = -INFINITY;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) mx[rr] = wave_max(mx[rr]);
         for (int c = lane; c < T; c += 64) {
-            float s = Srow[c];
-            if (mrow && (mi == 0.f || mrow[c] == 0.f)) s = -1e4f;
-            Srow[c] = s;
-            mx = fmaxf(mx, s);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const float ev = expf(Sw[rr * pitch + c] - mx[rr]);
+                Sw[rr * pitch + c] = ev;
+                sum[rr] += ev;
+            }
         }
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int c = lane; c < T; c += 64) {
-            const float e = expf(Srow[c] - mx);
-            Srow[c] = e;
-            sum += e;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) sum[rr] = wave_sum(sum[rr]);
+        for (int c = lane; c < ntiles * 32; c += 64) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) Sw[rr * pitch + c] = (c < T) ? Sw[rr * pitch + c] / sum[rr] : 0.f;
         }
-        sum = wave_sum(sum);
-        for (int c = lane; c < ntiles * 32; c += 64) Srow[c] = (c < T) ? Srow[c] / sum : 0.f;
     }
     __syncthreads();
+    ATT_STAMP(3);
 
     // ---- 3. O^T[n][i] = sum_kk V^T[n][kk] P^T[kk][i] ------------------------------------------
+    // The pairing of contracted indices with (k-step, half-wave) is free as long as both operands use the same one:
+    // with kk = 16*hh + ks a lane's 16 V values of a key tile are CONSECUTIVE in memory (row n, columns kt*32+16hh..+15),
+    // so V^T fragments come straight from global memory (next tile prefetched) — no LDS staging, no barriers in this loop.
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool mma_wave = wave < DK / 32;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        // stage V[:, kt*32 .. +32) -> Vs[n][c]   (coalesced along time, zero beyond T)
-        for (int e = tid; e < DK * 32; e += kAttThreads) {
-            const int n = e >> 5, c = e & 31;
-            const int tt = kt * 32 + c;
-            Vs[n * kAttVPitch + c] = (tt < T && n < dk) ? vh[(long)n * T + tt] : 0.f;
-        }
-        __syncthreads();
-        if (mma_wave) {
+    if (mma_wave) {
+        const int n = wave * 32 + j;                 // rows >= dk read 0 and are never stored
+        float vv[2][16];
+        auto vload = [&](int kt, float (&dst)[16]) {
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const float av = Vs[(wave * 32 + j) * kAttVPitch + 2 * ks + hh];
-                const float bv = S[j * pitch + kt * 32 + 2 * ks + hh];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int m = 0; m < 16; ++m) {
+                const int col = kt * 32 + 16 * hh + m;
+                dst[m] = ld_buf(rv, (n < dk && col < T) ? (n * T + col) * 4 : kBufOob, 0);
+            }
+        };
+        vload(0, vv[0]);
+        for (int kt = 0; kt < ntiles; kt += 2) {
+            if (kt + 1 < ntiles) vload(kt + 1, vv[1]);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[0][ks], S[j * pitch + kt * 32 + 16 * hh + ks], acc, 0, 0, 0);
+            if (kt + 1 < ntiles) {
+                if (kt + 2 < ntiles) vload(kt + 2, vv[0]);
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[1][ks], S[j * pitch + (kt + 1) * 32 + 16 * hh + ks], acc, 0, 0, 0);
             }
         }
-        __syncthreads();
     }
 
+    ATT_STAMP(4);
     // ---- 4. relative-value band + store ---------------------------------------------------------
     if (mma_wave) {
         const int ti = t0 + j;
         if (ti < T) {
+            float rel[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rel[r] = 0.f;
+            for (int d = 0; d < nrel; ++d) {
+                const int tj = ti + d - window;
+                const float p = (tj >= 0 && tj < T) ? S[j * pitch + tj] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rel[r] += p * EvL[d * DK + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (n >= dk) continue;
-                float o = acc[r];
-                if (emb_v) {
-                    float rel = 0.f;
-                    for (int d = 0; d <= 2 * window; ++d) {
-                        const int tj = ti + d - window;
-                        if (tj >= 0 && tj < T) rel += S[j * pitch + tj] * emb_v[d * dk + n];
-                    }
-                    o += rel;
-                }
-                out[((long)b * heads * dk + (long)head * dk + n) * T + ti] = o;
+                if (n < dk) out[((long)b * heads * dk + (long)head * dk + n) * T + ti] = acc[r] + rel[r];
             }
         }
     }
+    ATT_STAMP(5);
 }
 
 template <int DK>
@@ -186,13 +238,18 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
 {
     const int ntiles = (T + 31) / 32;
     const int pitch = ntiles * 32 + 1;
-    const size_t lds = (size_t)(kAttRows * pitch + DK * kAttVPitch) * sizeof(float);
+    const int nrel = ek ? 2 * window + 1 : 0;
+    const size_t lds = (size_t)(kAttRows * pitch + ntiles * 32 + 2 * nrel * DK) * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("rel_attention: T=%d with window=%d needs %zu bytes of LDS", T, window, lds);
+        return TTSAMD_ERR_UNSUPPORTED;
+    }
     auto kern = rel_attention_kernel<DK>;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
+    static bool attr_set = false;
+    if (!attr_set) {
         TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        lds_set = 160 * 1024;
+        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(ntiles, heads, batch), dim3(kAttThreads), lds, st, out, q, k, v, bstride, mask,
                        ek, ev, window, heads, dk, T, pitch);
@@ -202,6 +259,13 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
 
 }  // namespace ttsamd
 using namespace ttsamd;
+
+#ifdef TTSAMD_PHASE_CLOCKS
+extern "C" int ttsamd_debug_att_clocks(long long *host_out8)
+{
+    return hipMemcpyFromSymbol(host_out8, HIP_SYMBOL(ttsamd::g_att_clk), 8 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int ttsamd_rel_attention(float *out, const float *q, const float *k, const float *v, int64_t qkv_bstride,
                                     const float *mask, const float *emb_rel_k, const float *emb_rel_v, int window,

@@ -35,4 +35,22 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+constexpr int kBufOob = 0x7FFFFFF0;  // buffer offset of an invalid lane: the hardware range check drops it / reads 0
+// Buffer-resource helpers (raw buffer, stride 0; dword 3 = 0x00020000 as on gfx90a/gfx94x/gfx950).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0));
+}
+__device__ __forceinline__ void st_buf(__amdgpu_buffer_rsrc_t r, float v, int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voffset, soffset, 0);
+}
+
+#endif
+
 }  // namespace ttsamd

@@ -28,7 +28,7 @@ namespace ttsamd {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kConvCK = 16;  // input channels per LDS chunk (8 channel pairs)
-constexpr int kConvOob = 0x7FFFFFF0;  // buffer offset of an invalid lane: the hardware range check drops it
+constexpr int kConvOob = kBufOob;
 
 struct ConvTileCfg {
     int mi, ni, wm, wn;
@@ -46,20 +46,6 @@ struct ConvGeom {
     static constexpr int kGroupsPerChunk = (kConvCK / 2) * K / 4;  // k-step groups (of 4) per chunk
     static constexpr size_t kLdsBytes = (size_t)2 * kStageElems * sizeof(float);
 };
-
-// Buffer-resource helpers (raw buffer, stride 0; dword 3 = 0x00020000 as on gfx90a/gfx94x/gfx950).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, long bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float ld_buf(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, soffset, 0));
-}
-__device__ __forceinline__ void st_buf(__amdgpu_buffer_rsrc_t r, float v, int voffset, int soffset)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voffset, soffset, 0);
-}
 
 // Block -> tile assignment.  The hardware deals workgroups to the 8 XCDs round-robin by linear id (x fastest), each XCD
 // with its own 4 MiB L2.  With the plain (x = time tile, y = m-block, z = item) order every L2 sees every m-block's
