@@ -312,6 +312,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2],
                     help="split-bf16 NORMAL convs: 0 one block per tile (default), 1 persistent pipelined kernel on "
                          "128-row layers, 2 everywhere eligible")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="vits_e2e: request lanes (HIP streams) per GPU used round-robin by the steps, so that the "
+                         "latency-bound text front end of one batch overlaps the waveform decoder of the previous one "
+                         "(tts_amd.parallel.Lanes); 1 = one stream")
     ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1", "mas", "xtts_stream"],
                     help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
@@ -360,7 +364,11 @@ def main():
     x, xl, dur = synthetic_batch(args.batch, args.chars, seed=rank, device=dev)
     aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True}
 
+    lanes = parallel.Lanes(args.lanes, device=dev) if args.lanes > 1 else None
+
     def step():
+        if lanes is not None:
+            return lanes.run(model.inference, x, aux)
         return model.inference(x, aux)
 
     def fence():
@@ -368,6 +376,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.lanes if lanes is not None else 0):   # prime every lane (hipGraph capture, allocator pools): untimed
+        step()
     for _ in range(args.warmup):
         out = step()
     # live roofline measurement: HIP events around every launch of the dominant kernel instantiation
@@ -396,6 +406,7 @@ def main():
     # events on the stream it is launched on.
     timer = ops.ConvTimer(select)
     roof_steps = 2
+    lanes = None          # the roofline pass runs on the default stream, one request at a time
     if rank == 0:
         was = model.waveform_decoder.concurrent_branches
         model.waveform_decoder.concurrent_branches = False
@@ -442,7 +453,7 @@ def main():
                                    "(257 ids, 770 frames, 197120 samples each), 22.05 kHz" % (args.batch, args.chars),
                        "utterances_per_gpu": args.batch, "chars": args.chars, "parallelism": "replicas x%d" % world,
                        "weights": "random-init VitsArgs defaults (29.1 M params), broadcast from rank 0 in %.3f s" % bcast_s,
-                       "mrf_branch_streams": 1 if args.serial_branches else 3},
+                       "mrf_branch_streams": 1 if args.serial_branches else 3, "request_lanes": args.lanes},
             "roofline": {
                 "bound": "mfma",
                 "kernel": conv_kernel_name(args.precision, "11,1,2,2,2,2,0") + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",

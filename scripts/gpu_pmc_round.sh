@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-pmc}; PREC=${2:-x3}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  PYTHONPATH=$R timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -o pmc -- python $R/bench.py --precision $PREC --serial-branches --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+  PYTHONPATH=$R timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -o pmc -- python $R/bench.py --precision $PREC --serial-branches --lanes 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
 F=$(find $OUT/FETCH_SIZE -name '*counter_collection.csv' | head -1); W=$(find $OUT/WRITE_SIZE -name '*counter_collection.csv' | head -1)

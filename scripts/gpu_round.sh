@@ -9,7 +9,7 @@ fi
 timeout 600 python bench.py > $OUT/bench_x3.json 2> $OUT/bench_x3.err; echo "bench rc=$?"; cat $OUT/bench_x3.json
 timeout 300 python bench.py --precision f32 --no-cpu-baseline > $OUT/bench_f32.json 2> $OUT/bench_f32.err; cat $OUT/bench_f32.json
 cd /tmp && export TMPDIR=/tmp
-PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --serial-branches --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof.log 2>&1
+PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --serial-branches --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof.log 2>&1
 echo "prof rc=$?"
 S=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); T=$(find $OUT/prof -name '*kernel_trace.csv' | head -1)
 python $R/scripts/prof_summary.py stats $S > $OUT/kernel_stats.txt; head -12 $OUT/kernel_stats.txt

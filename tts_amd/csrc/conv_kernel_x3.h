@@ -253,7 +253,8 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
         // 128x128 block as four 32x128 wave tiles: 3 weight loads (L2) + 12 LDS fragment reads per 24 MFMAs instead of
         // 6 + 6 — LDS has 4x the L1 bandwidth (scripts/ubench/x3_tiles.hip: 0.54 -> 0.56 of peak at the throttled clock,
         // 0.70 -> 0.79 on zero operands)
-        // measured end to end (bench.py, two runs each): <2,2,2,2> 91.1 ms/step, <1,4,4,1> 87.3
+        // measured end to end (bench.py, two runs each): <2,2,2,2> 91.1 ms/step, <1,4,4,1> 87.3; 256-row blocks
+        // (<2,4,4,1>) for the 2-tap polyphase ConvTranspose launches: +-0
         if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
     }
     if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {

@@ -29,7 +29,7 @@ class GraphedSegment:
 class GraphCache:
     """Shape-keyed cache of captured segments with an eager escape hatch (capture disabled or failed)."""
 
-    def __init__(self, fn, max_entries=8):
+    def __init__(self, fn, max_entries=16):
         self.fn, self.max_entries = fn, max_entries
         self.entries = {}
         self.enabled = True
@@ -38,7 +38,9 @@ class GraphCache:
         """`key`: extra hashable state the captured launches depend on (scalars baked into the graph)."""
         if not self.enabled:
             return self.fn(*inputs)
-        key = (key,) + tuple((tuple(t.shape), t.dtype) for t in inputs)
+        # one capture per (shape, stream): concurrent request lanes (parallel.Lanes) replay on their own streams and must
+        # not share the static input / output buffers of a graph
+        key = (key, torch.cuda.current_stream().cuda_stream) + tuple((tuple(t.shape), t.dtype) for t in inputs)
         seg = self.entries.get(key)
         if seg is None:
             if len(self.entries) >= self.max_entries:

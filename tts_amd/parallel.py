@@ -70,3 +70,36 @@ def shard_by_length(lengths, world_size):
     -> list of index lists, one per rank."""
     order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
     return [order[r::world_size] for r in range(world_size)]
+
+
+class Lanes:
+    """Request lanes inside one GPU process: N HIP streams used round-robin, one request (batch) per lane at a time.
+    A request's text front end is a few milliseconds of tiny, latency-bound launches with a host sync in the middle
+    (`y_lengths.max()`), its waveform decoder 80+ ms of chip-filling convs; on ONE stream the chip idles through every
+    front end.  With two lanes the front end (and flows) of request i+1 run while the decoder of request i occupies the
+    matrix pipes — launches are asynchronous and the mid-request host sync only waits for its own lane's stream, so a
+    single host thread drives both.  Results are ordered by `sync()` (or by the caller waiting on the lane's event).
+
+        lanes = Lanes(2)
+        outs = [lanes.run(model.inference, x_i, aux_i) for ...]     # returns immediately after issuing
+        lanes.sync()
+    """
+
+    def __init__(self, n=2, device=None):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
+        self._next = 0
+        self._outs = [None] * len(self.streams)   # keep each lane's last result alive until the lane is reused
+
+    def run(self, fn, *args, **kwargs):
+        i = self._next
+        self._next = (i + 1) % len(self.streams)
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream())        # inputs produced on the caller's stream
+        with torch.cuda.stream(st):
+            out = fn(*args, **kwargs)
+        self._outs[i] = out
+        return out
+
+    def sync(self):
+        for st in self.streams:
+            st.synchronize()
