@@ -384,7 +384,7 @@ def main():
     # (ResBlock k=11 d=1 convs of the 256/128-channel stages, conv1d_mfma_kernel<11,1,2,2,2,2,0>) and around all conv launches of the
     # waveform decoder in aggregate, on the stream they are launched on, during the timed region.
     def select(pc, a):
-        # every launch that dispatches to the instantiation conv1d_mfma_kernel<11,1,2,2,2,2,NORMAL> (128x128 tile):
+        # every launch that dispatches to the 128x128-block k=11 d=1 NORMAL instantiation:
         # the ResBlock1 k=11 d=1 convs of the 256- and 128-channel MRF stages (8 per step)
         if pc.kernel == 11 and pc.dilation == 1 and a.mode == 0 and ((pc.c_out + 31) // 32) % 4 == 0:
             return "dominant"
@@ -456,7 +456,8 @@ def main():
                        "mrf_branch_streams": 1 if args.serial_branches else 3, "request_lanes": args.lanes},
             "roofline": {
                 "bound": "mfma",
-                "kernel": conv_kernel_name(args.precision, "11,1,2,2,2,2,0") + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
+                "kernel": conv_kernel_name(args.precision, "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0")
+                          + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
                 "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
                 "frac": ach / conv_peak(args.precision), "traffic": traffic,
                 "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B per launch) / launch time; peak = bf16 dense "

@@ -7,7 +7,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "$C rc=$?"
 done
 F=$(find $OUT/FETCH_SIZE -name '*counter_collection.csv' | head -1); W=$(find $OUT/WRITE_SIZE -name '*counter_collection.csv' | head -1)
-SUB="conv1d_mfma_kernel<11,1,2,2,2,2,0>"; [ "$PREC" = "x3" ] && SUB="conv1d_x3_kernel<11,1,2,2,2,2,0>"
+SUB="conv1d_mfma_kernel<11,1,2,2,2,2,0>"; [ "$PREC" = "x3" ] && SUB="conv1d_x3_kernel<11,1,1,4,4,1,0>"
 python $R/scripts/pmc_dominant.py $F $W "$SUB" $OUT/pmc_dominant_$PREC.json
 python $R/scripts/prof_summary.py pmc $F > $OUT/pmc_fetch.txt; python $R/scripts/prof_summary.py pmc $W > $OUT/pmc_write.txt
 rm -rf $OUT/FETCH_SIZE $OUT/WRITE_SIZE
