@@ -316,6 +316,7 @@ def main():
                     help="vits_e2e: request lanes (HIP streams) per GPU used round-robin by the steps, so that the "
                          "latency-bound text front end of one batch overlaps the waveform decoder of the previous one "
                          "(tts_amd.parallel.Lanes); 1 = one stream")
+    ap.add_argument("--lane-priority", type=int, default=-1, help="HIP stream priority of the request lanes (-1 high, 0 normal)")
     ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1", "mas", "xtts_stream"],
                     help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
@@ -364,7 +365,7 @@ def main():
     x, xl, dur = synthetic_batch(args.batch, args.chars, seed=rank, device=dev)
     aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True}
 
-    lanes = parallel.Lanes(args.lanes, device=dev) if args.lanes > 1 else None
+    lanes = parallel.Lanes(args.lanes, device=dev, priority=args.lane_priority) if args.lanes > 1 else None
 
     def step():
         if lanes is not None:
