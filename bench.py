@@ -309,9 +309,6 @@ def main():
     ap.add_argument("--precision", default=None, choices=["x3", "f32"],
                     help="conv arithmetic: x3 = split-bf16 kernels (default, fp32-class accuracy on the bf16 MFMA), "
                          "f32 = fp32-input MFMA kernels (bitwise fmaf chain)")
-    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2],
-                    help="split-bf16 NORMAL convs: 0 one block per tile (default), 1 persistent pipelined kernel on "
-                         "128-row layers, 2 everywhere eligible")
     ap.add_argument("--lanes", type=int, default=2,
                     help="vits_e2e: request lanes (HIP streams) per GPU used round-robin by the steps, so that the "
                          "latency-bound text front end of one batch overlaps the waveform decoder of the previous one "
@@ -343,8 +340,6 @@ def main():
     if args.precision is None:
         args.precision = ops.conv_precision()
     ops.set_conv_precision(args.precision)
-    if args.pipeline is not None:
-        ops.set_conv_pipeline(args.pipeline)
 
     if args.workload == "hifigan_v1":
         return bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel)

@@ -151,10 +151,6 @@ int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, 
  * group of prefetch slack); part q of a weight = round-to-nearest bf16 of what parts < q left of it. */
 size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kernel);
 int ttsamd_conv1d_pack_weights_split(void *dst, const float *w, int c_out, int c_in, int kernel);
-/* Split-bf16 NORMAL-mode launches: 0 (default) = one block per tile everywhere, 1 = the persistent, epilogue-pipelined
- * kernel (conv_kernel_x3p.h) where c_out is a multiple of 128, 2 = wherever it is eligible.  Returns the previous
- * setting.  Same arithmetic either way. */
-int ttsamd_conv1d_set_pipeline(int on);
 /* 1 if (kernel, dilation) has a tuned instantiation. */
 int ttsamd_conv1d_supported(int kernel, int dilation);
 

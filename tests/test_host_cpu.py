@@ -10,7 +10,7 @@ import numpy as np
 
 from tts_amd.audio import AudioProcessor
 from tts_amd.synthesizer import Synthesizer, load_config
-from tts_amd.text import Graphemes, TTSTokenizer
+from tts_amd.text import Graphemes, TTSTokenizer, VitsCharacters, basic_cleaners
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -20,15 +20,134 @@ def test_grapheme_vocab_and_tokenizer_known_answers():
     assert g.vocab[:4] == ["<PAD>", "<EOS>", "<BOS>", "<BLNK>"] and g.num_chars == 67
     assert (g.char_to_id("A"), g.char_to_id("a"), g.char_to_id("!"), g.char_to_id(" ")) == (4, 30, 56, 66)
     assert (g.pad_id, g.eos_id, g.bos_id, g.blank_id) == (0, 1, 2, 3)
-    t = TTSTokenizer(add_blank=False)
+    t = TTSTokenizer(add_blank=False, text_cleaner=basic_cleaners)
     assert t.text_to_ids("Ab!") == [30, 31, 56]
     assert t.text_to_ids("a  b\n") == [30, 66, 31]                       # whitespace collapsed, stripped
-    tb = TTSTokenizer(add_blank=True, use_eos_bos=True)
+    tb = TTSTokenizer(add_blank=True, use_eos_bos=True, text_cleaner=basic_cleaners)
     assert tb.text_to_ids("ab") == [2, 3, 30, 3, 31, 3, 1]               # blank interspersed (2n+1), then bos/eos
     assert t.text_to_ids("a#b") == [30, 31] and t.not_found_characters == ["#"]
     tok, _ = TTSTokenizer.init_from_config({"add_blank": True, "characters": {"characters": "ba", "punctuations": ".",
                                                                               "pad": "_", "eos": "", "bos": "", "blank": "~"}})
     assert tok.characters.vocab == ["_", "~", "a", "b", "."] and tok.text_to_ids("b.") == [1, 3, 1, 4, 1]
+
+
+def test_vits_characters_and_config_resolution():
+    """`characters_class` and `text_cleaner` of the config decide the id table / cleaning
+    (tokenizer.py:159-170); VitsCharacters = [pad] + punctuations + characters + phonemes (config order) + [blank]
+    (vits.py:1948); unknown classes / cleaners raise instead of falling back."""
+    import pytest
+
+    cfg = {"text_cleaner": "multilingual_cleaners", "add_blank": True,
+           "characters": {"characters_class": "TTS.tts.models.vits.VitsCharacters", "pad": "_", "punctuations": "!. ",
+                          "characters": "zyxab", "phonemes": "\u0259\u02c8", "eos": "&", "bos": "*", "blank": None,
+                          "is_unique": True, "is_sorted": True}}
+    tok, _ = TTSTokenizer.init_from_config(cfg)
+    assert isinstance(tok.characters, VitsCharacters)
+    assert tok.characters.vocab == ["_", "!", ".", " ", "z", "y", "x", "a", "b", "\u0259", "\u02c8", "<BLNK>"]
+    assert (tok.characters.pad_id, tok.characters.blank_id) == (0, 11)
+    assert tok.text_to_ids("A-b") == [11, 7, 11, 3, 11, 8, 11]          # lowercase, '-' -> ' ', blanks interspersed
+    v = VitsCharacters()
+    assert v.vocab[0] == "<PAD>" and v.vocab[1:12] == list("!'(),-.:;? ") and v.vocab[12] == "A" and v.vocab[-1] == "<BLNK>"
+    assert v.num_chars == 1 + 11 + 52 + len(v.characters) - 52 + 1
+    # grapheme config without a class: Graphemes with the config's tokens verbatim; no cleaner named -> none applied
+    tok, _ = TTSTokenizer.init_from_config({"characters": {"characters": "ab", "punctuations": " ", "pad": "<PAD>",
+                                                           "eos": None, "bos": None, "blank": None}})
+    assert tok.characters.vocab == ["<PAD>", "a", "b", " "] and tok.text_to_ids("aB b") == [1, 3, 2]
+    with pytest.raises(NotImplementedError):
+        TTSTokenizer.init_from_config({"characters": {"characters_class": "my.pkg.Chars", "characters": "a", "punctuations": ""}})
+    with pytest.raises(NotImplementedError):
+        TTSTokenizer.init_from_config({"text_cleaner": "chinese_mandarin_cleaners"})
+    with pytest.raises(NotImplementedError):
+        TTSTokenizer.init_from_config({"text_cleaner": "english_cleaners"})[0].text_to_ids("call 911")
+    tok, _ = TTSTokenizer.init_from_config({"text_cleaner": "english_cleaners"})
+    assert tok.ids_to_text(tok.text_to_ids("Dr. Who & Co. [ok]")) == "doctor who and company ok"
+
+
+def test_characters_match_reference_classes():
+    """Same vocabularies as the reference's own classes (build container only: /root/reference is absent on the GPU box).
+    `VitsCharacters` lives in the un-importable TTS/tts/models/vits.py, so its class body is lifted out with `ast`."""
+    import ast
+
+    import pytest
+
+    from oracle import ref_shim
+
+    if not ref_shim.available():
+        pytest.skip("reference tree not present")
+    # TTS/tts/utils/text/__init__.py pulls in the cleaners (anyascii, not installed): load characters.py by path
+    import importlib.util
+
+    ref_shim.install()
+    spec = importlib.util.spec_from_file_location(
+        "_ref_characters", os.path.join(ref_shim.REF_ROOT, "TTS", "tts", "utils", "text", "characters.py"))
+    C = importlib.util.module_from_spec(spec)
+    import sys
+    import types
+
+    stub_name = "TTS.tts.configs.shared_configs"       # characters.py only needs the CharactersConfig NAME (-> trainer, absent)
+    had = sys.modules.get(stub_name)
+    stub = types.ModuleType(stub_name)
+    stub.CharactersConfig = type("CharactersConfig", (), {})
+    sys.modules[stub_name] = stub
+    try:
+        spec.loader.exec_module(C)
+    finally:
+        if had is None:
+            sys.modules.pop(stub_name, None)
+            sys.modules.pop("TTS.tts.configs", None)
+        else:
+            sys.modules[stub_name] = had
+    src = open(os.path.join(ref_shim.REF_ROOT, "TTS", "tts", "models", "vits.py"), encoding="utf-8").read()
+    node = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "VitsCharacters"][0]
+    ns = {"BaseCharacters": C.BaseCharacters, "_characters": C._characters, "_punctuations": C._punctuations,
+          "_pad": C._pad, "_phonemes": C._phonemes, "Coqpit": object, "CharactersConfig": None, "replace": None}
+    exec(compile(ast.Module([node], []), "vits_characters", "exec"), ns)
+    RefVits = ns["VitsCharacters"]
+    ch = {"pad": "<PAD>", "punctuations": "!\u00a1'(),-.:;\u00bf? ", "characters": "ABCabc\u00e7\u00e3\u00e0", "phonemes": "\u0259\u02c8\u02d0"}
+    cfg = type("Cfg", (), {"characters": ch})()
+    ref, _ = RefVits.init_from_config(cfg)
+    mine = VitsCharacters.init_from_config({"characters": ch})
+    assert mine.vocab == ref.vocab and (mine.pad_id, mine.blank_id) == (ref.pad_id, ref.blank_id)
+    assert VitsCharacters().vocab == RefVits().vocab
+    assert Graphemes().vocab == C.Graphemes().vocab
+    kw = dict(characters="hello wrld", punctuations="?!", pad="_", eos="", bos=None, blank="~", is_unique=False, is_sorted=True)
+    r, m = C.Graphemes(**kw), Graphemes(**kw)
+    assert m.vocab == r.vocab and m._char_to_id == r._char_to_id and (m.pad_id, m.eos_id, m.bos_id, m.blank_id) == (
+        r.pad_id, r.eos_id, r.bos_id, r.blank_id)
+
+
+# the reference's own golden strings for `Synthesizer.split_into_sentences` (tests/inference_tests/test_synthesizer.py:29-79)
+SPLIT_GOLDEN = [
+    ("Hello. Two sentences", ["Hello.", "Two sentences"]),
+    ("He went to meet the adviser from Scott, Waltman & Co. next morning.",
+     ["He went to meet the adviser from Scott, Waltman & Co. next morning."]),
+    ("Let's run it past Sarah and co. They'll want to see this.", ["Let's run it past Sarah and co.", "They'll want to see this."]),
+    ("Where is Bobby Jr.'s rabbit?", ["Where is Bobby Jr.'s rabbit?"]),
+    ("Please inform the U.K. authorities right away.", ["Please inform the U.K. authorities right away."]),
+    ("Were David and co. at the event?", ["Were David and co. at the event?"]),
+    ("paging dr. green, please come to theatre four immediately.", ["paging dr. green, please come to theatre four immediately."]),
+    ("The email format is Firstname.Lastname@example.com. I think you reversed them.",
+     ["The email format is Firstname.Lastname@example.com.", "I think you reversed them."]),
+    ("The demo site is: https://top100.example.com/subsection/latestnews.html. Please send us your feedback.",
+     ["The demo site is: https://top100.example.com/subsection/latestnews.html.", "Please send us your feedback."]),
+    ("Scowling at him, 'You are not done yet!' she yelled.", ["Scowling at him, 'You are not done yet!' she yelled."]),
+    ("Hey!! So good to see you.", ["Hey!!", "So good to see you."]),
+    ("He went to Yahoo! but I don't know the division.", ["He went to Yahoo! but I don't know the division."]),
+    ("If you can't remember a quote, \u201cat least make up a memorable one that's plausible...\"",
+     ["If you can't remember a quote, \u201cat least make up a memorable one that's plausible...\""]),
+    ("The address is not google.com.", ["The address is not google.com."]),
+    ("1.) The first item 2.) The second item", ["1.) The first item", "2.) The second item"]),
+    ("1) The first item 2) The second item", ["1) The first item", "2) The second item"]),
+    ("a. The first item b. The second item c. The third list item",
+     ["a. The first item", "b. The second item", "c. The third list item"]),
+]
+
+
+def test_split_into_sentences_reference_golden_strings():
+    for text, want in SPLIT_GOLDEN:
+        assert Synthesizer.split_into_sentences(text) == want, text
+    assert Synthesizer.split_into_sentences("Dr. Green is in. Mr. Smith left.") == ["Dr. Green is in.", "Mr. Smith left."]
+    assert Synthesizer.split_into_sentences("   ") == []
 
 
 def test_audio_processor_norm_denorm_known_answers():

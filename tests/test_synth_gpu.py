@@ -83,6 +83,33 @@ def test_glow_hifigan_tts_to_file(gpu, tmp_path):
     assert isinstance(flat, list) and len(flat) == sum(len(w) for w in got) + 10000 * len(got)
 
 
+def test_vocoder_sample_rate_seam_batched(gpu, tmp_path):
+    """TTS and vocoder sample rates differ -> the vocoder input is interpolated along time per sentence
+    (synthesizer.py:418-424); a multi-sentence request runs as one ragged batch and every row equals its B=1 run."""
+    gargs = dict(num_flow_blocks_dec=2)
+    gargs["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=1)
+    gsd = W.make_glow_state(dict(gargs, num_chars=67), seed=18)
+    audio = {"sample_rate": 22050, "num_mels": 80, "do_trim_silence": False}
+    gcfg = dict(gargs, model="glow_tts", audio=audio, add_blank=False, use_phonemes=False,
+                encoder_params=dict(gargs["encoder_params"]))
+    hcfg = dict(W.HIFIGAN_V2)
+    hsd = O.make_hifigan_state(hcfg, 80, seed=19)
+    vcfg = {"model": "hifigan", "generator_model": "hifigan_generator", "discriminator_model": "hifigan_discriminator",
+            "audio": dict(audio, sample_rate=24000),
+            "generator_model_params": {k: hcfg[k] for k in ("upsample_factors", "upsample_kernel_sizes",
+                                                            "upsample_initial_channel", "resblock_kernel_sizes",
+                                                            "resblock_dilation_sizes", "resblock_type")}}
+    gck, gcf = _write(tmp_path, "glow", gsd, gcfg)
+    vck, vcf = _write(tmp_path, "voc", {"model_g." + k: v for k, v in hsd.items()}, vcfg)
+    syn = Synthesizer(tts_checkpoint=gck, tts_config_path=gcf, vocoder_checkpoint=vck, vocoder_config=vcf, use_cuda=True)
+    sens = ["A short one.", "And a rather longer second sentence, for raggedness!", "Mid length here?"]
+    batch = syn.tts_batch(sens)
+    for s, w in zip(sens, batch):
+        one = syn.tts_batch([s])[0]
+        assert one.shape == w.shape and len(w) > 0
+        assert float(np.abs(one - w).max()) < 1e-5, s
+
+
 def test_vits_synthesizer_smoke(gpu, tmp_path):
     vargs = dict(upsample_initial_channel_decoder=64, num_chars=67 + 1)
     sd = W.make_vits_state(vargs, seed=12)

@@ -43,8 +43,6 @@ def lib():
         _lib.ttsamd_last_error.restype = ctypes.c_char_p
         _lib.ttsamd_arch.restype = ctypes.c_char_p
         _lib.ttsamd_maximum_path_workspace_bytes.restype = ctypes.c_size_t
-        if os.environ.get("TTSAMD_CONV_PIPELINE"):      # 0 | 1 | 2, see ttsamd_conv1d_set_pipeline
-            _lib.ttsamd_conv1d_set_pipeline(int(os.environ["TTSAMD_CONV_PIPELINE"]))
     return _lib
 
 

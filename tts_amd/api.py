@@ -20,17 +20,45 @@ class TTS:
 
     @property
     def is_multi_speaker(self):
-        return False
+        """api.py:84-93: the loaded model's speaker manager decides."""
+        m = getattr(self.synthesizer.tts_model, "speaker_manager", None)
+        return m is not None and m.num_speakers > 1
 
     @property
     def is_multi_lingual(self):
-        return False
+        """api.py:95-107 (the XTTS / config.languages clauses concern models this build does not carry)."""
+        m = getattr(self.synthesizer.tts_model, "language_manager", None)
+        return m is not None and m.num_languages > 1
+
+    @property
+    def speakers(self):
+        return self.synthesizer.tts_model.speaker_manager.speaker_names if self.is_multi_speaker else None
+
+    @property
+    def languages(self):
+        return self.synthesizer.tts_model.language_manager.language_names if self.is_multi_lingual else None
+
+    def _check_arguments(self, speaker=None, language=None, speaker_wav=None, emotion=None, speed=None, **kwargs):
+        """api.py:215-235, same messages."""
+        if self.is_multi_speaker and (speaker is None and speaker_wav is None):
+            raise ValueError("Model is multi-speaker but no `speaker` is provided.")
+        if self.is_multi_lingual and language is None:
+            raise ValueError("Model is multi-lingual but no `language` is provided.")
+        if not self.is_multi_speaker and speaker is not None and "voice_dir" not in kwargs:
+            raise ValueError("Model is not multi-speaker but `speaker` is provided.")
+        if not self.is_multi_lingual and language is not None:
+            raise ValueError("Model is not multi-lingual but `language` is provided.")
+        if emotion is not None and speed is not None:
+            raise ValueError("Emotion and speed can only be used with Coqui Studio models. Which is discontinued.")
 
     def tts(self, text, speaker=None, language=None, speaker_wav=None, emotion=None, speed=None, split_sentences=True,
             **kwargs):
-        if speaker or language or speaker_wav:
-            raise ValueError("Model is not multi-speaker / multi-lingual.")     # api.py:215-235 _check_arguments
-        return self.synthesizer.tts(text=text, split_sentences=split_sentences, **kwargs)
+        """api.py:237-288: names go to the Synthesizer as speaker_name / language_name."""
+        self._check_arguments(speaker=speaker, language=language, speaker_wav=speaker_wav, emotion=emotion, speed=speed,
+                              **kwargs)
+        return self.synthesizer.tts(text=text, speaker_name=speaker, language_name=language, speaker_wav=speaker_wav,
+                                    reference_wav=None, style_wav=None, style_text=None, reference_speaker_name=None,
+                                    split_sentences=split_sentences, **kwargs)
 
     def tts_to_file(self, text, speaker=None, language=None, speaker_wav=None, emotion=None, speed=1.0, pipe_out=None,
                     file_path="output.wav", split_sentences=True, **kwargs):

@@ -245,12 +245,8 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
         return TTSAMD_ERR_UNSUPPORTED;
     }
     auto kern = rel_attention_kernel<DK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_attr_done{0};   // per device, see ensure_dynamic_lds
+    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)(160 * 1024), lds_attr_done));
     hipLaunchKernelGGL(kern, dim3(ntiles, heads, batch), dim3(kAttThreads), lds, st, out, q, k, v, bstride, mask,
                        ek, ev, window, heads, dk, T, pitch);
     TTSAMD_LAUNCH_CHECK();

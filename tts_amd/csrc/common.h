@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -34,6 +35,21 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 #define TTSAMD_LAUNCH_CHECK() TTSAMD_HIP(hipGetLastError())
 
 constexpr int kWave = 64;  // CDNA wavefront width
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device).  `done` is a per-call-site
+// bit mask of devices already configured (one static per template instantiation); the attribute call is idempotent, so a
+// race between two host threads costs a redundant call, never a missed one.
+inline hipError_t ensure_dynamic_lds(const void *kern, int bytes, std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 constexpr int kBufOob = 0x7FFFFFF0;  // buffer offset of an invalid lane: the hardware range check drops it / reads 0

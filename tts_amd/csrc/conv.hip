@@ -5,17 +5,6 @@
 
 using namespace ttsamd;
 
-namespace ttsamd {
-int g_conv_pipeline = 0;   // measured end to end (bench.py --pipeline 0|1|2): 95.1 / 95.2 / 97.9 ms per step -> off by default
-}
-
-extern "C" int ttsamd_conv1d_set_pipeline(int on)
-{
-    const int was = g_conv_pipeline;
-    g_conv_pipeline = on < 0 ? 0 : (on > 2 ? 2 : on);
-    return was;
-}
-
 extern "C" int ttsamd_conv1d_supported(int kernel, int dilation)
 {
     switch (kernel) {

@@ -2,7 +2,6 @@
 #pragma once
 #include "conv_kernel.h"
 #include "conv_kernel_x3.h"
-#include "conv_kernel_x3p.h"
 
 namespace ttsamd {
 
@@ -18,9 +17,6 @@ inline int conv1d_mode_unsupported(const ttsamd_conv1d_args &a)
 template <int K, int D, int MODE>
 int conv1d_launch_prec(const ttsamd_conv1d_args &a, hipStream_t st)
 {
-    if constexpr (MODE == TTSAMD_CONV_NORMAL) {
-        if (a.w_split && g_conv_pipeline && conv1d_x3p_eligible(a)) return conv1d_x3p_launch_tiles<K, D>(a, st);
-    }
     if (a.w_split) return conv1d_x3_launch_tiles<K, D, MODE>(a, st);
     return conv1d_launch_tiles<K, D, MODE>(a, st);
 }

@@ -229,12 +229,8 @@ int conv1d_x3_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     using G = ConvGeomX3<K, D, MI, NI, WM, WN>;
     auto kern = conv1d_x3_kernel<K, D, MI, NI, WM, WN, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TTSAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLdsBytes));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_attr_done{0};   // per device, see ensure_dynamic_lds
+    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)G::kLdsBytes, lds_attr_done));
     const int mtiles = (a.c_out + 31) / 32;
     const int mblocks = (mtiles + MI * WM - 1) / (MI * WM);
     const int nblocks = (a.t_out + G::kBN - 1) / G::kBN;

@@ -1,13 +1,21 @@
 """hipGraph capture of launch-bound segments (the text encoder + duration predictor is ~170 tiny launches whose
-host-side issue cost exceeds their GPU time).  The segment is captured once per input shape on torch's capture
-stream — every kernel of this package is launched on `torch.cuda.current_stream()`, so plain HIP stream capture
-records them — and replayed as ONE graph launch.  Inputs are copied into static buffers; outputs alias static
-buffers and are valid until the next replay of the same graph."""
+host-side issue cost exceeds their GPU time).  A segment is captured per input shape on torch's capture stream —
+every kernel of this package is launched on `torch.cuda.current_stream()`, so plain HIP stream capture records them —
+and replayed as ONE graph launch.  Inputs are copied into static buffers; outputs alias static buffers and are valid
+until the next replay of the same graph.
+
+Capture is not free (two warm-up runs, a capture run, and `torch.cuda.graph` entry synchronises the device and empties
+the allocator cache — which also stalls the other request lane), and real traffic brings a new text length with almost
+every request.  So a shape is captured only once it has been seen `capture_after` times; until then — and whenever
+capture fails — the segment runs as eager launches."""
+import collections
+
 import torch
 
 
 class GraphedSegment:
     def __init__(self, fn, example_inputs):
+        self.stream = torch.cuda.current_stream()
         self.static_in = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -25,14 +33,31 @@ class GraphedSegment:
         self.graph.replay()
         return self.static_out
 
+    def release(self):
+        """Before the graph, its private pool and its static outputs go away: the stream that replays it may still have
+        consumers of those buffers queued (request lanes)."""
+        self.stream.synchronize()
+
 
 class GraphCache:
-    """Shape-keyed cache of captured segments with an eager escape hatch (capture disabled or failed)."""
+    """Shape-keyed LRU cache of captured segments with an eager escape hatch (disabled, shape not yet hot, capture failed)."""
 
-    def __init__(self, fn, max_entries=16):
-        self.fn, self.max_entries = fn, max_entries
-        self.entries = {}
+    def __init__(self, fn, max_entries=16, capture_after=2):
+        self.fn, self.max_entries, self.capture_after = fn, max_entries, capture_after
+        self.entries = collections.OrderedDict()    # key -> GraphedSegment, least recently used first
+        self.hits = collections.OrderedDict()       # key -> times seen (not captured yet)
+        self.failed = set()                         # keys whose capture raised: eager from then on
         self.enabled = True
+        self.stats = {"replays": 0, "eager": 0, "captures": 0, "capture_failures": 0, "evictions": 0}
+
+    def clear(self):
+        """Drop every captured graph (they hold raw pointers to the weights they were captured with: call this whenever
+        the weights are re-packed)."""
+        for seg in self.entries.values():
+            seg.release()
+        self.entries.clear()
+        self.hits.clear()
+        self.failed.clear()
 
     def __call__(self, *inputs, key=None):
         """`key`: extra hashable state the captured launches depend on (scalars baked into the graph)."""
@@ -42,8 +67,34 @@ class GraphCache:
         # not share the static input / output buffers of a graph
         key = (key, torch.cuda.current_stream().cuda_stream) + tuple((tuple(t.shape), t.dtype) for t in inputs)
         seg = self.entries.get(key)
-        if seg is None:
-            if len(self.entries) >= self.max_entries:
-                self.entries.pop(next(iter(self.entries)))
-            seg = self.entries[key] = GraphedSegment(self.fn, inputs)
+        if seg is not None:
+            self.entries.move_to_end(key)
+            self.stats["replays"] += 1
+            return seg(*inputs)
+        if key in self.failed:
+            self.stats["eager"] += 1
+            return self.fn(*inputs)
+        n = self.hits.get(key, 0) + 1
+        if n < self.capture_after:
+            self.hits[key] = n
+            self.hits.move_to_end(key)
+            while len(self.hits) > 8 * self.max_entries:
+                self.hits.popitem(last=False)
+            self.stats["eager"] += 1
+            return self.fn(*inputs)
+        self.hits.pop(key, None)
+        while len(self.entries) >= self.max_entries:
+            _, old = self.entries.popitem(last=False)
+            old.release()
+            self.stats["evictions"] += 1
+        try:
+            seg = GraphedSegment(self.fn, inputs)
+        except Exception:                            # capture is an optimisation: never fail the request over it
+            self.failed.add(key)
+            self.stats["capture_failures"] += 1
+            torch.cuda.synchronize()
+            self.stats["eager"] += 1
+            return self.fn(*inputs)
+        self.entries[key] = seg
+        self.stats["captures"] += 1
         return seg(*inputs)

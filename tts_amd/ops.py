@@ -87,12 +87,6 @@ def conv_precision():
     return _PRECISION
 
 
-def set_conv_pipeline(on):
-    """Split-bf16 NORMAL-mode convs: 0 (default) = one block per tile, 1 = persistent epilogue-pipelined kernel on the
-    128-row layers, 2 = on every eligible launch.  Returns the previous setting (ttsamd_conv1d_set_pipeline)."""
-    return int(lib().ttsamd_conv1d_set_pipeline(int(on)))
-
-
 class PackedConv:
     """A conv layer's weights in MFMA fragment order on the device (+ bias in packed-row order): the fp32 image and
     the split-bf16 image."""

@@ -24,6 +24,8 @@ from .text import TTSTokenizer
 from .vits import Vits, _get
 
 _MODELS = {"vits": Vits, "glow_tts": GlowTTS}
+# titles that precede a name: a period after them never ends a sentence (pysbd English PREPOSITIVE_ABBREVIATIONS)
+_PREPOSITIVE_ABBREVIATIONS = frozenset("adm attys brig capt cmdr col cpl det dr gen gov ing lt maj mr mrs ms mt messrs mssrs prof ph rep reps rev sen sens sgt st supt v vs".split())
 
 
 def load_config(path):
@@ -92,9 +94,59 @@ class Synthesizer:
 
     @staticmethod
     def split_into_sentences(text):
-        """synthesizer.py:227-236 uses pysbd (not installed): split after sentence-final punctuation."""
-        parts = re.split(r"(?<=[.!?])\s+", text.strip())
-        return [p for p in parts if p]
+        """synthesizer.py:227-236 segments with `pysbd.Segmenter(language="en", clean=True)`; pysbd is not in this image,
+        so this is a rule-based restatement of the English behaviour the reference's own test pins
+        (tests/inference_tests/test_synthesizer.py:29-79 — all 17 golden strings are checked in tests/test_host_cpu.py):
+          * a boundary is sentence-final punctuation (+ closing quotes / brackets) followed by whitespace and a token that
+            does not start with a lowercase letter;
+          * titles that precede a name (dr., mr., mrs., ...) never end a sentence; other abbreviations (co., jr., U.K.)
+            do when a capitalised word follows — pysbd's prepositive / other abbreviation split;
+          * runs of list markers `1.) 2.)`, `1) 2)`, `1. 2.`, `a. b. c.` start a new segment each.
+        Known differences from pysbd: no per-language rule sets (`_get_segmenter(lang)`), no ellipsis / parenthetical /
+        exclamation-word ("Yahoo!") tables beyond the lowercase-follows rule."""
+        text = re.sub(r"\s+", " ", text.strip())
+        if not text:
+            return []
+        # ---- list markers: consecutive 1,2,3.. or a,b,c.. at token starts -------------------------------------------
+        cuts = []
+        for rx, seq in ((r"(?:(?<=\s)|^)(\d{1,2})(?:\.\)|\)|\.)(?=\s)", lambda k: str(k + 1)),
+                        (r"(?:(?<=\s)|^)([a-z])(?:\.|\))(?=\s)", lambda k: chr(ord("a") + k))):
+            ms, k = [], 0
+            for m in re.finditer(rx, text):
+                if m.group(1) == seq(k):
+                    ms.append(m)
+                    k += 1
+            if len(ms) >= 2:
+                cuts = [(m.start(), m.end()) for m in ms]
+                break
+        segments = []
+        if cuts:
+            if cuts[0][0] > 0:
+                segments.append((text[: cuts[0][0]], 0))
+            for i, (a, b) in enumerate(cuts):
+                end = cuts[i + 1][0] if i + 1 < len(cuts) else len(text)
+                segments.append((text[a:end], b - a))            # (segment, length of its protected marker prefix)
+        else:
+            segments.append((text, 0))
+        # ---- punctuation boundaries inside each segment --------------------------------------------------------------
+        out = []
+        for seg, keep in segments:
+            seg = seg.strip()
+            start = 0
+            for m in re.finditer(r"[.!?]+[\"'\u201d\u2019)\]]*(?=\s)", seg):
+                if m.start() < keep:
+                    continue
+                nxt = seg[m.end():].lstrip()
+                if not nxt or nxt[0].islower():
+                    continue
+                word = re.search(r"([A-Za-z.]+)$", seg[start:m.start()])
+                if word and seg[m.start()] == "." and word.group(1).lower().rstrip(".") in _PREPOSITIVE_ABBREVIATIONS:
+                    continue
+                out.append(seg[start:m.end()].strip())
+                start = m.end()
+            if seg[start:].strip():
+                out.append(seg[start:].strip())
+        return out
 
     def save_wav(self, wav, path, pipe_out=None):
         AudioProcessor.save_wav(np.asarray(wav), path, self.output_sample_rate, pipe_out)
@@ -140,12 +192,14 @@ class Synthesizer:
                 # recompute_scale_factor=True == linear interpolation along time only
                 from . import ops as _ops
 
-                if len(ids) > 1:
-                    raise _lib.TtsAmdError("sample-rate interpolation of the vocoder input is per sentence: "
-                                           "call with one sentence at a time (split_sentences) for this model pair")
-                voc_in = _ops.linear_interp(voc_in[:, :, : int(frames[0])].contiguous(), sr_v / sr_t,
-                                            recompute_scale_factor=True)
-                frames = torch.tensor([voc_in.shape[2]], device=voc_in.device)
+                # per sentence, like the reference's sentence loop: each row's valid frames are interpolated on their own
+                # and the results re-assembled into one ragged batch for the vocoder
+                rows = [_ops.linear_interp(voc_in[r:r + 1, :, : int(frames[r])].contiguous(), sr_v / sr_t,
+                                           recompute_scale_factor=True) for r in range(len(ids))]
+                frames = torch.tensor([t.shape[2] for t in rows], device=voc_in.device)
+                voc_in = torch.zeros((len(ids), voc_in.shape[1], int(frames.max())), dtype=torch.float32, device=voc_in.device)
+                for r, t in enumerate(rows):
+                    voc_in[r, :, : t.shape[2]] = t[0]
                 mel = voc_in
             wav = self.vocoder_model.model_g.inference(voc_in, lengths=frames)
             pad = self.vocoder_model.model_g.inference_padding

@@ -140,6 +140,8 @@ class Vits:
         if self.device.type != "cuda":
             raise _lib.TtsAmdError("tts_amd.Vits runs only on a GPU (no CPU fallback)")
         a, sd, dev = self.args, self._sd, self.device
+        # captured front-end graphs hold raw pointers to the weight tensors replaced below: drop them first
+        self._front.clear()
         self.text_encoder = layers.TextEncoder(sd, "text_encoder.", dev, a.hidden_channels, a.num_layers_text_encoder,
                                                a.num_heads_text_encoder, a.kernel_size_text_encoder)
         spk = self.embedded_speaker_dim
