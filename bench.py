@@ -2,7 +2,10 @@
 """Headline benchmark (BASELINE.json): audio samples/s + real-time factor of LJSpeech-shaped VITS
 end-to-end inference (text ids -> waveform, 22.05 kHz) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N>1 without a torchrun environment: bench.py re-launches itself as N ranks under torch.distributed.run
+        (one process per GPU, RCCL); under torchrun (WORLD_SIZE set) it is one of those ranks and --gpus must match.
+    python bench.py --workload glow_hifigan_v2 | hifigan_v1 | mas | xtts_stream   (the other BASELINE configs)
 
 A "step" = one full `Vits.inference` pass (text encoder, stochastic duration predictor, prior expansion incl.
 both random draws, 4 coupling flows, HiFiGAN waveform decoder) over a batch of 32 synthetic utterances of
@@ -13,13 +16,19 @@ released checkpoint).  Output length is pinned with the synthetic duration patte
 inside the timed region, nothing is skipped.
 
 N GPUs = N independent replicas (one process per GPU), each with its own 32-utterance shard (weak scaling);
-the only collective is the one-time weight broadcast from rank 0 (RCCL), outside the timed region.
+the only collective is the one-time weight broadcast from rank 0 (RCCL), outside the timed region (its time and
+size are reported in `config`).
 
-Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" + "cpu_baseline", see README/DESIGN.md).
+Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" + "cpu_baseline", see README/DESIGN.md).  At N=1 the
+default invocation also measures BASELINE configs[0] (Glow-TTS + HiFiGAN-v2, one 64-char sentence, CPU oracle beside
+it) and configs[2] (HiFiGAN-v1 vocoder only, 256 x 8192-frame mels) and carries their lines under "extra_workloads"
+(`--no-extras` skips them).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +41,7 @@ if ROOT not in sys.path:
 SAMPLE_RATE = 22050
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
+PEAK_HBM_GBPS = 8000.0          # same guide: HBM3E spec peak (a float4 copy reaches 6.29 TB/s)
 X3_PRODUCTS = 6                 # bf16 MFMA products issued per fp32 product by the split-bf16 kernels (conv_kernel_x3.h)
 DTYPE = {"x3": "f32 (conv products: both fp32 operands split 3-way into bf16, 6 products on the bf16 MFMA, fp32 "
                "accumulate; fp32-class accuracy, same parity tolerances as --precision f32)",
@@ -46,9 +56,121 @@ def conv_peak(precision):
 
 def conv_kernel_name(precision, tmpl):
     return ("ttsamd::conv1d_x3_kernel<%s>" if precision == "x3" else "ttsamd::conv1d_mfma_kernel<%s>") % tmpl
-PEAK_HBM_GBPS = 8000.0
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher + distributed context (replicas, one process per GPU, one weight broadcast, no data-path collective)
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside torchrun: become the launcher — N ranks of this same script under
+    torch.distributed.run on 127.0.0.1 — and exit with its return code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+class Ctx:
+    """One rank of the job: device, process group, and the timing contract (barrier + synchronize on both sides of the
+    timed region, MAX over ranks of the elapsed time, SUM over ranks of the units processed)."""
+
+    def __init__(self, args):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, self.world))
+        self.backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        self.gpu = torch.cuda.is_available() and self.backend != "gloo"
+        if self.gpu:
+            n_dev = torch.cuda.device_count()
+            if n_dev < self.world or self.local_rank >= n_dev:
+                raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (self.world, n_dev))
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        else:
+            self.dev = torch.device("cpu")
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"device_id": self.dev} if self.backend == "nccl" else {}
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        if self.gpu:
+            torch.cuda.synchronize()
+
+    def _reduce(self, v, op):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def max(self, v):
+        return self._reduce(v, self.dist.ReduceOp.MAX)
+
+    def sum(self, v):
+        return self._reduce(v, self.dist.ReduceOp.SUM)
+
+    def broadcast_weights(self, make_sd):
+        """rank 0 builds the synthetic checkpoint, everyone else receives it as ONE flat fp32 blob (tts_amd.parallel).
+        -> (state_dict, seconds, bytes); the broadcast is outside every timed region."""
+        from tts_amd import parallel
+
+        sd = make_sd() if self.rank == 0 else None
+        self.fence()
+        t0 = time.perf_counter()
+        sd = parallel.broadcast_state_dict(sd, src=0, device=self.dev)
+        self.fence()
+        dt = time.perf_counter() - t0
+        return sd, self.max(dt), 4 * sum(v.numel() for v in sd.values())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def base_line(args, ctx, metric, value, unit, elapsed_max, workload, dtype, higher=True, **cfg):
+    return {"metric": metric, "value": value, "unit": unit, "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": higher, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": dict({"workload": workload, "parallelism": "replicas x%d" % ctx.world}, **cfg)}
+
+
+def load_pmc(name):
+    """HBM bytes per launch from the committed PMC passes (profiles/<name>, scripts/gpu_pmc_round.sh), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def timer_table(res):
+    return {k: {"launches": r["launches"], "avg_us": r["ms"] * 1e3 / r["launches"],
+                "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12, "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
+                "algorithmic_gbps": r["bytes"] / (r["ms"] * 1e-3) / 1e9,
+                "frac_of_8TBps": r["bytes"] / (r["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+            for k, r in sorted(res.items()) if r["launches"]}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[1]: VITS end to end (the headline line)
+# ---------------------------------------------------------------------------------------------------------------------
 def synthetic_batch(batch, n_chars, seed, device):
     """128-char utterances -> 2*128+1 ids with the blank id interleaved (add_blank=True, vits_config.py:146;
     tokenizer.py:126-134): blank (id 0 here) at even positions, uniform random character ids at odd ones."""
@@ -60,13 +182,17 @@ def synthetic_batch(batch, n_chars, seed, device):
     return x.to(device), torch.full((batch,), T, dtype=torch.int64, device=device), dur.to(device)
 
 
-def cpu_baseline(sd, n_chars, seconds_budget=20.0):
+def cpu_threads():
+    cores = os.cpu_count() or 1
+    return min(cores, 64), cores
+
+
+def cpu_baseline_vits(sd, n_chars, seconds_budget=20.0):
     """The CPU oracle (oracle/tts_oracle.py: torch fp32 restatement of the reference's modules, pinned to them)
     on this box's host cores, reference call pattern: one utterance at a time (synthesizer.py:384)."""
     from oracle import tts_oracle as O
 
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads, cores = cpu_threads()
     torch.set_num_threads(threads)
     x, xl, dur = synthetic_batch(1, n_chars, 0, "cpu")
     noise_dp = torch.randn(1, 2, x.shape[1])
@@ -89,136 +215,384 @@ def cpu_baseline(sd, n_chars, seconds_budget=20.0):
                       % (n, n_chars, out["model_outputs"].shape[-1], threads, cores, samples / t_used / SAMPLE_RATE)}
 
 
-def bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel):
+def wl_vits_e2e(args, ctx):
+    from tts_amd import ops, parallel
+    from tts_amd import synthetic as W
+    from tts_amd.vits import Vits
+
+    dev = ctx.dev
+    sd, bcast_s, bcast_bytes = ctx.broadcast_weights(lambda: W.make_vits_state({}, seed=1234))
+    model = Vits({"model_args": {}})
+    model.load_state_dict(sd)
+    model.to(dev)
+
+    x, xl, dur = synthetic_batch(args.batch, args.chars, seed=ctx.rank, device=dev)
+    aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True}
+    lanes = parallel.Lanes(args.lanes, device=dev, priority=args.lane_priority) if args.lanes > 1 else None
+
+    def step():
+        if lanes is not None:
+            return lanes.run(model.inference, x, aux)
+        return model.inference(x, aux)
+
+    # prime every lane twice (a front-end shape is captured into a hipGraph on its 2nd occurrence; allocator pools): untimed
+    for _ in range(2 * (args.lanes if lanes is not None else 1)):
+        step()
+    for _ in range(args.warmup):
+        out = step()
+
+    def select(pc, a):
+        # every launch that dispatches to the 128x128-block k=11 d=1 NORMAL instantiation:
+        # the ResBlock1 k=11 d=1 convs of the 256- and 128-channel MRF stages
+        if pc.kernel == 11 and pc.dilation == 1 and a.mode == 0 and ((pc.c_out + 31) // 32) % 4 == 0:
+            return "dominant"
+        # every other waveform-decoder / flow conv; the tiny text-side launches are left untouched
+        if 2.0 * pc.c_out * pc.c_in * pc.kernel * a.t_out * a.batch < 1e9:
+            return None
+        return "conv c%d k%d d%d %s" % (pc.c_in, pc.kernel, pc.dilation,
+                                        {0: "normal", 2: "convT-polyphase"}.get(a.mode, "mode%d" % a.mode))
+
+    if args.serial_branches:
+        model.waveform_decoder.concurrent_branches = False
+    ctx.fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    ctx.fence()
+    elapsed = time.perf_counter() - t0
+
+    # Roofline pass (rank 0 only, AFTER the timed region, same inputs): in the timed region the three MRF resblock
+    # branches run on three HIP streams, so an event pair around one launch also counts the kernels co-running with it.
+    # Here the branches are serialised on one stream and every conv launch of the decoder / flows is bracketed by HIP
+    # events on the stream it is launched on.
+    timer = ops.ConvTimer(select)
+    roof_steps = 2
+    lanes = None          # the roofline pass runs on the default stream, one request at a time
+    if ctx.rank == 0:
+        was = model.waveform_decoder.concurrent_branches
+        model.waveform_decoder.concurrent_branches = False
+        step()
+        torch.cuda.synchronize()
+        ops.set_conv_timer(timer)
+        for _ in range(roof_steps):
+            step()
+        torch.cuda.synchronize()
+        ops.set_conv_timer(None)
+        model.waveform_decoder.concurrent_branches = was
+
+    samples_per_step = int(out["y_mask"].sum().item()) * 256        # valid output samples of this rank's shard
+    elapsed_max, total_samples_per_step = ctx.max(elapsed), ctx.sum(samples_per_step)
+    if ctx.rank != 0:
+        return None
+    res = timer.results()
+    dom = res.get("dominant", dict(launches=0, flops=0.0, bytes=0.0, ms=1.0))
+    allc = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)
+    for r in res.values():
+        for k in allc:
+            allc[k] += r[k]
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["launches"] else 0.0
+    value = total_samples_per_step * args.steps / elapsed_max
+    line = base_line(
+        args, ctx, "audio samples/sec (LJSpeech VITS -> HiFiGAN decoder, 22.05 kHz, end-to-end inference)", value,
+        "samples/s", elapsed_max,
+        "configs[1]: LJSpeech VITS end-to-end, batch=%d random %d-char utterances per GPU (257 ids, 770 frames, 197120 "
+        "samples each), 22.05 kHz" % (args.batch, args.chars), DTYPE[args.precision],
+        utterances_per_gpu=args.batch, chars=args.chars,
+        weights="random-init VitsArgs defaults (29.1 M params)", weight_broadcast_s=bcast_s, weight_broadcast_bytes=bcast_bytes,
+        weight_broadcast_backend=ctx.backend if ctx.world > 1 else "none (1 rank)",
+        mrf_branch_streams=1 if args.serial_branches else 3, request_lanes=args.lanes,
+        fused_resblocks=bool(getattr(model.waveform_decoder, "fuse_resblocks", False)))
+    line["rtf_x"] = value / SAMPLE_RATE
+    line["rtf_x_per_gpu"] = value / SAMPLE_RATE / ctx.world
+    line["roofline"] = {
+        "bound": "mfma",
+        "kernel": conv_kernel_name(args.precision, "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0")
+                  + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
+        "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
+        "frac": ach / conv_peak(args.precision), "traffic": load_pmc("pmc_dominant_%s.json" % args.precision),
+        "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B per launch) / launch time; peak = bf16 dense "
+                      "MFMA peak 2500 TF / 6 bf16 products per fp32 product; on the matrix pipe itself: %.0f of "
+                      "2500 bf16 TFLOP/s" % (ach * X3_PRODUCTS)) if args.precision == "x3" else
+                     "fp32-input MFMA peak (= fp32 vector peak); exact fp32 arithmetic",
+        "launches_timed": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
+        "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+        "algorithmic_gbps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["launches"] else 0.0,
+        "all_conv_launches": {"launches": allc["launches"],
+                              "tflops": allc["flops"] / (allc["ms"] * 1e-3) / 1e12 if allc["ms"] else 0.0,
+                              "algorithmic_gbps": allc["bytes"] / (allc["ms"] * 1e-3) / 1e9 if allc["ms"] else 0.0,
+                              "ms_per_step": allc["ms"] / roof_steps},
+        "per_kernel": timer_table(res),
+        "measured": "%d extra steps after the timed region with the MRF branch streams serialised (in the timed "
+                    "region three branch streams overlap and inflate per-launch event times); HIP events on the "
+                    "launch stream" % roof_steps,
+    }
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_vits(sd, args.chars)
+    del model
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[0]: Glow-TTS + HiFiGAN-v2, one 64-char sentence through the mel seam, CPU oracle beside it
+# ---------------------------------------------------------------------------------------------------------------------
+def wl_glow_hifigan_v2(args, ctx):
+    """BASELINE configs[0] (SURVEY §8d "Config 1"): B=1, 64 token ids uniform in [0,130) seed 0 (Glow add_blank=False),
+    GlowTTSConfig defaults (glow_tts_config.py:101-152, 12 flow blocks), durations pinned to 4+(t mod 3) -> 318 frames,
+    AudioProcessor denormalize -> vocoder normalize seam (synthesizer.py:412-429; on the device here),
+    HifiganGenerator v2 (C0=128) with inference_padding=5 -> 83 968 samples.  A step = one sentence, the reference's own
+    call pattern (TTS/tts/models/glow_tts.py:341-374 -> TTS/utils/synthesizer.py:412-433)."""
+    from tts_amd import synthetic as W
+    from tts_amd.audio import AudioProcessor, mel_renorm_device
+    from tts_amd.glow_tts import GlowTTS
+    from tts_amd.hifigan import HifiganGenerator
+
+    dev = ctx.dev
+    hcfg = dict(W.HIFIGAN_V2)
+    gsd, t1, b1 = ctx.broadcast_weights(lambda: W.make_glow_state({}, seed=4321))
+    hsd, t2, b2 = ctx.broadcast_weights(lambda: W.make_hifigan_state(hcfg, 80, seed=1234))
+    glow = GlowTTS({})
+    glow.load_state_dict(gsd)
+    glow.to(dev)
+    voc = HifiganGenerator(80, 1, hcfg["resblock_type"], hcfg["resblock_dilation_sizes"], hcfg["resblock_kernel_sizes"],
+                           hcfg["upsample_kernel_sizes"], hcfg["upsample_initial_channel"], hcfg["upsample_factors"],
+                           inference_padding=hcfg["inference_padding"])
+    voc.load_state_dict(hsd)
+    voc.to(dev)
+    ap_t, ap_v = AudioProcessor(), AudioProcessor()
+    T = 64
+    ids = torch.randint(0, 130, (1, T), generator=torch.Generator().manual_seed(ctx.rank))
+    dur = (4 + (torch.arange(T) % 3)).float().view(1, T)
+    x, xl, d = ids.to(dev), torch.tensor([T], device=dev), dur.to(dev)
+
+    def step():
+        o = glow.inference(x, {"x_lengths": xl, "durations": d})
+        mel = mel_renorm_device(o["model_outputs"].transpose(1, 2), ap_t, ap_v)
+        return voc.inference(mel)
+
+    for _ in range(max(args.warmup, 3)):
+        wav = step()
+    ctx.fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = step()
+    ctx.fence()
+    elapsed = time.perf_counter() - t0
+    lat = []
+    for _ in range(min(args.steps, 20)):        # per-sentence latency incl. the D2H of the waveform (what a caller waits for)
+        torch.cuda.synchronize()
+        t1_ = time.perf_counter()
+        step().cpu()
+        lat.append((time.perf_counter() - t1_) * 1e3)
+    samples = wav.shape[-1]
+    elapsed_max, total = ctx.max(elapsed), ctx.sum(samples)
+    if ctx.rank != 0:
+        return None
+    value = total * args.steps / elapsed_max
+    line = base_line(args, ctx, "audio samples/sec (Glow-TTS -> mel seam -> HiFiGAN-v2, one 64-char sentence, B=1)", value,
+                     "samples/s", elapsed_max,
+                     "configs[0]: tts_models/en/ljspeech/glow-tts + vocoder_models/en/ljspeech/hifigan_v2 shape, single "
+                     "64-char sentence (64 ids, 318 frames, %d samples), B=1 sentence loop" % samples, DTYPE[args.precision],
+                     weights="random-init GlowTTSConfig defaults + HiFiGAN-v2 (C0=128)", weight_broadcast_s=t1 + t2,
+                     weight_broadcast_bytes=b1 + b2, sentence_latency_ms_p50=float(sorted(lat)[len(lat) // 2]),
+                     frames=int(wav.shape[-1] // 256 - 10))
+    line["rtf_x"] = value / SAMPLE_RATE
+    # 20.4 GFLOP per sentence (SURVEY §8d, FlopCounter on the reference modules); a B=1 sentence is launch/latency-bound
+    # on this chip, the fraction is reported for completeness
+    ach = 20.4e9 * args.steps * ctx.world / elapsed_max / 1e12
+    line["roofline"] = {"bound": "mfma", "kernel": "whole sentence at B=1 (~330 launches): launch / latency-bound",
+                        "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
+                        "frac": ach / conv_peak(args.precision), "traffic": None}
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        from oracle import tts_oracle as O
+
+        threads, cores = cpu_threads()
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            def cpu_step():
+                o = O.glow_tts_inference(gsd, ids, torch.tensor([T]), {}, durations=dur.view(1, 1, T))
+                mel = o["model_outputs"][0].numpy()                                   # [T, C]
+                voc_in = ap_v.normalize(ap_t.denormalize(mel.T))                      # synthesizer.py:414-416 (numpy seam)
+                return O.hifigan_inference(hsd, "", torch.from_numpy(voc_in).unsqueeze(0), hcfg)
+            w = cpu_step()
+            n, t0 = 0, time.perf_counter()
+            while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 30):
+                w = cpu_step()
+                n += 1
+            dt = (time.perf_counter() - t0) / n
+        line["cpu_baseline"] = {"value": w.shape[-1] / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+                                "sample": "%d x the same sentence (%d samples) through the oracle + numpy seam, %d torch "
+                                          "threads of %d host cores, %.1f ms per sentence (SURVEY §8d measured 127 ms on 8 "
+                                          "threads with the reference modules)" % (n, w.shape[-1], threads, cores, dt * 1e3)}
+    del glow, voc
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[2]: HiFiGAN-v1 vocoder only, 256 x 8192-frame mels
+# ---------------------------------------------------------------------------------------------------------------------
+def hbm_subset_key(pc, a):
+    """Launches of the vocoder that are HBM-bound rather than matrix-bound (MRF3 k=3 at C=32, conv_post,
+    ups[3]); fused ResBlock pairs are keyed by ops.resblock_pair itself."""
+    if pc.c_out == 1:
+        return "conv_post (32->1, k=7, tanh)"
+    if a.mode == 2 and pc.c_in == 64:
+        return "ups[3] polyphase ConvTranspose (64->32)"
+    if pc.c_in <= 32 and pc.kernel == 3 and a.mode == 0:
+        return "MRF3 conv k=3 d=%d (32->32)" % pc.dilation
+    return None
+
+
+def wl_hifigan_v1(args, ctx):
     """BASELINE configs[2]: HiFiGAN-v1 vocoder only on precomputed 80-bin mels, batch 256 x 8192 frames per GPU
     (hifigan_config.py:95-104 generator, inference_padding 5, weight-norm folded).  The layer-by-layer live set of the
     literal shape is 6 x 69 GB, so the batch runs in slabs (HifiganGenerator.inference_slabbed); mels resident in HBM."""
+    from tts_amd import ops
+    from tts_amd import synthetic as W
     from tts_amd.hifigan import HifiganGenerator
 
+    dev = ctx.dev
     cfg = dict(W.HIFIGAN_V1)
-    sd = W.make_hifigan_state(cfg, 80, seed=1234) if rank == 0 else None
-    sd = parallel.broadcast_state_dict(sd, src=0, device=dev)
+    sd, bcast_s, bcast_bytes = ctx.broadcast_weights(lambda: W.make_hifigan_state(cfg, 80, seed=1234))
     m = HifiganGenerator(80, 1, cfg["resblock_type"], cfg["resblock_dilation_sizes"], cfg["resblock_kernel_sizes"],
                          cfg["upsample_kernel_sizes"], cfg["upsample_initial_channel"], cfg["upsample_factors"],
                          inference_padding=cfg["inference_padding"])
     m.load_state_dict(sd)
     m.to(dev)
-    mel = torch.randn(args.items, 80, args.frames, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+    mel = torch.randn(args.items, 80, args.frames, device=dev, generator=torch.Generator(device=dev).manual_seed(ctx.rank))
     out = torch.empty((args.items, 1, (args.frames + 10) * 256), dtype=torch.float32, device=dev)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    steps = args.hifigan_steps or args.steps
+    warm = args.warmup if args.hifigan_warmup is None else args.hifigan_warmup
+    for _ in range(warm):
         m.inference_slabbed(mel, out)
     timer = ops.ConvTimer(lambda pc, a: "conv")
     ops.set_conv_timer(timer)
-    fence()
+    ctx.fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         m.inference_slabbed(mel, out)
-    fence()
+    ctx.fence()
     elapsed = time.perf_counter() - t0
     ops.set_conv_timer(None)
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        r = timer.results()["conv"]
-        samples = float(out.shape[0] * out.shape[2]) * world
-        value = samples * args.steps / float(tt.item())
-        print(json.dumps({
-            "metric": "audio samples/sec (HiFiGAN-v1 vocoder only, 80-bin mels -> 22.05 kHz waveform)", "value": value,
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": float(tt.item()) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic", "rtf_x": value / SAMPLE_RATE,
-            "config": {"workload": "configs[2]: HiFiGAN-v1 vocoder only, batch=%d x %d-frame mels per GPU, slabbed"
-                                   % (args.items, args.frames), "parallelism": "replicas x%d" % world},
-            # the MRF branches run on three HIP streams here, so per-launch event times overlap; the aggregate is priced
-            # on the wall clock of the timed region instead (a lower bound on the conv kernels' own rate)
-            "roofline": {"bound": "mfma", "kernel": "all conv launches of the generator (%s)" % conv_kernel_name(args.precision, "..."),
-                         "achieved": r["flops"] / float(tt.item()) / 1e12, "peak": conv_peak(args.precision),
-                         "unit": "TFLOP/s", "frac": r["flops"] / float(tt.item()) / 1e12 / conv_peak(args.precision),
-                         "traffic": None, "algorithmic_gbps": r["bytes"] / float(tt.item()) / 1e9,
-                         "launches_timed": r["launches"],
-                         "measured": "algorithmic conv FLOP of the timed steps / wall time of the timed region"}}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    elapsed_max = ctx.max(elapsed)
+
+    # HBM-roofline pass for the launches that are NOT matrix-bound: one slab, MRF branches serialised on one stream,
+    # HIP events around each of those launches on the launch stream.
+    sub = None
+    if ctx.rank == 0:
+        n_slab = min(args.items, 16)
+        was = m.concurrent_branches
+        m.concurrent_branches = False
+        m.inference(mel[:n_slab])
+        torch.cuda.synchronize()
+        st = ops.ConvTimer(hbm_subset_key)
+        ops.set_conv_timer(st)
+        m.inference(mel[:n_slab])
+        torch.cuda.synchronize()
+        ops.set_conv_timer(None)
+        m.concurrent_branches = was
+        sub = timer_table(st.results())
+    if ctx.rank != 0:
+        return None
+    r = timer.results()["conv"]
+    samples = float(out.shape[0] * out.shape[2]) * ctx.world
+    value = samples * steps / elapsed_max
+    line = base_line(args, ctx, "audio samples/sec (HiFiGAN-v1 vocoder only, 80-bin mels -> 22.05 kHz waveform)", value,
+                     "samples/s", elapsed_max,
+                     "configs[2]: HiFiGAN-v1 vocoder only, batch=%d x %d-frame mels per GPU, slabbed" % (args.items, args.frames),
+                     DTYPE[args.precision], weight_broadcast_s=bcast_s, weight_broadcast_bytes=bcast_bytes,
+                     fused_resblocks=bool(getattr(m, "fuse_resblocks", False)))
+    line["steps"], line["warmup"], line["ms_per_step"] = steps, warm, elapsed_max / steps * 1e3
+    line["rtf_x"] = value / SAMPLE_RATE
+    # the MRF branches run on three HIP streams here, so per-launch event times overlap; the aggregate is priced
+    # on the wall clock of the timed region instead (a lower bound on the conv kernels' own rate)
+    ach = r["flops"] / elapsed_max / 1e12
+    line["roofline"] = {"bound": "mfma", "kernel": "all conv launches of the generator (%s)" % conv_kernel_name(args.precision, "..."),
+                        "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
+                        "frac": ach / conv_peak(args.precision), "traffic": load_pmc("pmc_hifigan_v1_%s.json" % args.precision),
+                        "algorithmic_gbps": r["bytes"] / elapsed_max / 1e9, "launches_timed": r["launches"],
+                        "measured": "algorithmic conv FLOP of the timed steps / wall time of the timed region",
+                        "hbm_subset": {"note": "launches bound by HBM, not the matrix pipe (SURVEY App. A): algorithmic bytes "
+                                               "(input + output (+ residual / accumulate) read or written once) / HIP-event "
+                                               "time, one 16-item slab, branches serialised; peak 8000 GB/s (a float4 copy "
+                                               "reaches 6290)",
+                                       "launches": sub}}
+    del m
+    return line
 
 
-def bench_mas(args, world, rank, dev, dist):
-    """The `maximum_path` operator alone (BASELINE.md "MAS" row): randn [32,257,770] fp32, ragged t_x in [200,257],
+# ---------------------------------------------------------------------------------------------------------------------
+# MAS alone, XTTS streaming (vocoder half)
+# ---------------------------------------------------------------------------------------------------------------------
+def wl_mas(args, ctx):
+    """The `maximum_path` operator alone (BASELINE.md "MAS" row): randn [B,257,770] fp32, ragged t_x in [200,257],
     t_y in [600,770], seed 0.  HBM-bound: 12 B per band cell (value read + in-place write + path write)."""
     import numpy as np
 
     from tts_amd import helpers
 
-    B, TX, TY = 32, 257, 770
-    rng = np.random.default_rng(rank)
+    B, TX, TY = args.mas_batch, 257, 770
+    rng = np.random.default_rng(ctx.rank)
     tx = rng.integers(200, TX + 1, B)
     ty = rng.integers(600, TY + 1, B)
     tx[0], ty[0] = TX, TY
     mask = ((np.arange(TX)[None, :, None] < tx[:, None, None]) & (np.arange(TY)[None, None, :] < ty[:, None, None]))
-    mask_t = torch.from_numpy(mask.astype(np.float32)).to(dev)
-    value = torch.randn(B, TX, TY, device=dev)
+    mask_t = torch.from_numpy(mask.astype(np.float32)).to(ctx.dev)
+    value = torch.randn(B, TX, TY, device=ctx.dev)
     cells = float(sum(int(a) * int(b) - int(a) * (int(a) - 1) for a, b in zip(tx, ty)))   # band-limited cell count
     for _ in range(max(args.warmup, 1)):
         helpers.maximum_path(value, mask_t)
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
-        dist.barrier()
+    ctx.fence()
     e0.record()
     for _ in range(args.steps):
-        path = helpers.maximum_path(value, mask_t)
+        helpers.maximum_path(value, mask_t)
     e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / args.steps
-    line = {"metric": "monotonic alignment search, DP cells/s (maximum_path on [32,257,770])", "value": cells * world / (ms * 1e-3),
-            "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32->int32", "data": "synthetic",
-            "config": {"workload": "maximum_path(value, mask), B=32, T_x<=257, T_y<=770, ragged"},
-            "roofline": {"bound": "hbm", "achieved": 12.0 * cells / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": 12.0 * cells / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "traffic": None,
-                         "note": "one workgroup per item (32 items): the DP is a serial column sweep per item, i.e. "
-                                 "latency-bound, not bandwidth-bound, at this batch size"}}
-    if world == 1 and not args.no_cpu_baseline:
+    ctx.fence()
+    ms = ctx.max(e0.elapsed_time(e1)) / args.steps
+    if ctx.rank != 0:
+        return None
+    line = base_line(args, ctx, "monotonic alignment search, DP cells/s (maximum_path on [%d,257,770])" % B,
+                     cells * ctx.world / (ms * 1e-3), "cells/s", ms * 1e-3 * args.steps,
+                     "maximum_path(value, mask), B=%d, T_x<=257, T_y<=770, ragged" % B, "f32->int32")
+    gbps = 12.0 * cells / (ms * 1e-3) / 1e9
+    line["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                        "traffic": None,
+                        "note": "the DP is a serial sweep over T_y per item (770 dependent steps): latency-bound unless "
+                                "the batch fills the chip"}
+    if ctx.world == 1 and not args.no_cpu_baseline:
         from oracle import mas as omas
 
-        v, m = value.cpu().numpy(), mask.astype(np.float32)
-        omas.maximum_path(v, m, "c")
+        nb = min(B, 32)
+        v, mm = value[:nb].cpu().numpy(), mask[:nb].astype(np.float32)
+        c32 = float(sum(int(a) * int(b) - int(a) * (int(a) - 1) for a, b in zip(tx[:nb], ty[:nb])))
+        omas.maximum_path(v, mm, "c")
         t0 = time.time()
-        n = 3
-        for _ in range(n):
-            omas.maximum_path(v, m, "c")
-        dt = (time.time() - t0) / n
-        line["cpu_baseline"] = {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-                                "sample": "same problem, C restatement of core.pyx (single thread, as the reference ships it)"}
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        for _ in range(3):
+            omas.maximum_path(v, mm, "c")
+        dt = (time.time() - t0) / 3
+        line["cpu_baseline"] = {"value": c32 / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                                "sample": "first %d items of the same problem, C restatement of core.pyx (single thread, as "
+                                          "the reference ships it)" % nb}
+    return line
 
 
-def bench_xtts_stream(args, world, rank, dev, dist, W):
+def wl_xtts_stream(args, ctx):
     """Vocoder half of BASELINE configs[4] (XTTS-v2 streaming; the GPT-2 half is out of scope): one
     sentence of 200 synthetic GPT latents [1024], stream_chunk_size=20, overlap 1024 (xtts.py:609-616 defaults) through
     the XTTS-v2 HifiDecoder (1024 -> 512 ch, ups 8,8,2,2, d-vector 512).  A "step" is one streamed sentence; the metric
     is the wall time from "chunk's last latent available" to "chunk's waveform on the host", p50 over chunks."""
     import numpy as np
 
+    from tts_amd import synthetic as W
     from tts_amd.xtts_decoder import HifiDecoder
     from tts_amd.xtts_stream import XttsStreamer
 
+    dev = ctx.dev
     sd, cfg = W.make_hifi_decoder_state(seed=31)
     dec = HifiDecoder()
     dec.load_state_dict(sd)
     dec.to(dev)
-    gen = torch.Generator().manual_seed(rank)
+    gen = torch.Generator().manual_seed(ctx.rank)
     lat = torch.randn(200, 1024, generator=gen).to(dev)
     g = torch.randn(1, 512, 1, generator=gen).to(dev)
 
@@ -241,9 +615,7 @@ def bench_xtts_stream(args, world, rank, dev, dist, W):
     for _ in range(max(args.warmup, 1)):
         run(True)
         run(False)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    ctx.fence()
     t0 = time.perf_counter()
     first, rest, samples = [], [], 0
     for _ in range(args.steps):
@@ -251,33 +623,29 @@ def bench_xtts_stream(args, world, rank, dev, dist, W):
         first.append(l[0])
         rest += l[1:]
         samples += n
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    ctx.fence()
+    wall = ctx.max(time.perf_counter() - t0)
     ref_first, ref_rest = [], []
     for _ in range(args.steps):
         l, _, frames_f = run(False)
         ref_first.append(l[0])
         ref_rest += l[1:]
-    line = {"metric": "XTTS-v2 streaming, vocoder half: p50 first-chunk latency (20 latents -> waveform on host)",
-            "value": float(np.median(first)), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[4] vocoder half: 200 GPT latents/sentence, stream_chunk_size=20, "
-                                   "overlap_wav_len=1024, HifiDecoder 1024->512ch, tail-window schedule",
-                       "p50_later_chunk_ms": float(np.median(rest)), "max_later_chunk_ms": float(np.max(rest)),
-                       "reference_schedule_p50_first_ms": float(np.median(ref_first)),
-                       "reference_schedule_p50_later_ms": float(np.median(ref_rest)),
-                       "reference_schedule_max_later_ms": float(np.max(ref_rest)),
-                       "frames_vocoded_window": frames_w, "frames_vocoded_reference_schedule": frames_f,
-                       "samples_per_s_per_gpu": samples / wall}}
-    if world == 1 and not args.no_cpu_baseline:
+    if ctx.rank != 0:
+        return None
+    line = base_line(args, ctx, "XTTS-v2 streaming, vocoder half: p50 first-chunk latency (20 latents -> waveform on host)",
+                     float(np.median(first)), "ms", wall,
+                     "configs[4] vocoder half: 200 GPT latents/sentence, stream_chunk_size=20, overlap_wav_len=1024, "
+                     "HifiDecoder 1024->512ch, tail-window schedule", "f32", higher=False,
+                     p50_later_chunk_ms=float(np.median(rest)), max_later_chunk_ms=float(np.max(rest)),
+                     reference_schedule_p50_first_ms=float(np.median(ref_first)),
+                     reference_schedule_p50_later_ms=float(np.median(ref_rest)),
+                     reference_schedule_max_later_ms=float(np.max(ref_rest)),
+                     frames_vocoded_window=frames_w, frames_vocoded_reference_schedule=frames_f,
+                     samples_per_s_per_gpu=samples / wall)
+    if ctx.world == 1 and not args.no_cpu_baseline:
         from oracle import tts_oracle as O
 
-        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        torch.set_num_threads(cpu_threads()[0])
         cpu_sd = {k: v.float() for k, v in sd.items()}
         with torch.no_grad():
             O.hifi_decoder_forward(cpu_sd, lat[:20].cpu()[None], g.cpu(), cfg)
@@ -288,11 +656,35 @@ def bench_xtts_stream(args, world, rank, dev, dist, W):
             dt = (time.perf_counter() - t0) / n
         line["cpu_baseline"] = {"value": dt * 1e3, "unit": "ms", "cores": torch.get_num_threads(), "kind": "port",
                                 "sample": "first chunk only (20 latents) through the oracle's HifiDecoder restatement"}
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
+
+
+def wl_launch_check(args, ctx):
+    """The launcher / process-group / broadcast / reduction skeleton every workload above runs on, with a trivial timed
+    body — runs without a GPU on gloo (tests/test_parallel.py drives `bench.py --gpus 2 --workload launch_check`)."""
+    from tts_amd import synthetic as W
+
+    sd, bcast_s, bcast_bytes = ctx.broadcast_weights(lambda: W.make_hifigan_state(dict(W.HIFIGAN_V2), 80, seed=7))
+    digest = float(sum(float(v.double().sum()) for v in sd.values()))
+    same = ctx.max(digest) == -ctx.max(-digest)                    # identical weights on every rank
+    units = 1000 + ctx.rank
+    ctx.fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + ctx.rank))                          # rank r is slower: the MAX over ranks must win
+    ctx.fence()
+    elapsed = time.perf_counter() - t0
+    elapsed_max, total = ctx.max(elapsed), ctx.sum(units)
+    if ctx.rank != 0:
+        return None
+    return base_line(args, ctx, "launch check (no kernels)", total * args.steps / elapsed_max, "units/s", elapsed_max,
+                     "launcher skeleton", "none", backend=ctx.backend, weights_identical=bool(same),
+                     weight_broadcast_s=bcast_s, weight_broadcast_bytes=bcast_bytes, units_per_step_all_ranks=total,
+                     slowest_rank_floor_s=0.01 * ctx.world * args.steps)
+
+
+WORKLOADS = {"vits_e2e": wl_vits_e2e, "glow_hifigan_v2": wl_glow_hifigan_v2, "hifigan_v1": wl_hifigan_v1, "mas": wl_mas,
+             "xtts_stream": wl_xtts_stream, "launch_check": wl_launch_check}
 
 
 def main():
@@ -303,6 +695,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--chars", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline run only: skip the configs[0] / configs[2] lines carried under extra_workloads at N=1")
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the MRF resblock branches on one stream (for rocprof: per-kernel durations are then not "
                          "inflated by co-running kernels; the roofline pass always runs this way)")
@@ -314,169 +708,50 @@ def main():
                          "latency-bound text front end of one batch overlaps the waveform decoder of the previous one "
                          "(tts_amd.parallel.Lanes); 1 = one stream")
     ap.add_argument("--lane-priority", type=int, default=-1, help="HIP stream priority of the request lanes (-1 high, 0 normal)")
-    ap.add_argument("--workload", default="vits_e2e", choices=["vits_e2e", "hifigan_v1", "mas", "xtts_stream"],
-                    help="vits_e2e = BASELINE configs[1] (the headline line); hifigan_v1 = configs[2], vocoder only")
+    ap.add_argument("--workload", default="vits_e2e", choices=sorted(WORKLOADS),
+                    help="vits_e2e = BASELINE configs[1] (the headline line); glow_hifigan_v2 = configs[0]; hifigan_v1 = "
+                         "configs[2], vocoder only; launch_check = the multi-rank skeleton without kernels (CPU-runnable)")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
     ap.add_argument("--items", type=int, default=256, help="hifigan_v1: items per GPU per step")
+    ap.add_argument("--hifigan-steps", type=int, default=None, help="hifigan_v1: timed steps (default --steps; 1 as an extra)")
+    ap.add_argument("--hifigan-warmup", type=int, default=None)
+    ap.add_argument("--mas-batch", type=int, default=32, help="mas: items per GPU")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend (default: nccl = RCCL on GPUs; gloo only for launch_check on CPU)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if args.workload != "launch_check" and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
+    ctx = Ctx(args)
+    if args.workload != "launch_check":
+        from tts_amd import ops
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.precision is None:
+            args.precision = ops.conv_precision()
+        ops.set_conv_precision(args.precision)
 
-    from tts_amd import synthetic as W         # seeded synthetic checkpoint (no network => no released weights)
-    from tts_amd import ops, parallel
-    from tts_amd.vits import Vits
+    line = WORKLOADS[args.workload](args, ctx)
+    if args.workload == "vits_e2e" and ctx.world == 1 and not args.no_extras:
+        import gc
 
-    if args.precision is None:
-        args.precision = ops.conv_precision()
-    ops.set_conv_precision(args.precision)
-
-    if args.workload == "hifigan_v1":
-        return bench_hifigan_v1(args, world, rank, dev, dist, W, ops, parallel)
-    if args.workload == "mas":
-        return bench_mas(args, world, rank, dev, dist)
-    if args.workload == "xtts_stream":
-        return bench_xtts_stream(args, world, rank, dev, dist, W)
-
-    # rank 0 builds the weights, everyone else receives them in one RCCL broadcast
-    sd = W.make_vits_state({}, seed=1234) if rank == 0 else None
-    t0 = time.time()
-    sd = parallel.broadcast_state_dict(sd, src=0, device=dev)
-    bcast_s = time.time() - t0
-    model = Vits({"model_args": {}})
-    model.load_state_dict(sd)
-    model.to(dev)
-
-    x, xl, dur = synthetic_batch(args.batch, args.chars, seed=rank, device=dev)
-    aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True}
-
-    lanes = parallel.Lanes(args.lanes, device=dev, priority=args.lane_priority) if args.lanes > 1 else None
-
-    def step():
-        if lanes is not None:
-            return lanes.run(model.inference, x, aux)
-        return model.inference(x, aux)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.lanes if lanes is not None else 0):   # prime every lane (hipGraph capture, allocator pools): untimed
-        step()
-    for _ in range(args.warmup):
-        out = step()
-    # live roofline measurement: HIP events around every launch of the dominant kernel instantiation
-    # (ResBlock k=11 d=1 convs of the 256/128-channel stages, conv1d_mfma_kernel<11,1,2,2,2,2,0>) and around all conv launches of the
-    # waveform decoder in aggregate, on the stream they are launched on, during the timed region.
-    def select(pc, a):
-        # every launch that dispatches to the 128x128-block k=11 d=1 NORMAL instantiation:
-        # the ResBlock1 k=11 d=1 convs of the 256- and 128-channel MRF stages (8 per step)
-        if pc.kernel == 11 and pc.dilation == 1 and a.mode == 0 and ((pc.c_out + 31) // 32) % 4 == 0:
-            return "dominant"
-        # every other waveform-decoder / flow conv; the tiny text-side launches are left untouched
-        return "other_conv" if 2.0 * pc.c_out * pc.c_in * pc.kernel * a.t_out * a.batch >= 1e9 else None
-
-    if args.serial_branches:
-        model.waveform_decoder.concurrent_branches = False
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-
-    # Roofline pass (rank 0 only, AFTER the timed region, same inputs): in the timed region the three MRF resblock
-    # branches run on three HIP streams, so an event pair around one launch also counts the kernels co-running with it.
-    # Here the branches are serialised on one stream and every conv launch of the decoder / flows is bracketed by HIP
-    # events on the stream it is launched on.
-    timer = ops.ConvTimer(select)
-    roof_steps = 2
-    lanes = None          # the roofline pass runs on the default stream, one request at a time
-    if rank == 0:
-        was = model.waveform_decoder.concurrent_branches
-        model.waveform_decoder.concurrent_branches = False
-        step()
-        torch.cuda.synchronize()
-        ops.set_conv_timer(timer)
-        for _ in range(roof_steps):
-            step()
-        torch.cuda.synchronize()
-        ops.set_conv_timer(None)
-        model.waveform_decoder.concurrent_branches = was
-
-    samples_per_step = int(out["y_mask"].sum().item()) * 256        # valid output samples of this rank's shard
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ss = torch.tensor([float(samples_per_step)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ss, op=dist.ReduceOp.SUM)
-    elapsed_max, total_samples_per_step = float(tt.item()), float(ss.item())
-
-    if rank == 0:
-        res = timer.results()
-        dom = res.get("dominant", dict(launches=0, flops=0.0, bytes=0.0, ms=1.0))
-        allc = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)
-        for r in res.values():
-            for k in allc:
-                allc[k] += r[k]
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["launches"] else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_dominant_%s.json" % args.precision)
-        if os.path.exists(pmc):
+        extras = {}
+        for name, fn, over in (("configs[0] glow_hifigan_v2", wl_glow_hifigan_v2, dict(steps=50, warmup=5)),
+                               ("configs[2] hifigan_v1", wl_hifigan_v1,
+                                dict(hifigan_steps=args.hifigan_steps or 1,
+                                     hifigan_warmup=1 if args.hifigan_warmup is None else args.hifigan_warmup))):
+            gc.collect()
+            torch.cuda.empty_cache()
+            sub = argparse.Namespace(**dict(vars(args), **over))
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        value = total_samples_per_step * args.steps / elapsed_max
-        line = {
-            "metric": "audio samples/sec (LJSpeech VITS -> HiFiGAN decoder, 22.05 kHz, end-to-end inference)",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
-            "rtf_x": value / SAMPLE_RATE, "rtf_x_per_gpu": value / SAMPLE_RATE / world,
-            "config": {"workload": "configs[1]: LJSpeech VITS end-to-end, batch=%d random %d-char utterances per GPU "
-                                   "(257 ids, 770 frames, 197120 samples each), 22.05 kHz" % (args.batch, args.chars),
-                       "utterances_per_gpu": args.batch, "chars": args.chars, "parallelism": "replicas x%d" % world,
-                       "weights": "random-init VitsArgs defaults (29.1 M params), broadcast from rank 0 in %.3f s" % bcast_s,
-                       "mrf_branch_streams": 1 if args.serial_branches else 3, "request_lanes": args.lanes},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": conv_kernel_name(args.precision, "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0")
-                          + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
-                "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
-                "frac": ach / conv_peak(args.precision), "traffic": traffic,
-                "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B per launch) / launch time; peak = bf16 dense "
-                              "MFMA peak 2500 TF / 6 bf16 products per fp32 product; on the matrix pipe itself: %.0f of "
-                              "2500 bf16 TFLOP/s" % (ach * X3_PRODUCTS)) if args.precision == "x3" else
-                             "fp32-input MFMA peak (= fp32 vector peak); exact fp32 arithmetic",
-                "launches_timed": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
-                "algorithmic_gbps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["launches"] else 0.0,
-                "all_conv_launches": {"launches": allc["launches"],
-                                      "tflops": allc["flops"] / (allc["ms"] * 1e-3) / 1e12 if allc["ms"] else 0.0,
-                                      "algorithmic_gbps": allc["bytes"] / (allc["ms"] * 1e-3) / 1e9 if allc["ms"] else 0.0,
-                                      "ms_per_step": allc["ms"] / roof_steps},
-                "measured": "%d extra steps after the timed region with the MRF branch streams serialised (in the timed "
-                            "region three branch streams overlap and inflate per-launch event times); HIP events on the "
-                            "launch stream" % roof_steps,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, args.chars)
+                extras[name] = fn(sub, ctx)
+            except Exception as e:          # an extra must never cost the headline line
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["extra_workloads"] = extras
+    if ctx.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

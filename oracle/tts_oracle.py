@@ -757,13 +757,16 @@ def glow_inference_with_mas(sd, tokens, x_lengths, y, y_lengths, args=None, maxi
             "y_mean": y_mean.transpose(1, 2), "total_durations_log": o_attn_dur.transpose(1, 2)}
 
 
-def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None, g=None):
-    """GlowTTS.inference, glow_tts.py:341-374 (g: speaker conditioning from glow_speaker_g, or None)."""
+def glow_tts_inference(sd, tokens, x_lengths, args=None, noise=None, g=None, durations=None):
+    """GlowTTS.inference, glow_tts.py:341-374 (g: speaker conditioning from glow_speaker_g, or None).
+    `durations` [B,1,T] (not a reference argument) replaces w_ceil: benches / parity harnesses pin the output length."""
     a = dict(GLOW_DEFAULTS)
     a.update(args or {})
     o_mean, o_log_scale, o_dur_log, x_mask = glow_encoder(sd, "encoder.", tokens, x_lengths, a, g=g)
     w = (torch.exp(o_dur_log) - 1) * x_mask * a["length_scale"]
     w_ceil = torch.clamp_min(torch.ceil(w), 1)
+    if durations is not None:
+        w_ceil = durations.to(w.dtype) * x_mask
     y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
     y_mask = torch.unsqueeze(sequence_mask(y_lengths, None), 1).to(x_mask.dtype)
     attn_mask = torch.unsqueeze(x_mask, -1) * torch.unsqueeze(y_mask, 2)

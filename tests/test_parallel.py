@@ -49,3 +49,24 @@ def test_flatten_roundtrip_and_length_sharding():
     assert sorted(sum(shards, [])) == list(range(7)) and max(map(len, shards)) - min(map(len, shards)) <= 1
     tot = [sum(lens[i] for i in s) for s in shards]
     assert max(tot) - min(tot) <= max(lens)
+
+
+def test_bench_self_launch_world2_gloo():
+    """`python bench.py --gpus 2` outside torchrun re-launches itself as 2 ranks (torch.distributed.run, 127.0.0.1) and
+    rank 0 prints ONE JSON line with n_gpus=2: the launcher, process group, flat-blob weight broadcast, barrier-fenced
+    timed region, MAX-over-ranks time and SUM-over-ranks units — the skeleton every GPU workload runs on — on gloo/CPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "launch_check",
+                        "--backend", "gloo", "--steps", "3"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["config"]["parallelism"] == "replicas x2"
+    assert r["config"]["weights_identical"] and r["config"]["weight_broadcast_bytes"] > 1e6
+    assert r["config"]["units_per_step_all_ranks"] == 2001.0                  # SUM over ranks
+    assert r["ms_per_step"] >= 20.0 * 0.99                                     # MAX over ranks: rank 1 sleeps 20 ms per step
+    # a rank count that does not match --gpus is refused, never silently measured as something else
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "launch_check"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0"), cwd=ROOT, timeout=120)
+    assert p.returncode != 0 and "--gpus 1" in (p.stderr + p.stdout)
