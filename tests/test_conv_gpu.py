@@ -171,3 +171,86 @@ def test_replicate_pad(gpu):
     y = torch.empty(3, 5, 27, device=gpu)
     ops.replicate_pad(x.to(gpu), y, 5)
     assert torch.equal(y.cpu(), F.pad(x, (5, 5), mode="replicate"))
+
+
+# ---- split-bf16 arithmetic under adversarial operands (only randn had been tried) ----------------------------
+def _f32_from_bits(sign, exp, mant):
+    bits = (sign.astype(np.uint32) << 31) | (exp.astype(np.uint32) << 23) | mant.astype(np.uint32)
+    return torch.from_numpy(bits.view(np.float32).copy())
+
+
+def _max_residual_values(rng, shape, e_lo, e_hi):
+    """fp32 values whose 3-way bf16 split has the LARGEST residuals: after the leading 8 significant bits, each further
+    8-bit group sits next to the round-to-nearest tie (0x7F.. / 0x80..), so |x - bf16(x)| and |r1 - bf16(r1)| are ~1/2 ulp
+    of the part before them — the products the kernel drops (w2 x3, w3 x2, w3 x3) are then as large as they can get."""
+    n = int(np.prod(shape))
+    hi = rng.integers(0, 128, n)                               # 7 explicit mantissa bits of part 1
+    mid = rng.choice([0x7F, 0x80, 0x7E, 0x81], n)              # next 8 bits: next to the tie
+    lo = rng.choice([0x7F, 0x80, 0xFF, 0x01], n)               # last 8 bits
+    mant = (hi << 16) | (mid << 8) | lo
+    return _f32_from_bits(rng.integers(0, 2, n), rng.integers(e_lo, e_hi + 1, n), mant).reshape(shape)
+
+
+def _conv64(x, w, b, K, D):
+    return F.conv1d(x.double(), w.double(), None if b is None else b.double(), padding=(K - 1) * D // 2, dilation=D)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 7, 1, 400), (1, 256, 256, 11, 1, 260), (2, 32, 32, 3, 5, 900)])
+def test_split_bf16_maximal_residual_operands_vs_fp64(gpu, case, conv_precision):
+    """Both operands built to maximise the dropped products; the error against an fp64 conv must stay fp32-class: no worse
+    than twice what torch's own fp32 CPU conv makes on the same data (or 2^-22 of sum|w x|, whichever is larger)."""
+    B, Cin, Cout, K, D, T = case
+    rng = np.random.default_rng(sum(case))
+    x = _max_residual_values(rng, (B, Cin, T), 120, 130)        # |x| in [2^-7, 2^4)
+    w = _max_residual_values(rng, (Cout, Cin, K), 115, 122)     # |w| in [2^-12, 2^-4)
+    want = _conv64(x, w, None, K, D)
+    scale = _conv64(x.abs(), w.abs(), None, K, D)               # sum |w x| per output
+    y = torch.empty(B, Cout, T, device=gpu)
+    ops.conv1d(ops.PackedConv(w, None, gpu, dilation=D), x.to(gpu), y)
+    err_gpu = float(((y.cpu().double() - want).abs() / scale).max())
+    err_cpu = float(((F.conv1d(x, w, None, padding=(K - 1) * D // 2, dilation=D).double() - want).abs() / scale).max())
+    print("max |err| / sum|wx|: gpu %.3e, torch fp32 cpu %.3e (%s)" % (err_gpu, err_cpu, conv_precision))
+    assert err_gpu <= max(2.0 * err_cpu, 2.0 ** -22), (err_gpu, err_cpu)
+    assert _rel(y, want) < TOL
+
+
+def test_split_bf16_cancellation_k2816_vs_fp64(gpu, conv_precision):
+    """K = 256 channels x 11 taps = 2816 products of alternating sign and near-equal magnitude per output: the result is
+    ~1e-3 of sum|w x|, so any systematic product error would surface.  Error measured against fp64, relative to sum|w x|."""
+    B, C, K, T = 1, 256, 11, 300
+    rng = np.random.default_rng(2816)
+    sign = np.where((np.arange(C)[:, None] + np.arange(T)[None, :]) % 2 == 0, 1.0, -1.0)
+    x = torch.from_numpy((sign * (1.0 + 1e-3 * rng.standard_normal((C, T)))).astype(np.float32))[None]
+    w = torch.from_numpy((0.05 * (1.0 + 1e-3 * rng.standard_normal((C, C, K)))).astype(np.float32))
+    want = _conv64(x, w, None, K, 1)
+    scale = _conv64(x.abs(), w.abs(), None, K, 1)
+    y = torch.empty(B, C, T, device=gpu)
+    ops.conv1d(ops.PackedConv(w, None, gpu), x.to(gpu), y)
+    err_gpu = float(((y.cpu().double() - want).abs() / scale).max())
+    err_cpu = float(((F.conv1d(x, w, None, padding=5).double() - want).abs() / scale).max())
+    print("cancellation: |result|/sum|wx| median %.2e; max err/sum|wx|: gpu %.3e, torch fp32 cpu %.3e"
+          % (float((want.abs() / scale).median()), err_gpu, err_cpu))
+    assert err_gpu <= max(2.0 * err_cpu, 2.0 ** -22), (err_gpu, err_cpu)
+
+
+def test_split_bf16_tiny_activations_flush_bound(gpu, conv_precision):
+    """|x| in [1e-40, 1e-36]: the 2nd / 3rd bf16 parts of such values fall below bf16's normal range (1.18e-38).  Whatever
+    the hardware does with them (keep as denormals or flush), the error is bounded by the flushed parts themselves:
+    |err| <= 2 * 2^-126 * sum|w| per output (+ fp32-level relative error) — and a batch that mixes such values with
+    ordinary ones keeps the ordinary tolerance."""
+    B, C, K, T = 1, 64, 7, 500
+    rng = np.random.default_rng(40)
+    mag = 10.0 ** rng.uniform(-40, -36, (B, C, T))
+    x = torch.from_numpy((mag * rng.choice([-1.0, 1.0], mag.shape)).astype(np.float32))
+    w = torch.randn(C, C, K, generator=torch.Generator().manual_seed(1)) / np.sqrt(C * K)
+    want = _conv64(x, w, None, K, 1)
+    y = torch.empty(B, C, T, device=gpu)
+    ops.conv1d(ops.PackedConv(w, None, gpu), x.to(gpu), y)
+    bound = 2.0 * 2.0 ** -126 * float(w.abs().sum(dim=(1, 2)).max()) + 1e-5 * float(want.abs().max())
+    err = float((y.cpu().double() - want).abs().max())
+    print("tiny activations: max |err| %.3e (bound %.3e, max |want| %.3e)" % (err, bound, float(want.abs().max())))
+    assert err <= bound
+    xm = torch.randn(B, C, T, generator=torch.Generator().manual_seed(2))
+    xm[:, ::3] = x[:, ::3]                                       # a third of the channels tiny, the rest ordinary
+    ops.conv1d(ops.PackedConv(w, None, gpu), xm.to(gpu), y)
+    assert _rel(y, _conv64(xm, w, None, K, 1)) < TOL

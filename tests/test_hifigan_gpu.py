@@ -121,3 +121,21 @@ def test_xtts_streaming_chunker(gpu, length_scale):
             rms, rel = _errs(ca, cw)
             assert rms < 1e-4 and rel < 1e-5, (rms, rel)
     assert win.frames_decoded < 0.6 * full.frames_decoded
+
+
+def test_inference_slabbed_equals_inference_bitwise(gpu):
+    """BASELINE configs[2] runs through `inference_slabbed` (the batch cut into slabs that fit HBM): items are independent,
+    so a 3-slab run must reproduce the unslabbed call bit for bit — device output, host output and preallocated `out`."""
+    cfg = dict(W.HIFIGAN_V1, upsample_initial_channel=64)
+    sd = O.make_hifigan_state(cfg, 80, seed=21)
+    m = _make(cfg, 80, gpu, sd)
+    mel = torch.randn(7, 80, 40, generator=torch.Generator().manual_seed(4))
+    want = m.inference(mel.to(gpu))
+    widest = max((64 >> (i + 1)) * h for i, h in enumerate((8, 64, 128, 256)))
+    per_item = 6 * 4 * widest * (40 + 10)
+    got = m.inference_slabbed(mel.to(gpu), max_live_bytes=3 * per_item)          # slabs of 3, 3, 1 items
+    assert torch.equal(got, want)
+    host = torch.empty(want.shape, dtype=torch.float32)
+    m.inference_slabbed(mel, out=host, max_live_bytes=3 * per_item)              # host mels -> host waveforms
+    torch.cuda.synchronize()
+    assert torch.equal(host, want.cpu())

@@ -338,3 +338,33 @@ def test_vits_request_lanes_equal_single_stream(gpu):
         got = [o["model_outputs"] for o in outs]
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+
+
+def test_vits_bench_batch32_rows_match_oracle(gpu):
+    """The benchmark's exact step (VitsArgs defaults, B=32 x 257 ids, 770 frames, both noise draws pinned) — 8 sampled
+    rows of the batch against B=1 oracle runs on the same row: waveform <= 1e-4 RMS and <= 1e-5 relative per row, and the
+    duration predictor's logw of every sampled row."""
+    import bench
+
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    sd = W.make_vits_state({}, seed=1234)
+    B = 32
+    x, xl, dur = bench.synthetic_batch(B, 128, 0, "cpu")
+    g = torch.Generator().manual_seed(32)
+    noise_dp = torch.randn(B, 2, 257, generator=g)
+    noise_z = torch.randn(B, 192, 770, generator=g)
+    m = _model({}, sd, gpu)
+    out = m.inference(x.to(gpu), {"x_lengths": xl.to(gpu), "durations": dur.to(gpu), "noise_dp": noise_dp.to(gpu),
+                                  "noise_z": noise_z.to(gpu), "run_duration_predictor": True, "return_extras": True})
+    wav, logw = out["model_outputs"].cpu(), out["logw"].cpu()
+    assert wav.shape == (B, 1, 197120)
+    worst = (0.0, 0.0)
+    for r in (0, 3, 7, 12, 17, 22, 27, 31):
+        want = O.vits_inference(sd, x[r:r + 1], xl[r:r + 1], {}, noise_z=noise_z[r:r + 1], durations=dur[r:r + 1].view(1, 1, -1))
+        rms, rel = _errs(wav[r:r + 1], want["model_outputs"])
+        assert rms < 1e-4 and rel < 1e-5, (r, rms, rel)
+        worst = max(worst, (rms, rel))
+        lw = O.vits_inference(sd, x[r:r + 1], xl[r:r + 1], {}, noise_dp=noise_dp[r:r + 1], stop_after="prior",
+                              noise_z=torch.zeros(1, 192, 1))["logw"]
+        assert _errs(logw[r:r + 1], lw)[1] < 1e-5, r
+    print("B=32 bench step, 8 rows vs oracle: worst waveform rms %.2e rel %.2e" % worst)

@@ -4,10 +4,13 @@
 //
 //     w x  ~=  w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1)
 //
-// The three dropped products sum to < 2^-26 |w x|, and w1+w2+w3 / x1+x2+x3 reproduce the fp32 values to < 2^-27
-// relative — i.e. every product is MORE accurate than one fp32 rounding of it (2^-24), and accumulation is fp32 as in
-// the fp32-input MFMA path (conv_kernel.h).  Same arithmetic class, same parity tolerances, but the bf16 matrix pipe
-// runs 16x the fp32-input rate, so six of its instructions cost 6/16 of the one they replace.
+// The split itself is exact (24 significand bits = 3 x 8: w1+w2+w3 == w, x1+x2+x3 == x bit for bit, above bf16's
+// denormal range).  The three dropped products (w2 x3, w3 x2, w3 x3) sum to at most 2^-24.2 |w x| in the worst case and
+// 2^-27.4 |w x| RMS (measured over 2 M random pairs, CPU emulation) — about ONE fp32 rounding of the product in the worst
+// case, far below it on average; accumulation is fp32 as in the fp32-input MFMA path (conv_kernel.h).  Same arithmetic
+// class, same parity tolerances (tests/test_conv_gpu.py runs adversarial operands — maximal bf16 residuals, K = 2816
+// cancellation, activations below bf16's normal range — against an fp64 conv), but the bf16 matrix pipe runs 16x the
+// fp32-input rate, so six of its instructions cost 6/16 of the one they replace.
 //
 //   * A (weights): split and packed at load time as [m-tile][chunk][tap][part][64 lanes][8 bf16]: one 16-byte load per
 //     lane per (tap, part) straight from L2, prefetched one tap ahead.  Lane l holds row l%32, channels 8*(l/32)..+7.
