@@ -154,6 +154,36 @@ int ttsamd_conv1d_pack_weights_split(void *dst, const float *w, int c_out, int c
 /* 1 if (kernel, dilation) has a tuned instantiation. */
 int ttsamd_conv1d_supported(int kernel, int dilation);
 
+/* One ResBlock1 iteration of the HiFiGAN MRF as a single launch — replaces the body of the loop in
+ * TTS/vocoder/models/hifigan_generator.py:90-98 (ResBlock1.forward):
+ *     xt = F.leaky_relu(x, slope); xt = c1(xt)   [kernel k, dilation d, same padding]
+ *     xt = F.leaky_relu(xt, slope); xt = c2(xt)  [kernel k, dilation 1]
+ *     x  = xt + x
+ * plus, for the block's last iteration, the MRF accumulate / average of hifigan_generator.py:255-261
+ * (y = accum + y, then y = y / out_div when out_div != 0).  x, y, accum: [batch, c, t] fp32 contiguous (y may not
+ * alias x); mask [batch, t] (or NULL) multiplies the input of BOTH convs (ragged-exact batching, see ttsamd_conv1d_args
+ * in_mask).  Weights are the split-bf16 images of ttsamd_conv1d_pack_weights_split ([c, c, k] each); the intermediate
+ * tensor stays in LDS (5 HBM tensor passes -> 2) and the arithmetic is product-for-product that of two ttsamd_conv1d
+ * launches with w_split set: results are bitwise identical to the unfused pair.
+ * Limits: c in {32, 64, 128}, kernel in {3, 7, 11}, dilation in {1, 3, 5} (ttsamd_resblock_pair_supported). */
+typedef struct ttsamd_resblock_args {
+    const float *x;
+    float *y;
+    const float *accum;     /* or NULL */
+    const float *mask;      /* [batch, t] or NULL */
+    const void *w1_split;
+    const float *bias1;     /* [c] or NULL */
+    const void *w2_split;
+    const float *bias2;
+    int32_t c, t, batch;
+    int32_t kernel, dilation;
+    float slope;            /* leaky-ReLU slope of both activations */
+    float out_div;
+    int32_t variant;        /* 0 = default tile; other values select alternative tiles (measurement only) */
+} ttsamd_resblock_args;
+int ttsamd_resblock_pair(const ttsamd_resblock_args *args /* host */, void *stream);
+int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
+
 /* ------------------------------------------------------------------------------------------
  * Channel LayerNorm on [B, C, T] (normalise over C for every (b, t)), with the fusions the text
  * encoder / duration predictors need.

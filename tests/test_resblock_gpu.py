@@ -1,0 +1,134 @@
+"""GPU parity of the fused ResBlock1-iteration kernel (ttsamd_resblock_pair, tts_amd/csrc/resblock_kernel_x3.h):
+  * BITWISE equal to the two ttsamd_conv1d launches it replaces (same split-bf16 products in the same order), over
+    every (channels, kernel, dilation) instantiation, ragged masks, the MRF accumulate / average epilogue, tensors
+    shorter than one tile and tile-edge lengths;
+  * within the conv tolerance (1e-5 relative RMS) of torch's fp32 CPU ops for hifigan_generator.py:90-98;
+  * the HiFiGAN generator gives identical waveforms with fusion on and off."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tts_oracle as O
+from oracle import weights as W
+from tts_amd import _lib, ops
+from tts_amd.hifigan import HifiganGenerator
+
+pytestmark = pytest.mark.gpu
+SLOPE = 0.1
+
+
+def _pair(C, K, D, seed, gpu):
+    g = torch.Generator().manual_seed(seed)
+    w1 = torch.randn(C, C, K, generator=g) / np.sqrt(C * K)
+    w2 = torch.randn(C, C, K, generator=g) / np.sqrt(C * K)
+    b1, b2 = 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    return (w1, b1, w2, b2), ops.PackedConv(w1, b1, gpu, dilation=D), ops.PackedConv(w2, b2, gpu, dilation=1), g
+
+
+def _unfused(pc1, pc2, x, mask, accum, div):
+    tmp, y = torch.empty_like(x), torch.empty_like(x)
+    ops.conv1d(pc1, x, tmp, in_act=ops.ACT_LRELU, in_slope=SLOPE, in_mask=mask)
+    ops.conv1d(pc2, tmp, y, in_act=ops.ACT_LRELU, in_slope=SLOPE, res=x, accum=accum, out_div=div, in_mask=mask)
+    return y
+
+
+def _torch_ref(w, x, mask, accum, div, K, D):
+    w1, b1, w2, b2 = w
+    m = 1.0 if mask is None else mask[:, None]
+    xt = F.conv1d(F.leaky_relu(x * m, SLOPE), w1, b1, padding=(K - 1) * D // 2, dilation=D)
+    xt = F.conv1d(F.leaky_relu(xt * m, SLOPE), w2, b2, padding=(K - 1) // 2)
+    y = xt + x
+    if accum is not None:
+        y = accum + y
+    return y / div if div else y
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+ALL = [(C, K, D) for C in (32, 64, 128) for K in (3, 7, 11) for D in (1, 3, 5)]
+
+
+@pytest.mark.parametrize("ckd", ALL, ids=lambda c: "c%d_k%d_d%d" % c)
+def test_fused_pair_bitwise_equals_two_convs(gpu, ckd):
+    C, K, D = ckd
+    B, T = 2, 700 + 13 * K + D                       # several tiles, ragged last tile
+    w, pc1, pc2, g = _pair(C, K, D, C + K + D, gpu)
+    assert ops.resblock_pair_supported(pc1, pc2)
+    x = torch.randn(B, C, T, generator=g).to(gpu)
+    y = torch.full((B, C, T), float("nan"), device=gpu)
+    ops.resblock_pair(pc1, pc2, x, y, slope=SLOPE)
+    want = _unfused(pc1, pc2, x, None, None, 0.0)
+    assert torch.equal(y, want), float((y - want).abs().max())
+    assert _rel(y, _torch_ref(w, x.cpu(), None, None, 0.0, K, D)) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(32, 11, 5, 3, 1000, True, True, 3.0), (32, 3, 1, 2, 256, True, False, 0.0),
+                                  (64, 7, 3, 3, 517, True, True, 3.0), (64, 11, 1, 1, 247, False, True, 0.0),
+                                  (128, 3, 5, 2, 300, True, True, 3.0), (32, 7, 1, 4, 5, True, True, 3.0),
+                                  (64, 3, 1, 1, 1, False, False, 0.0), (32, 11, 3, 1, 246, False, False, 0.0),
+                                  (32, 11, 3, 1, 247, False, True, 3.0)])
+def test_fused_pair_mask_accum_div_and_edges(gpu, case):
+    """Ragged length masks (both convs see x*mask / mid*mask), the MRF accumulate + true division of the block's last
+    iteration, tensors shorter than the halo, and lengths that end exactly on / one past a tile edge (kBN = 256-(K-1))."""
+    C, K, D, B, T, has_mask, has_acc, div = case
+    w, pc1, pc2, g = _pair(C, K, D, sum(case[:5]), gpu)
+    x = torch.randn(B, C, T, generator=g)
+    lens = torch.tensor([max(1, T - 97 * i) for i in range(B)])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float() if has_mask else None
+    acc = torch.randn(B, C, T, generator=g) if has_acc else None
+    dev = lambda t: None if t is None else t.to(gpu)  # noqa: E731
+    y = torch.full((B, C, T), float("nan"), device=gpu)
+    ops.resblock_pair(pc1, pc2, dev(x), y, slope=SLOPE, mask=dev(mask), accum=dev(acc), out_div=div)
+    want = _unfused(pc1, pc2, dev(x), dev(mask), dev(acc), div)
+    assert torch.equal(y, want), float((y - want).abs().max())
+    assert _rel(y, _torch_ref(w, x, mask, acc, div, K, D)) < 1e-5
+
+
+def test_fused_pair_alternative_tile_and_limits(gpu):
+    w, pc1, pc2, g = _pair(64, 11, 5, 9, gpu)
+    x = torch.randn(2, 64, 900, generator=g).to(gpu)
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    ops.resblock_pair(pc1, pc2, x, ya, slope=SLOPE)
+    ops.resblock_pair(pc1, pc2, x, yb, slope=SLOPE, variant=1)         # 4-wave / 128-column tile
+    assert torch.equal(ya, yb)
+    with pytest.raises(_lib.TtsAmdError):
+        ops.resblock_pair(pc1, pc2, x, x, slope=SLOPE)                 # in place is refused (tiles read x's halo)
+    _, p1, p2, _ = _pair(16, 3, 1, 1, gpu)
+    assert not ops.resblock_pair_supported(p1, p2)                     # C = 16 (HiFiGAN-v2 tail stages): unfused path
+    with pytest.raises(_lib.TtsAmdError):
+        ops.resblock_pair(p1, p2, x[:, :16].contiguous(), ya[:, :16].contiguous(), slope=SLOPE)
+    was = ops.conv_precision()
+    ops.set_conv_precision("f32")
+    try:
+        assert not ops.resblock_pair_supported(pc1, pc2)               # exact-fp32 path keeps the two-launch form
+    finally:
+        ops.set_conv_precision(was)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_hifigan_fused_equals_unfused(gpu, ragged):
+    """Whole generator (v1, C0 = 256: stages of 128, 64, 32, 16 channels), fusion on every supported stage vs off:
+    identical waveform bits; and against the oracle at the usual tolerance."""
+    cfg = dict(W.HIFIGAN_V1, upsample_initial_channel=256)
+    sd = O.make_hifigan_state(cfg, 80, seed=5)
+    m = HifiganGenerator(80, 1, cfg["resblock_type"], cfg["resblock_dilation_sizes"], cfg["resblock_kernel_sizes"],
+                         cfg["upsample_kernel_sizes"], cfg["upsample_initial_channel"], cfg["upsample_factors"],
+                         inference_padding=cfg["inference_padding"])
+    m.load_state_dict(sd)
+    m.to(gpu)
+    mel = torch.randn(3, 80, 23, generator=torch.Generator().manual_seed(6))
+    lengths = torch.tensor([23, 17, 9]) if ragged else None
+    m.fuse_resblocks, m.fuse_channels = True, (32, 64, 128)
+    fused = m.inference(mel.to(gpu), lengths=lengths)
+    m.fuse_resblocks = False
+    plain = m.inference(mel.to(gpu), lengths=lengths)
+    assert torch.equal(fused, plain)
+    if not ragged:
+        want = O.hifigan_inference(sd, "", mel, cfg)
+        a, b = fused.double().cpu(), want.double()
+        rms = float((a - b).pow(2).mean().sqrt())
+        assert rms < 1e-4 and rms / float(b.pow(2).mean().sqrt()) < 1e-5

@@ -11,12 +11,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libtts_amd.so")
+# TTSAMD_BUILD_TAG=<tag> + TTSAMD_EXTRA_FLAGS="-D..." build a variant library libtts_amd_<tag>.so next to the default one
+# (A/B measurements: point TTSAMD_LIB_PATH at it); the default build takes neither.
+TAG = os.environ.get("TTSAMD_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libtts_amd%s.so" % ("_" + TAG if TAG else ""))
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wno-unused-result", "-Wno-pass-failed"]
+         "-Wno-unused-result", "-Wno-pass-failed"] + os.environ.get("TTSAMD_EXTRA_FLAGS", "").split()
 
 
 def _newer(target, deps):

@@ -15,9 +15,11 @@
 //   * A (weights): split and packed at load time as [m-tile][chunk][tap][part][64 lanes][8 bf16]: one 16-byte load per
 //     lane per (tap, part) straight from L2, prefetched one tap ahead.  Lane l holds row l%32, channels 8*(l/32)..+7.
 //   * B (activations): staged per 16-channel chunk; a thread owns (column, 8-channel half): 8 coalesced fp32 loads,
-//     activation / mask, split, three ds_write_b128 into [part][column][16 ch] bf16.  A fragment is then ONE
-//     ds_read_b128 (lane -> column, half-wave -> 8 channels): 32 consecutive 32-byte rows per half-wave, conflict free,
-//     and tap / dilation are immediates on the column index.
+//     activation / mask, split, three ds_write_b128 into [part][half][column][8 ch] bf16.  A fragment is then ONE
+//     ds_read_b128 (lane -> column, half-wave -> 8-channel half = its own plane): consecutive columns are consecutive
+//     16-byte slots, so the 16 lanes the LDS serves per cycle ({0-3,12-15,20-27}, ...) hit 16 different slots —
+//     conflict free — and tap / dilation are immediates on the column index.  (TTSAMD_X3_PLANAR=0 builds the earlier
+//     [part][column][16 ch] image, whose 32-byte rows put two lanes of each group on the same slot: 2-way conflicts.)
 //   * one MFMA K-step = 16 channels of one tap; any kernel size works (no pairing constraint).
 //   * accumulators, residual folding and the fused epilogues are the fp32 path's (conv_acc_init / conv_epilogue).
 #pragma once
@@ -30,6 +32,9 @@
 #endif
 #ifndef TTSAMD_X3_CFG64
 #define TTSAMD_X3_CFG64 1, 4, 2, 2
+#endif
+#ifndef TTSAMD_X3_PLANAR
+#define TTSAMD_X3_PLANAR 1
 #endif
 
 namespace ttsamd {
@@ -143,7 +148,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
                     w.y = p[q][2] | (p[q][3] << 16);
                     w.z = p[q][4] | (p[q][5] << 16);
                     w.w = p[q][6] | (p[q][7] << 16);
+#if TTSAMD_X3_PLANAR
+                    *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + half * (G::kXW * 16) + col * 16) = w;
+#else
                     *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + col * 32 + half * 16) = w;
+#endif
                 }
             }
         }
@@ -172,7 +181,13 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
     pc[1] = clock64();
 #endif
 
-    const int bbyte = (wn * (32 * NI) + j) * 32 + h * 16;   // this lane's fragment inside a part, tap 0, ni 0
+#if TTSAMD_X3_PLANAR
+    constexpr int kColBytes = 16;
+    const int bbyte = h * (G::kXW * 16) + (wn * (32 * NI) + j) * 16;   // this lane's fragment inside a part, tap 0, ni 0
+#else
+    constexpr int kColBytes = 32;
+    const int bbyte = (wn * (32 * NI) + j) * 32 + h * 16;
+#endif
     for (int c = 0; c < nchunks; ++c) {
         const unsigned char *cur = xs3 + (c & 1) * G::kBufBytes + bbyte;
         if (c + 1 < nchunks) stage_load(c + 1);
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
                 u32x4 bq[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * 32);
+                    bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * kColBytes);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     constexpr int pa[6] = {2, 1, 0, 1, 0, 0};   // smallest products first

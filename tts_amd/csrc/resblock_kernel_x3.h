@@ -1,0 +1,344 @@
+// One ResBlock1 iteration of the HiFiGAN MRF as ONE kernel (TTS/vocoder/models/hifigan_generator.py:90-98):
+//
+//     mid = conv1(lrelu(x * mask), kernel K, dilation D) + bias1
+//     y   = conv2(lrelu(mid * mask), kernel K, dilation 1) + bias2 + x   [+ accum] [/ div]
+//
+// Unfused, the pair is two launches and five tensor passes over HBM (x, mid written, mid read, x again as the residual,
+// y); here `mid` never leaves the CU: conv1's accumulators are biased / masked / leaky-ReLU'd / split into the three
+// bf16 parts in registers and written straight into the LDS image that conv2's B fragments are read from.  HBM sees x
+// once (plus the halo overlap of neighbouring time tiles and the residual re-read of the tile's own columns, both L2
+// hits) and y once: 5 passes -> 2.  Arithmetic is the split-bf16 scheme of conv_kernel_x3.h, product for product and in
+// the same order, so the result is BITWISE what the two conv1d_x3 launches produce (tests/test_resblock_gpu.py).
+//
+// Block = all C channels (C = c_in = c_out in {32, 64, 128}) x kNM mid columns; waves are arranged WM x WN over
+// (32-row m-tiles, 32-column n-tiles).  conv2 computes kNM columns too, of which kBN = kNM - (K-1) are valid outputs
+// (the rest are the halo mid columns' worth of work: (K-1)/kNM of conv2's MFMAs, 4 % at K = 11, kNM = 256).
+//
+// LDS image (x tile, then — after a barrier — the mid tile in the same bytes): [part 3][chunk C/16][half 2][column][8 ch]
+// bf16.  A B fragment (lane = column, half-wave = 8-channel half) is one ds_read_b128 at a 16-byte column stride inside
+// one plane: the 16 lanes the LDS serves per cycle cover 16 different 16-byte slots -> conflict free (the
+// [column][16 ch] image of conv_kernel_x3.h is 2-way conflicted on ds_read_b128's lane groups), and tap / dilation /
+// n-tile / plane offsets are compile-time immediates.
+#pragma once
+#include "conv_kernel_x3.h"
+
+namespace ttsamd {
+
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+template <int K, int D, int C, int WM, int WN, int NI>
+struct ResGeom {
+    static constexpr int kThreads = 64 * WM * WN;
+    static constexpr int kMI = C / (32 * WM);      // m-tiles per wave
+    static constexpr int kNCh = C / 16;            // 16-channel chunks of the reduction
+    static constexpr int kNM = 32 * NI * WN;       // mid columns computed (= conv2 columns computed)
+    static constexpr int kBN = kNM - (K - 1);      // valid output columns per block
+    static constexpr int kH2 = (K - 1) / 2;        // conv2 halo (dilation 1)
+    static constexpr int kH1 = (K - 1) * D / 2;    // conv1 halo
+    static constexpr int kXW = kNM + (K - 1) * D;  // x tile columns
+    static constexpr int kXWm = kNM + (K - 1);     // mid tile columns (conv2 reads up to column kNM - 1 + K - 1)
+    static constexpr int kPlaneX = kXW * 16;       // bytes of one [column][8 ch] plane of the x tile
+    static constexpr int kPlaneM = kXWm * 16;
+    static constexpr int kItems = kNCh * 2 * kXW;  // staged (chunk, half, column) items: 8 channels each
+    static constexpr int kRounds = (kItems + kThreads - 1) / kThreads;
+    static constexpr size_t kLdsBytes = (size_t)3 * kNCh * 2 * kPlaneX;
+    static constexpr int kOcc = (2 * kLdsBytes <= 160 * 1024 && kThreads <= 256) ? 2 : (kThreads >= 512 ? 2 : 1);
+    static_assert(C % (32 * WM) == 0 && kBN > 0, "bad tile");
+};
+
+// Main loop of one conv of the pair: acc[mi][ni] += sum over (chunk, tap) of the six split products.
+//   wp[mi]  this wave's A stream (m-tile (wm*MI + mi)): [chunk][tap][part][64 lanes] x 16 bytes, read from L2/L1 one tap
+//           ahead; a_cur holds tap 0 of chunk 0 on entry.
+//   bbase   LDS address of this lane's fragment for (part 0, chunk 0, n-tile 0, tap 0): plane `half`, column wn*32*NI + j.
+template <int KK, int DD, int MI, int NI, int NCH, int PLANE>
+__device__ __forceinline__ void res_conv_mainloop(f32x16 (&acc)[MI][NI], const u32x4 *const (&wp)[MI], u32x4 (&a_cur)[MI][3],
+                                                  const unsigned char *bbase)
+{
+    u32x4 a_nxt[MI][3];
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const unsigned char *cb = bbase + c * (2 * PLANE);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const long g = ((long)c * KK + tap + 1) * (3 * 64);   // the packed image ends with one group of slack
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a_nxt[mi][q] = wp[mi][g + q * 64];
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                u32x4 bq[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    bq[q] = *reinterpret_cast<const u32x4 *>(cb + q * (NCH * 2 * PLANE) + (ni * 32 + tap * DD) * 16);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    constexpr int pa[6] = {2, 1, 0, 1, 0, 0};   // smallest products first (as conv1d_x3_kernel)
+                    constexpr int pb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[mi][pa[t]]),
+                                                                              __builtin_bit_cast(bf16x8, bq[pb[t]]),
+                                                                              acc[mi][ni], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a_cur[mi][q] = a_nxt[mi][q];
+        }
+    }
+}
+
+template <int K, int D, int C, int WM, int WN, int NI>
+__global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_x3_kernel(const ttsamd_resblock_args a)
+{
+    using G = ResGeom<K, D, C, WM, WN, NI>;
+    constexpr int MI = G::kMI;
+    constexpr int NCH = G::kNCh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs3[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const ConvTile tile = conv_tile_of_block();
+    const int b = tile.b;
+    const int t0 = tile.nb * G::kBN;      // first output column of this block
+    const int T = a.t;
+    constexpr int kOob = kConvOob;
+
+    const long slab = (long)C * T * 4;    // one item's [C, T] tensor (contiguous rows)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * C * T, slab);
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(a.mask ? a.mask + (long)b * T : nullptr, a.mask ? (long)T * 4 : 0);
+    const bool has_mask = a.mask != nullptr;
+
+    // ---- stage the x tile: columns [t0 - H2 - H1, +kXW) of all C channels, leaky-ReLU'd and split, into LDS ----------
+    {
+        const int tx0 = t0 - G::kH2 - G::kH1;
+        const int row_bytes = T * 4;
+        constexpr int kBatch = G::kRounds < 6 ? G::kRounds : 6;   // rounds whose loads are in flight together (8 dwords each)
+#pragma unroll 1
+        for (int r0 = 0; r0 < G::kRounds; r0 += kBatch) {
+            float st[kBatch][8];
+            float sm[kBatch];
+#pragma unroll
+            for (int rr = 0; rr < kBatch; ++rr) {
+                const int e = tid + (r0 + rr) * G::kThreads;
+                const int pl = e / G::kXW;                 // chunk * 2 + half
+                const int col = e - pl * G::kXW;
+                const int gt = tx0 + col;
+                const bool ok = (e < G::kItems) && (gt >= 0) && (gt < T);
+                const int off = ok ? (pl * 8 * row_bytes + gt * 4) : kOob;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off == kOob ? kOob : off + i * row_bytes, 0);
+                sm[rr] = has_mask ? ld_buf(rmask, ok ? gt * 4 : kOob, 0) : 1.f;
+            }
+#pragma unroll
+            for (int rr = 0; rr < kBatch; ++rr) {
+                const int e = tid + (r0 + rr) * G::kThreads;
+                const int pl = e / G::kXW;
+                const int col = e - pl * G::kXW;
+                if (e < G::kItems) {
+                    unsigned p[3][8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        conv_split3(conv_in_act(st[rr][i] * sm[rr], TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        u32x4 w;
+                        w.x = p[q][0] | (p[q][1] << 16);
+                        w.y = p[q][2] | (p[q][3] << 16);
+                        w.z = p[q][4] | (p[q][5] << 16);
+                        w.w = p[q][6] | (p[q][7] << 16);
+                        *reinterpret_cast<u32x4 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneX + col * 16) = w;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- conv1 ------------------------------------------------------------------------------------------------------
+    const u32x4 *wp1[MI], *wp2[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long mtile = (long)wm * MI + mi;
+        wp1[mi] = reinterpret_cast<const u32x4 *>(a.w1_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
+        wp2[mi] = reinterpret_cast<const u32x4 *>(a.w2_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
+    }
+    u32x4 a_cur[MI][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp1[mi][q * 64];
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    __syncthreads();
+    res_conv_mainloop<K, D, MI, NI, NCH, G::kPlaneX>(acc, wp1, a_cur, rs3 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
+
+    // conv2's first weight fragments: requested before the mid epilogue so that their latency hides behind it
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp2[mi][q * 64];
+
+    // ---- mid epilogue: (acc + bias1) * mask -> leaky ReLU -> 3-way split -> LDS (same bytes as the x tile) ------------
+    {
+        float mk[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 - G::kH2 + (wn * NI + ni) * 32 + j;      // time of this lane's mid column
+            const bool ok = (t >= 0) && (t < T);                      // outside the tensor conv2 sees its zero padding
+            mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
+        }
+        float bia[MI][16];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                bia[mi][r] = a.bias1 ? a.bias1[row] : 0.f;
+            }
+        __syncthreads();                                               // every wave is done reading the x tile
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = (wn * NI + ni) * 32 + j;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    unsigned p[3][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = (acc[mi][ni][rg * 4 + i] + bia[mi][rg * 4 + i]) * mk[ni];
+                        conv_split3(conv_in_act(v, TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
+                    }
+                    // rows 8*rg + 4*h + i of m-tile (wm*MI + mi): chunk 2*mtile + rg/2, 8-channel half rg%2, channels 4h..4h+3
+                    const int pl = (2 * (wm * MI + mi) + (rg >> 1)) * 2 + (rg & 1);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        u32x2 w;
+                        w.x = p[q][0] | (p[q][1] << 16);
+                        w.y = p[q][2] | (p[q][3] << 16);
+                        *reinterpret_cast<u32x2 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneM + col * 16 + h * 8) = w;
+                    }
+                }
+            }
+    }
+
+    // ---- conv2: accumulators start from the residual x (the tile's own columns: L2 hits) -------------------------------
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row0 = (wm * MI + mi) * 32;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int o = (wn * NI + ni) * 32 + j;
+            const int t = t0 + o;
+            const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+        }
+    }
+    __syncthreads();                                                   // the mid tile is complete
+    res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc, wp2, a_cur, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
+
+    // ---- output epilogue: + bias2 (+ accum) (/ div) -------------------------------------------------------------------
+    {
+        const ttsamd_resblock_args __attribute__((address_space(4))) *ep =
+            (const ttsamd_resblock_args __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ep) : : "memory");
+        const float *bias2 = ep->bias2;
+        const float out_div = ep->out_div;
+        const bool has_accum = ep->accum != nullptr;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(ep->y + (long)b * C * T, slab);
+        const __amdgpu_buffer_rsrc_t racc = make_rsrc(has_accum ? ep->accum + (long)b * C * T : nullptr, has_accum ? slab : 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row0 = (wm * MI + mi) * 32;
+            float radd[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) radd[r] = bias2 ? bias2[row0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int o = (wn * NI + ni) * 32 + j;
+                const int t = t0 + o;
+                const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+                float e2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e2[r] = 0.f;
+                if (has_accum) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mi][ni][r] + radd[r];
+                    v += 0.f;                    // (the unfused epilogue's absent-operand add: keeps -0.0 handling identical)
+                    v = e2[r] + v;
+                    if (out_div != 0.f) v = v / out_div;
+                    st_buf(ry, v, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+                }
+            }
+        }
+    }
+}
+
+template <int K, int D, int C, int WM, int WN, int NI>
+int resblock_pair_launch_cfg(const ttsamd_resblock_args &a, hipStream_t st)
+{
+    using G = ResGeom<K, D, C, WM, WN, NI>;
+    auto kern = resblock_pair_x3_kernel<K, D, C, WM, WN, NI>;
+    static std::atomic<unsigned long long> lds_attr_done{0};
+    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)G::kLdsBytes, lds_attr_done));
+    const int nblocks = (a.t + G::kBN - 1) / G::kBN;
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, a.batch), dim3(G::kThreads), G::kLdsBytes, st, a);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+// Tile per channel count (a.variant selects alternatives for A/B measurements; 0 = default):
+//   C = 32 : 4 waves as 1x4, NI = 2 -> 256 mid columns, 59 KB LDS at K=11 D=5 (2 blocks / CU)
+//   C = 64 : 8 waves as 2x4, NI = 2 -> 256 mid columns, 117 KB (1 block / CU, 2 waves / SIMD);  variant 1: 4 waves 2x2, 128 columns
+//   C = 128: 8 waves as 4x2, NI = 2 -> 128 mid columns, 137 KB (1 block / CU)
+template <int K, int D>
+int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
+{
+    switch (a.c) {
+        case 32: return resblock_pair_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
+        case 64:
+            if (a.variant == 1) return resblock_pair_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
+            return resblock_pair_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
+        case 128: return resblock_pair_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
+    }
+    set_error("resblock_pair: c = %d has no instantiation (32, 64, 128)", a.c);
+    return TTSAMD_ERR_UNSUPPORTED;
+}
+
+template <int K>
+int resblock_pair_launch_k(const ttsamd_resblock_args &a, hipStream_t st)
+{
+    switch (a.dilation) {
+        case 1: return resblock_pair_launch_kd<K, 1>(a, st);
+        case 3: return resblock_pair_launch_kd<K, 3>(a, st);
+        case 5: return resblock_pair_launch_kd<K, 5>(a, st);
+    }
+    set_error("resblock_pair: dilation %d has no instantiation (1, 3, 5)", a.dilation);
+    return TTSAMD_ERR_UNSUPPORTED;
+}
+
+int resblock_pair_launch_k3(const ttsamd_resblock_args &a, hipStream_t st);
+int resblock_pair_launch_k7(const ttsamd_resblock_args &a, hipStream_t st);
+int resblock_pair_launch_k11(const ttsamd_resblock_args &a, hipStream_t st);
+
+}  // namespace ttsamd

@@ -50,6 +50,11 @@ class HifiganGenerator:
         self._sd = None
         self._packed = None
         self.concurrent_branches = True     # MRF resblocks on separate HIP streams (see forward)
+        # ResBlock1 iterations (lrelu -> conv(k,d) -> lrelu -> conv(k,1) -> +x) run as ONE fused launch where the kernel
+        # covers the shape (C in {32,64,128} per `fuse_channels`, split-bf16 arithmetic): the intermediate tensor stays in
+        # LDS, 5 HBM tensor passes -> 2.  Bitwise equal to the unfused pair.
+        self.fuse_resblocks = True
+        self.fuse_channels = (32, 64)
         self._side_streams = []
 
     def hop_length(self):
@@ -194,8 +199,9 @@ class HifiganGenerator:
             for j in range(nk):
                 rp = "resblocks.%d." % (i * nk + j)
                 dil = self.resblock_dilation_sizes[j]
-                tmp, xa, xb = new(ch, T), new(ch, T), new(ch, T)
-                keep += [tmp, xa, xb]
+                xa, xb = new(ch, T), new(ch, T)
+                tmp = None               # conv1 -> conv2 intermediate of an UNFUSED ResBlock1 iteration (allocated on first use)
+                keep += [xa, xb]
                 st = side[j] if side else main
                 if side:
                     st.wait_event(ev_up)
@@ -210,10 +216,20 @@ class HifiganGenerator:
                         else:
                             dst, accum, div = (xa if cur is not xa else xb), None, 0.0
                         if self.resblock_type == "1":
-                            ops.conv1d(P[rp + "convs1.%d" % m], cur, tmp, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, in_mask=msk)
+                            pc1, pc2 = P[rp + "convs1.%d" % m], P[rp + "convs2.%d" % m]
+                            if self.fuse_resblocks and ch in self.fuse_channels and ops.resblock_pair_supported(pc1, pc2):
+                                if last and side and prev_done is not None:
+                                    st.wait_event(prev_done)      # zsum holds the previous branches' sum
+                                ops.resblock_pair(pc1, pc2, cur, dst, slope=LRELU_SLOPE, mask=msk, accum=accum, out_div=div)
+                                cur = dst
+                                continue
+                            if tmp is None:
+                                tmp = new(ch, T)
+                                keep.append(tmp)
+                            ops.conv1d(pc1, cur, tmp, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, in_mask=msk)
                             if last and side and prev_done is not None:
                                 st.wait_event(prev_done)      # zsum holds the previous branches' sum
-                            ops.conv1d(P[rp + "convs2.%d" % m], tmp, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
+                            ops.conv1d(pc2, tmp, dst, in_act=ACT_LRELU, in_slope=LRELU_SLOPE,
                                        res=cur, accum=accum, out_div=div, in_mask=msk)
                         else:
                             if last and side and prev_done is not None:

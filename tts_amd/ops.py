@@ -168,6 +168,52 @@ def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, 
     return y
 
 
+class ResblockArgs(ctypes.Structure):
+    """Mirror of `ttsamd_resblock_args` (include/tts_amd.h)."""
+
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("accum", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+        ("w1_split", ctypes.c_void_p), ("bias1", ctypes.c_void_p), ("w2_split", ctypes.c_void_p), ("bias2", ctypes.c_void_p),
+        ("c", ctypes.c_int32), ("t", ctypes.c_int32), ("batch", ctypes.c_int32),
+        ("kernel", ctypes.c_int32), ("dilation", ctypes.c_int32),
+        ("slope", ctypes.c_float), ("out_div", ctypes.c_float), ("variant", ctypes.c_int32),
+    ]
+
+
+def resblock_pair_supported(pc1: PackedConv, pc2: PackedConv):
+    """True when the fused ResBlock1-iteration kernel covers this conv pair (split-bf16 arithmetic only)."""
+    return (_PRECISION == "x3" and pc1.c_in == pc1.c_out == pc2.c_in == pc2.c_out and pc1.kernel == pc2.kernel
+            and pc2.dilation == 1 and bool(lib().ttsamd_resblock_pair_supported(pc1.c_out, pc1.kernel, pc1.dilation)))
+
+
+def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, accum=None, out_div=0.0, variant=0):
+    """y = conv2(lrelu(conv1(lrelu(x*mask)) * mask)) + x [+ accum] [/ out_div] as ONE launch (ttsamd_resblock_pair):
+    one ResBlock1 iteration, hifigan_generator.py:90-98.  Bitwise equal to the two conv1d launches it replaces."""
+    B, C, T = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and x.dtype == y.dtype == torch.float32
+    assert accum is None or (accum.is_contiguous() and accum.shape == x.shape)
+    a = ResblockArgs()
+    a.x, a.y, a.accum, a.mask = x.data_ptr(), y.data_ptr(), _dp(accum), _dp(mask)
+    a.w1_split, a.bias1, a.w2_split, a.bias2 = pc1.w_split.data_ptr(), _dp(pc1.bias), pc2.w_split.data_ptr(), _dp(pc2.bias)
+    a.c, a.t, a.batch, a.kernel, a.dilation = C, T, B, pc1.kernel, pc1.dilation
+    a.slope, a.out_div, a.variant = slope, out_div, variant
+    if _TIMER is not None:
+        sel = getattr(_TIMER, "select_pair", None)
+        key = sel(pc1, a) if sel is not None else "fused resblock pair c%d k%d d%d" % (C, pc1.kernel, pc1.dilation)
+        if key is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().ttsamd_resblock_pair(ctypes.byref(a), stream_ptr()), "resblock_pair")
+            e1.record()
+            flops = 2 * 2.0 * C * C * pc1.kernel * T * B
+            # algorithmic HBM bytes of the fused pair: x read once, y written once (+ the accumulate operand)
+            nbytes = 4.0 * C * T * B * (2 + (accum is not None))
+            _TIMER.records.append((key, flops, nbytes, e0, e1))
+            return y
+    check(lib().ttsamd_resblock_pair(ctypes.byref(a), stream_ptr()), "resblock_pair")
+    return y
+
+
 def fold_weight_norm(sd, name):
     """Effective conv weight from a reference-layout state_dict entry: plain `.weight`, torch>=2.1
     parametrizations (`original0`=g, `original1`=v) or legacy `weight_g/weight_v`.
