@@ -197,8 +197,12 @@ def _conv64(x, w, b, K, D):
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 7, 1, 400), (1, 256, 256, 11, 1, 260), (2, 32, 32, 3, 5, 900)])
 def test_split_bf16_maximal_residual_operands_vs_fp64(gpu, case, conv_precision):
-    """Both operands built to maximise the dropped products; the error against an fp64 conv must stay fp32-class: no worse
-    than twice what torch's own fp32 CPU conv makes on the same data (or 2^-22 of sum|w x|, whichever is larger)."""
+    """Both operands built to maximise the dropped products; the error against an fp64 conv must stay fp32-class: below
+    2^-20 of sum|w x| on BOTH arithmetic paths (the classical worst-case bound of an fp32 dot product of this length is
+    K * 2^-24 = 2^-15..2^-12.5 of sum|w x|; a random-walk estimate sqrt(K) * 2^-24 = 2^-19.6..2^-18.3).
+    Measured on MI355X (max over outputs, K = 448 / 2816 / 96): split-bf16 5.0e-7 / 3.5e-7 / ~2e-7, the exact fp32-input
+    MFMA path (a plain fmaf chain) 5.3e-7 at K = 2816 — i.e. the split path is no worse than sequential fp32 FMA — and
+    torch's fp32 CPU conv (blocked, pairwise-like summation) 2.3e-7 / 8.4e-8."""
     B, Cin, Cout, K, D, T = case
     rng = np.random.default_rng(sum(case))
     x = _max_residual_values(rng, (B, Cin, T), 120, 130)        # |x| in [2^-7, 2^4)
@@ -210,7 +214,7 @@ def test_split_bf16_maximal_residual_operands_vs_fp64(gpu, case, conv_precision)
     err_gpu = float(((y.cpu().double() - want).abs() / scale).max())
     err_cpu = float(((F.conv1d(x, w, None, padding=(K - 1) * D // 2, dilation=D).double() - want).abs() / scale).max())
     print("max |err| / sum|wx|: gpu %.3e, torch fp32 cpu %.3e (%s)" % (err_gpu, err_cpu, conv_precision))
-    assert err_gpu <= max(2.0 * err_cpu, 2.0 ** -22), (err_gpu, err_cpu)
+    assert err_gpu < 2.0 ** -20, (err_gpu, err_cpu)
     assert _rel(y, want) < TOL
 
 
@@ -230,7 +234,7 @@ def test_split_bf16_cancellation_k2816_vs_fp64(gpu, conv_precision):
     err_cpu = float(((F.conv1d(x, w, None, padding=5).double() - want).abs() / scale).max())
     print("cancellation: |result|/sum|wx| median %.2e; max err/sum|wx|: gpu %.3e, torch fp32 cpu %.3e"
           % (float((want.abs() / scale).median()), err_gpu, err_cpu))
-    assert err_gpu <= max(2.0 * err_cpu, 2.0 ** -22), (err_gpu, err_cpu)
+    assert err_gpu < 2.0 ** -20, (err_gpu, err_cpu)
 
 
 def test_split_bf16_tiny_activations_flush_bound(gpu, conv_precision):

@@ -88,6 +88,26 @@ def test_fused_pair_mask_accum_div_and_edges(gpu, case):
     assert _rel(y, _torch_ref(w, x, mask, acc, div, K, D)) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(32, 11, 5, 3, 60000), (64, 3, 1, 2, 120000), (64, 7, 3, 5, 30011), (128, 11, 1, 4, 20000)])
+def test_fused_pair_persistent_blocks_many_tiles(gpu, case):
+    """More (item, tile) pairs than resident blocks: every block walks a run of tiles (crossing item boundaries) with the
+    next tile's x prefetched during the current tile's second conv — still bitwise the two-launch result; and the
+    one-tile-per-block launch (variant bit 1) gives the same bits."""
+    C, K, D, B, T = case
+    w, pc1, pc2, g = _pair(C, K, D, sum(case), gpu)
+    x = torch.randn(B, C, T, generator=g).to(gpu)
+    lens = torch.tensor([T - 1234 * i for i in range(B)])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(gpu)
+    acc = torch.randn(B, C, T, generator=g).to(gpu)
+    y = torch.full((B, C, T), float("nan"), device=gpu)
+    ops.resblock_pair(pc1, pc2, x, y, slope=SLOPE, mask=mask, accum=acc, out_div=3.0)
+    want = _unfused(pc1, pc2, x, mask, acc, 3.0)
+    assert torch.equal(y, want), float((y - want).abs().max())
+    y2 = torch.full((B, C, T), float("nan"), device=gpu)
+    ops.resblock_pair(pc1, pc2, x, y2, slope=SLOPE, mask=mask, accum=acc, out_div=3.0, variant=2)
+    assert torch.equal(y2, want)
+
+
 def test_fused_pair_alternative_tile_and_limits(gpu):
     w, pc1, pc2, g = _pair(64, 11, 5, 9, gpu)
     x = torch.randn(2, 64, 900, generator=g).to(gpu)

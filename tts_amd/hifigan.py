@@ -8,6 +8,8 @@ stripped).  78 fused conv launches per call: leaky-ReLU lives in each conv's pro
 residual add / MRF accumulate-and-average / tanh in its epilogue; ConvTranspose1d runs as a
 polyphase 2-tap conv with a pixel-shuffle epilogue.  No elementwise passes over HBM remain.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -53,8 +55,8 @@ class HifiganGenerator:
         # ResBlock1 iterations (lrelu -> conv(k,d) -> lrelu -> conv(k,1) -> +x) run as ONE fused launch where the kernel
         # covers the shape (C in {32,64,128} per `fuse_channels`, split-bf16 arithmetic): the intermediate tensor stays in
         # LDS, 5 HBM tensor passes -> 2.  Bitwise equal to the unfused pair.
-        self.fuse_resblocks = True
-        self.fuse_channels = (32, 64)
+        self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
+        self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "32,64").split(",") if c)
         self._side_streams = []
 
     def hop_length(self):
@@ -281,10 +283,12 @@ class HifiganGenerator:
         `lengths` [B] (frames, optional) = ragged-exact batching (see forward): row b's first
         (lengths[b] + 2*pad)*hop samples equal `inference(c[b:b+1, :, :lengths[b]])`."""
         c = c.to(self.device).contiguous().float()
+        if lengths is not None:
+            lengths = torch.as_tensor(lengths).to(self.device, torch.int64)     # the pad kernel reads them on the device
         p = self.inference_padding
         if p > 0:
             B, C, T = c.shape
             cp = torch.empty((B, C, T + 2 * p), dtype=torch.float32, device=c.device)
             ops.replicate_pad(c, cp, p, lengths)
             c = cp
-        return self.forward(c, lengths=None if lengths is None else lengths.to(self.device) + 2 * p)
+        return self.forward(c, lengths=None if lengths is None else lengths + 2 * p)
