@@ -180,7 +180,6 @@ typedef struct ttsamd_resblock_args {
     float slope;            /* leaky-ReLU slope of both activations */
     float out_div;
     int32_t variant;        /* 0 = default tile; other values select alternative tiles (measurement only) */
-    void *dbg;              /* NULL.  (-DTTSAMD_PHASE_CLOCKS debug builds write 9 int64 phase stamps of one block here) */
 } ttsamd_resblock_args;
 int ttsamd_resblock_pair(const ttsamd_resblock_args *args /* host */, void *stream);
 int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);

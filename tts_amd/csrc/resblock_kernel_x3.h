@@ -92,13 +92,11 @@ __device__ __forceinline__ void res_conv_mainloop(f32x16 (&acc)[MI][NI], const u
 }
 
 template <int K, int D, int C, int WM, int WN, int NI>
-__global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_x3_kernel(
-    const ttsamd_resblock_args a, int tiles_per_item, int total_tiles, int tiles_per_block)
+__global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_x3_kernel(const ttsamd_resblock_args a)
 {
     using G = ResGeom<K, D, C, WM, WN, NI>;
     constexpr int MI = G::kMI;
     constexpr int NCH = G::kNCh;
-    constexpr int kOob = kConvOob;
     extern __shared__ __attribute__((aligned(16))) unsigned char rs3[];
 
     const int tid = threadIdx.x;
@@ -108,70 +106,63 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
     const int wn = wave % WN;
     const int h = lane >> 5;
     const int j = lane & 31;
+    const ConvTile tile = conv_tile_of_block();
+    const int b = tile.b;
+    const int t0 = tile.nb * G::kBN;      // first output column of this block
     const int T = a.t;
-    const int row_bytes = T * 4;
+    constexpr int kOob = kConvOob;
+
     const long slab = (long)C * T * 4;    // one item's [C, T] tensor (contiguous rows)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * C * T, slab);
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(a.mask ? a.mask + (long)b * T : nullptr, a.mask ? (long)T * 4 : 0);
     const bool has_mask = a.mask != nullptr;
 
-    // Persistent block: a contiguous run of (item, time tile) pairs, software-pipelined — the x tile of pair u+1 is
-    // requested from HBM while pair u's second conv runs and is split into LDS once pair u is done with it, so that no
-    // HBM latency sits between two tiles' MFMA phases; biases stay in registers across tiles.
-    const int first = blockIdx.x * tiles_per_block;
-    const int last = (first + tiles_per_block < total_tiles) ? first + tiles_per_block : total_tiles;
-    if (first >= last) return;
-#ifdef TTSAMD_PHASE_CLOCKS
-    // debug build only (scripts/resblock_phases.py): shader-clock stamps of one mid-grid block's 2nd tile go to a.dbg
-    long long pc[10];
-    long long prt0 = 0;
-#define RB_STAMP(i) pc[i] = clock64()
-#else
-#define RB_STAMP(i)
-#endif
-
-    float st[G::kRounds][8];   // x tile in flight: (chunk, half, column) items of this thread, 8 channels each
-    float sm[G::kRounds];      // their mask values
-    auto issue_x_loads = [&](int u) {
-        const int b = u / tiles_per_item;
-        const int tx0 = (u - b * tiles_per_item) * G::kBN - G::kH2 - G::kH1;
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * C * T, slab);
-        const __amdgpu_buffer_rsrc_t rm = make_rsrc(has_mask ? a.mask + (long)b * T : nullptr, has_mask ? (long)T * 4 : 0);
+    // ---- stage the x tile: columns [t0 - H2 - H1, +kXW) of all C channels, leaky-ReLU'd and split, into LDS ----------
+    {
+        const int tx0 = t0 - G::kH2 - G::kH1;
+        const int row_bytes = T * 4;
+        constexpr int kBatch = G::kRounds < 6 ? G::kRounds : 6;   // rounds whose loads are in flight together (8 dwords each)
+#pragma unroll 1
+        for (int r0 = 0; r0 < G::kRounds; r0 += kBatch) {
+            float st[kBatch][8];
+            float sm[kBatch];
 #pragma unroll
-        for (int rr = 0; rr < G::kRounds; ++rr) {
-            const int e = tid + rr * G::kThreads;
-            const int pl = e / G::kXW;                 // chunk * 2 + half
-            const int col = e - pl * G::kXW;
-            const int gt = tx0 + col;
-            const bool ok = (e < G::kItems) && (gt >= 0) && (gt < T);
-            const int off = ok ? (pl * 8 * row_bytes + gt * 4) : kOob;
+            for (int rr = 0; rr < kBatch; ++rr) {
+                const int e = tid + (r0 + rr) * G::kThreads;
+                const int pl = e / G::kXW;                 // chunk * 2 + half
+                const int col = e - pl * G::kXW;
+                const int gt = tx0 + col;
+                const bool ok = (e < G::kItems) && (gt >= 0) && (gt < T);
+                const int off = ok ? (pl * 8 * row_bytes + gt * 4) : kOob;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off == kOob ? kOob : off + i * row_bytes, 0);
-            sm[rr] = has_mask ? ld_buf(rm, ok ? gt * 4 : kOob, 0) : 1.f;
-        }
-    };
-    auto split_store_x = [&]() {
+                for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off == kOob ? kOob : off + i * row_bytes, 0);
+                sm[rr] = has_mask ? ld_buf(rmask, ok ? gt * 4 : kOob, 0) : 1.f;
+            }
 #pragma unroll
-        for (int rr = 0; rr < G::kRounds; ++rr) {
-            const int e = tid + rr * G::kThreads;
-            const int pl = e / G::kXW;
-            const int col = e - pl * G::kXW;
-            if (e < G::kItems) {
-                unsigned p[3][8];
+            for (int rr = 0; rr < kBatch; ++rr) {
+                const int e = tid + (r0 + rr) * G::kThreads;
+                const int pl = e / G::kXW;
+                const int col = e - pl * G::kXW;
+                if (e < G::kItems) {
+                    unsigned p[3][8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    conv_split3(conv_in_act(st[rr][i] * sm[rr], TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
+                    for (int i = 0; i < 8; ++i)
+                        conv_split3(conv_in_act(st[rr][i] * sm[rr], TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    u32x4 w;
-                    w.x = p[q][0] | (p[q][1] << 16);
-                    w.y = p[q][2] | (p[q][3] << 16);
-                    w.z = p[q][4] | (p[q][5] << 16);
-                    w.w = p[q][6] | (p[q][7] << 16);
-                    *reinterpret_cast<u32x4 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneX + col * 16) = w;
+                    for (int q = 0; q < 3; ++q) {
+                        u32x4 w;
+                        w.x = p[q][0] | (p[q][1] << 16);
+                        w.y = p[q][2] | (p[q][3] << 16);
+                        w.z = p[q][4] | (p[q][5] << 16);
+                        w.w = p[q][6] | (p[q][7] << 16);
+                        *reinterpret_cast<u32x4 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneX + col * 16) = w;
+                    }
                 }
             }
         }
-    };
+    }
 
+    // ---- conv1 ------------------------------------------------------------------------------------------------------
     const u32x4 *wp1[MI], *wp2[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -179,83 +170,47 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
         wp1[mi] = reinterpret_cast<const u32x4 *>(a.w1_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
         wp2[mi] = reinterpret_cast<const u32x4 *>(a.w2_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
     }
-    // biases of this lane's 16 rows per m-tile: loaded once per block
-    float bia1[MI][16], bia2[MI][16];
+    u32x4 a_cur[MI][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp1[mi][q * 64];
+
+    // operands of the mid epilogue, requested here so that their latency hides behind conv1's main loop
+    float mk[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int t = t0 - G::kH2 + (wn * NI + ni) * 32 + j;      // time of this lane's mid column
+        const bool ok = (t >= 0) && (t < T);                      // outside the tensor conv2 sees its zero padding
+        mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
+    }
+    float bia[MI][16];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            bia1[mi][r] = a.bias1 ? a.bias1[row] : 0.f;
-            bia2[mi][r] = a.bias2 ? a.bias2[row] : 0.f;
+            bia[mi][r] = a.bias1 ? a.bias1[row] : 0.f;
         }
-    const float out_div = a.out_div;
-    const bool has_accum = a.accum != nullptr;
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    __syncthreads();
+    res_conv_mainloop<K, D, MI, NI, NCH, G::kPlaneX>(acc, wp1, a_cur, rs3 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
 
-    issue_x_loads(first);
-#pragma unroll 1
-    for (int u = first; u < last; ++u) {
-        const int b = u / tiles_per_item;
-        const int t0 = (u - b * tiles_per_item) * G::kBN;      // first output column of this tile
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * C * T, slab);
-        const __amdgpu_buffer_rsrc_t rmask = make_rsrc(has_mask ? a.mask + (long)b * T : nullptr, has_mask ? (long)T * 4 : 0);
-#ifdef TTSAMD_PHASE_CLOCKS
-        if (u == first + 1) { pc[0] = clock64(); prt0 = wall_clock64(); }
-#endif
-        __syncthreads();                       // the previous tile's conv2 is done reading the LDS image
-        split_store_x();                       // x tile: leaky-ReLU'd, split, into LDS
-        RB_STAMP(1);
+    // conv2's first weight fragments: requested before the mid epilogue so that their latency hides behind it
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp2[mi][q * 64];
 
-        // ---- conv1 ----------------------------------------------------------------------------------------------
-        u32x4 a_cur[MI][3];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp1[mi][q * 64];
-        float mk[NI];                          // mask of this lane's mid columns (outside the tensor: conv2's zero padding)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int t = t0 - G::kH2 + (wn * NI + ni) * 32 + j;
-            const bool ok = (t >= 0) && (t < T);
-            mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
-        }
-        f32x16 acc[MI][NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        __syncthreads();
-        RB_STAMP(2);
-        res_conv_mainloop<K, D, MI, NI, NCH, G::kPlaneX>(acc, wp1, a_cur, rs3 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
-        RB_STAMP(3);
-
-        // ---- requests for what comes next, oldest-needed first (vmcnt retires in order): conv2's first weight
-        // fragments, the residual (conv2's accumulators start from x: the tile's own columns, L2 hits), then the NEXT
-        // tile's x — its HBM latency hides behind the mid epilogue and conv2
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp2[mi][q * 64];
-        f32x16 acc2[MI][NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int row0 = (wm * MI + mi) * 32;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int o = (wn * NI + ni) * 32 + j;
-                const int t = t0 + o;
-                const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-            }
-        }
-        if (u + 1 < last) issue_x_loads(u + 1);
-        __syncthreads();                       // every wave is done reading the x tile
-        RB_STAMP(4);
-
-        // ---- mid epilogue: (acc + bias1) * mask -> leaky ReLU -> 3-way split -> LDS (same bytes as the x tile) ------
+    // ---- mid epilogue: (acc + bias1) * mask -> leaky ReLU -> 3-way split -> LDS (same bytes as the x tile) ------------
+    {
+        __syncthreads();                                               // every wave is done reading the x tile
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -266,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                     unsigned p[3][4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float v = (acc[mi][ni][rg * 4 + i] + bia1[mi][rg * 4 + i]) * mk[ni];
+                        const float v = (acc[mi][ni][rg * 4 + i] + bia[mi][rg * 4 + i]) * mk[ni];
                         conv_split3(conv_in_act(v, TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
                     }
                     // rows 8*rg + 4*h + i of m-tile (wm*MI + mi): chunk 2*mtile + rg/2, 8-channel half rg%2, channels 4h..4h+3
@@ -280,66 +235,65 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                     }
                 }
             }
-        RB_STAMP(5);
-        __syncthreads();                       // the mid tile is complete
-        RB_STAMP(6);
+    }
 
-        // ---- conv2 ------------------------------------------------------------------------------------------------
-        res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc2, wp2, a_cur, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
-        RB_STAMP(7);
+    // ---- conv2: accumulators start from the residual x (the tile's own columns: L2 hits) -------------------------------
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row0 = (wm * MI + mi) * 32;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int o = (wn * NI + ni) * 32 + j;
+            const int t = t0 + o;
+            const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+        }
+    }
+    float bia2[MI][16];      // output bias: requested ahead of conv2's main loop
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bia2[mi][r] = a.bias2 ? a.bias2[(wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    __syncthreads();                                                   // the mid tile is complete
+    res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc, wp2, a_cur, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
 
-        // ---- output epilogue: + bias2 (+ accum) (/ div); stores are fire-and-forget ----------------------------------
-        {
-            const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y + (long)b * C * T, slab);
-            const __amdgpu_buffer_rsrc_t racc = make_rsrc(has_accum ? a.accum + (long)b * C * T : nullptr, has_accum ? slab : 0);
+    // ---- output epilogue: + bias2 (+ accum) (/ div) -------------------------------------------------------------------
+    {
+        const ttsamd_resblock_args __attribute__((address_space(4))) *ep =
+            (const ttsamd_resblock_args __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ep) : : "memory");
+        const float out_div = ep->out_div;
+        const bool has_accum = ep->accum != nullptr;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(ep->y + (long)b * C * T, slab);
+        const __amdgpu_buffer_rsrc_t racc = make_rsrc(has_accum ? ep->accum + (long)b * C * T : nullptr, has_accum ? slab : 0);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int row0 = (wm * MI + mi) * 32;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row0 = (wm * MI + mi) * 32;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int o = (wn * NI + ni) * 32 + j;
-                    const int t = t0 + o;
-                    const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-                    float e2[16];
+            for (int ni = 0; ni < NI; ++ni) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int o = (wn * NI + ni) * 32 + j;
+                const int t = t0 + o;
+                const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+                float e2[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) e2[r] = 0.f;
-                    if (has_accum) {
+                for (int r = 0; r < 16; ++r) e2[r] = 0.f;
+                if (has_accum) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-                    }
+                    for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+                }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc2[mi][ni][r] + bia2[mi][r];
-                        v += 0.f;                // (the unfused epilogue's absent-operand add: keeps -0.0 handling identical)
-                        v = e2[r] + v;
-                        if (out_div != 0.f) v = v / out_div;
-                        st_buf(ry, v, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mi][ni][r] + bia2[mi][r];
+                    v += 0.f;                    // (the unfused epilogue's absent-operand add: keeps -0.0 handling identical)
+                    v = e2[r] + v;
+                    if (out_div != 0.f) v = v / out_div;
+                    st_buf(ry, v, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
                 }
             }
         }
-#ifdef TTSAMD_PHASE_CLOCKS
-        RB_STAMP(8);
-        if (u == first + 1 && a.dbg && tid == 0 && blockIdx.x == gridDim.x / 2) {
-            long long *o = reinterpret_cast<long long *>(a.dbg);
-            for (int i = 0; i < 9; ++i) o[i] = pc[i] - pc[0];
-            o[9] = wall_clock64() - prt0;
-        }
-#endif
     }
-}
-
-// CUs of the current device (cached per device).
-inline int device_cu_count()
-{
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    int v = cached[dev & 63].load(std::memory_order_relaxed);
-    if (v > 0) return v;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cached[dev & 63].store(v, std::memory_order_relaxed);
-    return v;
 }
 
 template <int K, int D, int C, int WM, int WN, int NI>
@@ -349,23 +303,16 @@ int resblock_pair_launch_cfg(const ttsamd_resblock_args &a, hipStream_t st)
     auto kern = resblock_pair_x3_kernel<K, D, C, WM, WN, NI>;
     static std::atomic<unsigned long long> lds_attr_done{0};
     TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)G::kLdsBytes, lds_attr_done));
-    const int tiles_per_item = (a.t + G::kBN - 1) / G::kBN;
-    const int total = tiles_per_item * a.batch;
-    // resident blocks: LDS-limited, at most two waves per SIMD (the kernel is compiled for that register budget)
-    const int by_lds = (int)((160 * 1024) / G::kLdsBytes);
-    const int by_waves = (G::kThreads >= 512) ? 1 : 2;
-    const int resident = device_cu_count() * (by_lds < by_waves ? by_lds : by_waves);
-    int tpb = (a.variant & 2) ? 1 : (total + resident - 1) / resident;   // variant bit 1: one tile per block (no pipelining)
-    if (tpb < 1) tpb = 1;
-    const int blocks = (total + tpb - 1) / tpb;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::kThreads), G::kLdsBytes, st, a, tiles_per_item, total, tpb);
+    const int nblocks = (a.t + G::kBN - 1) / G::kBN;
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, a.batch), dim3(G::kThreads), G::kLdsBytes, st, a);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
 
 // Tile per channel count (a.variant selects alternatives for A/B measurements; 0 = default):
 //   C = 32 : 4 waves as 1x4, NI = 2 -> 256 mid columns, 59 KB LDS at K=11 D=5 (2 blocks / CU)
-//   C = 64 : 8 waves as 2x4, NI = 2 -> 256 mid columns, 117 KB (1 block / CU, 2 waves / SIMD);  variant 1: 4 waves 2x2, 128 columns
+//   C = 64 : 4 waves as 2x2, NI = 2 -> 128 mid columns, 68 KB (2 blocks / CU);  variant 1: 8 waves 2x4, 256 columns, 117 KB
+//            (measured at the benchmark shape, us per pair, 4-wave / 8-wave: k=3 988 / 1088, k=7 1784 / 1835, k=11 2691 / 2721)
 //   C = 128: 8 waves as 4x2, NI = 2 -> 128 mid columns, 137 KB (1 block / CU)
 template <int K, int D>
 int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
@@ -373,8 +320,8 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
     switch (a.c) {
         case 32: return resblock_pair_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:
-            if (a.variant & 1) return resblock_pair_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
-            return resblock_pair_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
+            if (a.variant == 1) return resblock_pair_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
+            return resblock_pair_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
         case 128: return resblock_pair_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
     }
     set_error("resblock_pair: c = %d has no instantiation (32, 64, 128)", a.c);

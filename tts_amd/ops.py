@@ -176,7 +176,7 @@ class ResblockArgs(ctypes.Structure):
         ("w1_split", ctypes.c_void_p), ("bias1", ctypes.c_void_p), ("w2_split", ctypes.c_void_p), ("bias2", ctypes.c_void_p),
         ("c", ctypes.c_int32), ("t", ctypes.c_int32), ("batch", ctypes.c_int32),
         ("kernel", ctypes.c_int32), ("dilation", ctypes.c_int32),
-        ("slope", ctypes.c_float), ("out_div", ctypes.c_float), ("variant", ctypes.c_int32), ("dbg", ctypes.c_void_p),
+        ("slope", ctypes.c_float), ("out_div", ctypes.c_float), ("variant", ctypes.c_int32),
     ]
 
 
@@ -186,7 +186,7 @@ def resblock_pair_supported(pc1: PackedConv, pc2: PackedConv):
             and pc2.dilation == 1 and bool(lib().ttsamd_resblock_pair_supported(pc1.c_out, pc1.kernel, pc1.dilation)))
 
 
-def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, accum=None, out_div=0.0, variant=0, dbg=None):
+def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, accum=None, out_div=0.0, variant=0):
     """y = conv2(lrelu(conv1(lrelu(x*mask)) * mask)) + x [+ accum] [/ out_div] as ONE launch (ttsamd_resblock_pair):
     one ResBlock1 iteration, hifigan_generator.py:90-98.  Bitwise equal to the two conv1d launches it replaces."""
     B, C, T = x.shape
@@ -196,7 +196,7 @@ def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, a
     a.x, a.y, a.accum, a.mask = x.data_ptr(), y.data_ptr(), _dp(accum), _dp(mask)
     a.w1_split, a.bias1, a.w2_split, a.bias2 = pc1.w_split.data_ptr(), _dp(pc1.bias), pc2.w_split.data_ptr(), _dp(pc2.bias)
     a.c, a.t, a.batch, a.kernel, a.dilation = C, T, B, pc1.kernel, pc1.dilation
-    a.slope, a.out_div, a.variant, a.dbg = slope, out_div, variant, _dp(dbg)
+    a.slope, a.out_div, a.variant = slope, out_div, variant
     if _TIMER is not None and not torch.cuda.is_current_stream_capturing():
         sel = getattr(_TIMER, "select_pair", None)
         key = sel(pc1, a) if sel is not None else "fused resblock pair c%d k%d d%d" % (C, pc1.kernel, pc1.dilation)
