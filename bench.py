@@ -494,7 +494,10 @@ def wl_hifigan_v1(args, ctx):
         sub = timer_table(st.results())
     if ctx.rank != 0:
         return None
-    r = timer.results()["conv"]
+    r = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)          # plain convs ("conv") + fused ResBlock pairs
+    for v in timer.results().values():
+        for k in r:
+            r[k] += v[k]
     samples = float(out.shape[0] * out.shape[2]) * ctx.world
     value = samples * steps / elapsed_max
     line = base_line(args, ctx, "audio samples/sec (HiFiGAN-v1 vocoder only, 80-bin mels -> 22.05 kHz waveform)", value,

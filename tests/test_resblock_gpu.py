@@ -141,7 +141,7 @@ def test_hifigan_fused_equals_unfused(gpu, ragged):
     m.to(gpu)
     mel = torch.randn(3, 80, 23, generator=torch.Generator().manual_seed(6))
     lengths = torch.tensor([23, 17, 9]) if ragged else None
-    m.fuse_resblocks, m.fuse_channels = True, (32, 64, 128)
+    m.fuse_resblocks, m.fuse_channels, m.fuse_max_kernel = True, (32, 64, 128), {}
     fused = m.inference(mel.to(gpu), lengths=lengths)
     m.fuse_resblocks = False
     plain = m.inference(mel.to(gpu), lengths=lengths)

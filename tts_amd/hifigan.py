@@ -55,8 +55,11 @@ class HifiganGenerator:
         # ResBlock1 iterations (lrelu -> conv(k,d) -> lrelu -> conv(k,1) -> +x) run as ONE fused launch where the kernel
         # covers the shape (C in {32,64,128} per `fuse_channels`, split-bf16 arithmetic): the intermediate tensor stays in
         # LDS, 5 HBM tensor passes -> 2.  Bitwise equal to the unfused pair.
+        # Measured at the benchmark's stage shapes (scripts/resblock_ab.py, fused / unfused time): C=32 0.59-0.83,
+        # C=64 0.66-0.92, C=128 0.88 (k=3), 1.00 (k=7), 1.07 (k=11) -> the 128-channel stage fuses its k=3 blocks only.
         self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
-        self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "32,64").split(",") if c)
+        self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "32,64,128").split(",") if c)
+        self.fuse_max_kernel = {128: 3}     # channel count -> largest kernel size fused (absent = all)
         self._side_streams = []
 
     def hop_length(self):
@@ -219,7 +222,8 @@ class HifiganGenerator:
                             dst, accum, div = (xa if cur is not xa else xb), None, 0.0
                         if self.resblock_type == "1":
                             pc1, pc2 = P[rp + "convs1.%d" % m], P[rp + "convs2.%d" % m]
-                            if self.fuse_resblocks and ch in self.fuse_channels and ops.resblock_pair_supported(pc1, pc2):
+                            if (self.fuse_resblocks and ch in self.fuse_channels and pc1.kernel <= self.fuse_max_kernel.get(ch, 99)
+                                    and ops.resblock_pair_supported(pc1, pc2)):
                                 if last and side and prev_done is not None:
                                     st.wait_event(prev_done)      # zsum holds the previous branches' sum
                                 ops.resblock_pair(pc1, pc2, cur, dst, slope=LRELU_SLOPE, mask=msk, accum=accum, out_div=div)
