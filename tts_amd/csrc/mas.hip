@@ -21,6 +21,8 @@
 //     all waves then write complete 256-byte path row segments (zeros included).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace ttsamd {
 
 constexpr int kMasThreads = 512;          // 8 waves: 1 DP + 7 tile movers
@@ -32,10 +34,10 @@ template <int YT> struct MasTile {
 };
 
 // ---- tile movers -----------------------------------------------------------------------------
-template <int YT>
+template <int YT, int kBatch = 16>
 __device__ __forceinline__ void mas_stage_tile(float *lds, const float *in,
                                                const float *__restrict__ mask, long base, int Tx,
-                                               int Ty, int XP, int tile, int mover, int lane)
+                                               int Ty, int XP, int tile, int mover, int lane, int nmov = kMasMovers)
 {
     const int yl = lane & (YT - 1);
     const int xs = lane >> MasTile<YT>::kShift;
@@ -43,22 +45,24 @@ __device__ __forceinline__ void mas_stage_tile(float *lds, const float *in,
     const int ngroups = (Tx + MasTile<YT>::kRowsPerInstr - 1) / MasTile<YT>::kRowsPerInstr;
     // batches of 16 row groups: all loads of a batch are issued before the first LDS write (clamped addresses + select,
     // no branch between them), so a tile costs ~one HBM round trip per batch instead of one per row group
-    constexpr int kBatch = 16;
-    const bool has_mask = mask != nullptr;
-    for (int g0 = mover; g0 < ngroups; g0 += kMasMovers * kBatch) {
+    // a NULL mask reads `in` a second time (L1 hits) and multiplies by 1: one straight-line body, no branch per element
+    // (hipcc otherwise branches around every mask load and waits for each)
+    const float *mk = mask ? mask : in;
+    const float one = mask ? 0.f : 1.f;
+    for (int g0 = mover; g0 < ngroups; g0 += nmov * kBatch) {
         float v[kBatch], m[kBatch];
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            const int x = (g0 + i * kMasMovers) * MasTile<YT>::kRowsPerInstr + xs;
+            const int x = (g0 + i * nmov) * MasTile<YT>::kRowsPerInstr + xs;
             const bool ok = (x < Tx) && (y < Ty);
             const long off = ok ? base + (long)x * Ty + y : base;
             v[i] = in[off];
-            m[i] = has_mask ? mask[off] : 1.f;
+            m[i] = mk[off];
         }
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            const int x = (g0 + i * kMasMovers) * MasTile<YT>::kRowsPerInstr + xs;
-            if ((x < Tx) && (y < Ty)) lds[yl * XP + x] = has_mask ? v[i] * m[i] : v[i];
+            const int x = (g0 + i * nmov) * MasTile<YT>::kRowsPerInstr + xs;
+            if ((x < Tx) && (y < Ty)) lds[yl * XP + x] = mask ? v[i] * m[i] : v[i];
         }
     }
 }
@@ -66,14 +70,14 @@ __device__ __forceinline__ void mas_stage_tile(float *lds, const float *in,
 template <int YT>
 __device__ __forceinline__ void mas_writeback_tile(const float *lds, float *out,
                                                    long base, int Tx, int Ty, int XP, int tile,
-                                                   int mover, int lane)
+                                                   int mover, int lane, int nmov = kMasMovers)
 {
     const int yl = lane & (YT - 1);
     const int xs = lane >> MasTile<YT>::kShift;
     const int y = tile * YT + yl;
     const int ngroups = (Tx + MasTile<YT>::kRowsPerInstr - 1) / MasTile<YT>::kRowsPerInstr;
 #pragma unroll 8
-    for (int g = mover; g < ngroups; g += kMasMovers) {
+    for (int g = mover; g < ngroups; g += nmov) {
         const int x = g * MasTile<YT>::kRowsPerInstr + xs;
         if (x < Tx && y < Ty) out[base + (long)x * Ty + y] = lds[yl * XP + x];
     }
@@ -189,14 +193,135 @@ __global__ __launch_bounds__(kMasThreads) void mas_forward_kernel(
     }
 }
 
+// ---- forward DP, one wave per 64-row group (T_x <= 512) ------------------------------------------
+// The column sweep is serial in y, but row group r of column y only needs row 64r-1 of column y-1 from the group
+// below it: the R row groups run as a skewed pipeline of R waves (wave r works on column y while wave r-1 is already
+// past it), each holding ONE previous-column register.  The boundary value travels through a 64-slot LDS ring per
+// wave: the producer's lane 63 publishes {value, column tag} as ONE 8-byte ds_write, the consumer reads the slot with
+// one 8-byte ds_read — requested right after it finished its own previous column, so the LDS round trip is off the
+// serial chain whenever the producer is ahead — and re-reads only while the tag is not the column it needs.  Consumers
+// never block producers, and every wave meets the tile movers at the tile barriers (32 columns), which also bounds
+// the skew below the ring size (a slot is reused 64 columns later).  Same single fp32 add per cell as the reference
+// => bit-exact, like the one-wave kernel.
+// 12 waves per item: R DP waves + (12 - R) tile movers.  Measured on [32,257,770] (R = 5), forward kernel alone: one DP wave
+// 520 us -> this kernel 250 us; with the DP switched off the movers need 70 us, with the movers off the DP needs the same
+// 250 us: the DP waves are instruction-issue bound (~75 instructions per column and wave; waves 0 and 4 share a SIMD).
+constexpr int kMasMwWaves = 12;
+constexpr int kMasRing = 64;
+
+__global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw_kernel(
+    const float *in_values, const float *__restrict__ mask, float *dp_values, unsigned long long *__restrict__ dirs,
+    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R, float neg)
+{
+    constexpr int YT = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int XP = 64 * R + 1;
+    float *buf0 = smem;
+    float *buf1 = smem + YT * XP;
+    // [R][kMasRing] {value, column}: accessed with relaxed workgroup-scope atomics = plain ds_read_b64 / ds_write_b64 that
+    // the compiler may neither cache nor reorder against each other (a `volatile` pointer here is demoted to FLAT accesses
+    // with system-scope cache bits and a full wait after each one)
+    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + 2 * YT * XP);
+#define MAS_RING_LD(i) __hip_atomic_load(ring + (i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define MAS_RING_ST(i, v) __hip_atomic_store(ring + (i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    const int t_x = min(t_xs[b], Tx);
+    const int t_y = min(t_ys[b], Ty);
+    const long base = (long)b * Tx * Ty;
+    const int nt = (Ty + YT - 1) / YT;
+    const bool need_copy = (dp_values != nullptr);
+    const int nt_work = need_copy ? nt : ((t_x > 0 && t_y > 0) ? (min(t_y, Ty) + YT - 1) / YT : 0);
+    const bool dp_wave = wave < R;
+    const int mover = wave - R;
+    const int nmov = kMasMwWaves - R;
+
+    for (int i = threadIdx.x; i < R * kMasRing; i += blockDim.x) MAS_RING_ST(i, ~0ull);     // tag -1: nothing published
+    if (!dp_wave && nt_work > 0)
+        mas_stage_tile<YT, 16>(buf0, in_values, mask, base, Tx, Ty, XP, 0, mover, lane, nmov);
+    __syncthreads();
+
+    const int r = wave;
+    const int x = r * 64 + lane;
+    float prev = 0.f;      // this row's value in the previous column
+    for (int t = 0; t < nt_work; ++t) {
+        float *cur = (t & 1) ? buf1 : buf0;
+        float *oth = (t & 1) ? buf0 : buf1;
+        if (dp_wave) {
+            const int y_end = min(t_y, min(Ty, (t + 1) * YT));
+            if (t_x > 0) {
+                float cnext = (x < Tx && t * YT < y_end) ? cur[x] : 0.f;
+                unsigned long long wq = ~0ull;     // ring slot of the column before the one being processed
+                if (r > 0 && t > 0) wq = MAS_RING_LD((r - 1) * kMasRing + ((t * YT - 1) & (kMasRing - 1)));
+                const float *cp = cur + x;         // this lane's row in the tile, one column = XP floats
+                unsigned long long *dp = dirs + ((long)b * Ty + (t * YT - 1)) * R + r;   // bit-plane word of column y-1
+                for (int y = t * YT; y < y_end; ++y, cp += XP, dp += R) {
+                    const int x_lo = max(0, t_x + y - t_y);
+                    const int x_hi = min(t_x, y + 1);
+                    const float c = cnext;
+                    if (y + 1 < y_end) cnext = (x < Tx) ? cp[XP] : 0.f;
+                    // x-1 neighbour of the previous column: DPP wave shift inside the group, the ring across groups
+                    float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, prev), 0x138, 0xf,
+                                                                                     0xf, false));
+                    if (r > 0) {
+                        float carry = 0.f;
+                        if (y > 0) {
+                            while ((int)(wq >> 32) != y - 1) wq = MAS_RING_LD((r - 1) * kMasRing + ((y - 1) & (kMasRing - 1)));
+                            carry = __builtin_bit_cast(float, (unsigned)(wq & 0xffffffffull));
+                        }
+                        // the slot the NEXT column needs, requested a whole column ahead of its use (a miss — the wave below
+                        // has not published it yet — is re-read above; the lag then grows until these reads hit)
+                        if (y + 1 < y_end) wq = MAS_RING_LD((r - 1) * kMasRing + (y & (kMasRing - 1)));
+                        if (lane == 0) up = carry;
+                    }
+                    if (y > 0) {   // direction bit-plane of column y-1: value[x,y-1] < value[x-1,y-1]
+                        const unsigned long long bits = __ballot(x >= 1 && prev < up);
+                        if (lane == 0) *dp = bits;
+                    }
+                    const float v_cur = (x == y) ? neg : prev;
+                    const float v_prev = (x == 0) ? (y == 0 ? 0.f : neg) : up;
+                    const float nv = fmaxf(v_cur, v_prev) + c;
+                    const bool inb = (x >= x_lo) && (x < x_hi);
+                    const float keep = inb ? nv : c;
+                    prev = keep;
+                    if (need_copy && inb) const_cast<float *>(cp)[0] = keep;
+                    if (r + 1 < R && lane == 63)
+                        MAS_RING_ST(r * kMasRing + (y & (kMasRing - 1)),
+                                    ((unsigned long long)(unsigned)y << 32) | __builtin_bit_cast(unsigned, keep));
+                }
+            }
+        } else {
+            if (need_copy && t > 0)
+                mas_writeback_tile<YT>(oth, dp_values, base, Tx, Ty, XP, t - 1, mover, lane, nmov);
+            if (t + 1 < nt_work)
+                mas_stage_tile<YT, 16>(oth, in_values, mask, base, Tx, Ty, XP, t + 1, mover, lane, nmov);
+        }
+        __syncthreads();
+    }
+    if (need_copy && nt_work > 0 && !dp_wave) {
+        const float *last = ((nt_work - 1) & 1) ? buf1 : buf0;
+        mas_writeback_tile<YT>(last, dp_values, base, Tx, Ty, XP, nt_work - 1, mover, lane, nmov);
+    }
+}
+
 // ---- backtrack -------------------------------------------------------------------------------
+// Backtrack: wave 0 walks the columns from the last to the first in 64-column chunks (the index chain is serial:
+// core.pyx:34-37); per chunk every lane holds a 64-row window of its column's direction bit-plane around the index the
+// chunk starts from, and the walk itself is scalar readlane work.  The bit-planes of the NEXT chunk are requested before
+// the current chunk is walked (its start index can only be 0..64 rows below the current one: three candidate row groups
+// are fetched and two selected afterwards), and waves 1..7 write chunk c's path columns while wave 0 already walks chunk
+// c-1 (double-buffered index row, one barrier per chunk) — neither an HBM round trip nor the path stores sit on the
+// serial chain.
+constexpr int kMasBtThreads = 512;
+
 template <typename PathT>
-__global__ __launch_bounds__(256) void mas_backtrack_kernel(
+__global__ __launch_bounds__(kMasBtThreads) void mas_backtrack_kernel(
     PathT *__restrict__ paths, const unsigned long long *__restrict__ dirs,
     const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R,
     int prezeroed)
 {
-    __shared__ int s_idx[64];
+    __shared__ int s_idx[2][64];
     const int b = blockIdx.x;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -206,20 +331,34 @@ __global__ __launch_bounds__(256) void mas_backtrack_kernel(
     const long base = (long)b * Tx * Ty;
     int idx = t_x - 1;  // wave-uniform (core.pyx:18)
     const int nchunks = (Ty + 63) / 64;
+    constexpr int kWriters = kMasBtThreads / 64 - 1;
+
+    // candidate bit-planes of chunk c for a start index whose row group is rg, rg-1 (window: + one group below each)
+    unsigned long long cand[3] = {0ull, 0ull, 0ull};
+    int cand_rg = 0;
+    auto fetch = [&](int c, int rg) {
+        const int y = c * 64 + lane;
+        cand_rg = rg;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = rg - i;
+            cand[i] = (valid && wave == 0 && c >= 0 && y >= 1 && y < t_y && r >= 0)
+                          ? dirs[((long)b * Ty + (y - 1)) * R + r] : 0ull;
+        }
+    };
+    if (wave == 0) fetch(nchunks - 1, idx >> 6);
+
     for (int c = nchunks - 1; c >= 0; --c) {
         const int y_lo = c * 64;
-        const int y = y_lo + lane;
         if (wave == 0) {
             int myidx = -1;
+            const int idx0 = idx;
+            const int r0 = idx0 >> 6;
+            const int sel = cand_rg - r0;            // 0 or 1: which candidate pair belongs to this start index
+            const unsigned long long hi = sel == 0 ? cand[0] : cand[1];
+            const unsigned long long lo = sel == 0 ? cand[1] : cand[2];
+            fetch(c - 1, r0);                        // next chunk: in flight during this chunk's walk
             if (valid && y_lo < t_y) {
-                const int idx0 = idx;
-                const int r0 = idx0 >> 6;
-                unsigned long long hi = 0ull, lo = 0ull;
-                if (y >= 1 && y < t_y) {
-                    const unsigned long long *d = dirs + ((long)b * Ty + (y - 1)) * R;
-                    hi = d[r0];
-                    if (r0 > 0) lo = d[r0 - 1];
-                }
                 const int s = (idx0 & 63) + 1;  // window bit k <-> row idx0-63+k
                 const unsigned long long window = (s == 64) ? hi : ((lo >> s) | (hi << (64 - s)));
                 const int wlo = (int)(unsigned)(window & 0xffffffffull);
@@ -236,16 +375,16 @@ __global__ __launch_bounds__(256) void mas_backtrack_kernel(
                     idx -= dec ? 1 : 0;
                 }
             }
-            s_idx[lane] = myidx;
+            s_idx[c & 1][lane] = myidx;
+            if (prezeroed && myidx >= 0) paths[base + (long)myidx * Ty + y_lo + lane] = (PathT)1;
         }
-        __syncthreads();
-        const int m = s_idx[lane];
-        if (prezeroed) {
-            if (wave == 0 && m >= 0) paths[base + (long)m * Ty + y] = (PathT)1;
-        } else if (y < Ty) {
-            for (int x = wave; x < Tx; x += 4) paths[base + (long)x * Ty + y] = (x == m) ? (PathT)1 : (PathT)0;
+        __syncthreads();        // chunk c's index row is published; the writers of chunk c+1 are done with the other row
+        if (wave > 0 && !prezeroed) {
+            const int y = y_lo + lane;
+            const int m = s_idx[c & 1][lane];
+            if (y < Ty)
+                for (int x = wave - 1; x < Tx; x += kWriters) paths[base + (long)x * Ty + y] = (x == m) ? (PathT)1 : (PathT)0;
         }
-        __syncthreads();
     }
 }
 
@@ -272,6 +411,18 @@ __global__ void mask_lengths_kernel(int *__restrict__ t_xs, int *__restrict__ t_
         t_xs[b] = (int)a;
         t_ys[b] = (int)c;
     }
+}
+
+static int launch_forward_mw(const float *in, const float *mask, float *dp, unsigned long long *dirs, const int *t_xs,
+                             const int *t_ys, int B, int Tx, int Ty, int R, float neg, hipStream_t st)
+{
+    const size_t lds = ((size_t)2 * 32 * (64 * R + 1) + (size_t)2 * R * kMasRing) * sizeof(float);
+    static std::atomic<unsigned long long> lds_attr_done{0};
+    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw_kernel), 160 * 1024, lds_attr_done));
+    hipLaunchKernelGGL(mas_forward_mw_kernel, dim3(B), dim3(64 * kMasMwWaves), lds, st, in, mask, dp, dirs, t_xs, t_ys,
+                       Tx, Ty, R, neg);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
 }
 
 template <int RMAX, int YT, bool EXACT = false>
@@ -319,6 +470,10 @@ extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const fl
     hipStream_t st = as_stream(stream);
     auto *dirs = reinterpret_cast<unsigned long long *>(workspace);
     int rc;
+    static const bool single_wave = getenv("TTSAMD_MAS_SINGLE_WAVE") != nullptr;   // A/B switch: the one-DP-wave kernel
+    if (R <= 8 && !single_wave) {
+        rc = launch_forward_mw(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
+    } else
 #define TTSAMD_MAS_EXACT(n) \
     case n: rc = launch_forward<n, 32, true>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st); break;
     if (R <= 8) {
@@ -334,9 +489,9 @@ extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const fl
     if (rc != TTSAMD_OK) return rc;
     const int prezeroed = (flags & TTSAMD_MAS_PATHS_PREZEROED) ? 1 : 0;
     if (flags & TTSAMD_MAS_PATHS_F32)
-        hipLaunchKernelGGL(mas_backtrack_kernel<float>, dim3(b), dim3(256), 0, st, (float *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
+        hipLaunchKernelGGL(mas_backtrack_kernel<float>, dim3(b), dim3(kMasBtThreads), 0, st, (float *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
     else
-        hipLaunchKernelGGL(mas_backtrack_kernel<int>, dim3(b), dim3(256), 0, st, (int *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
+        hipLaunchKernelGGL(mas_backtrack_kernel<int>, dim3(b), dim3(kMasBtThreads), 0, st, (int *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
