@@ -1,23 +1,38 @@
-import sys, time, torch
-sys.path.insert(0, '.')
-from tts_amd import synthetic as W
-from tts_amd.vits import Vits
-import bench
+"""Latency of one request at small batch (VitsArgs defaults, 128-char utterance = 257 ids, 770 frames):
+python scripts/b1_latency.py [B] -> per call wall time and host-issue time, eager launches vs the two-graph path."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+from tts_amd import synthetic as W  # noqa: E402
+from tts_amd.vits import Vits  # noqa: E402
+
 dev = torch.device("cuda:0")
-m = Vits({"model_args": {}}); m.load_state_dict(W.make_vits_state({}, seed=1)); m.to(dev)
+m = Vits({"model_args": {}})
+m.load_state_dict(W.make_vits_state({}, seed=1))
+m.to(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 x, xl, dur = bench.synthetic_batch(B, 128, 0, dev)
-aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True}
-for _ in range(3): m.inference(x, aux)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 10
-for _ in range(n): o = m.inference(x, aux)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print("B=%d: %.2f ms per call, rtf_x=%.0f" % (B, dt * 1e3, B * 197120 / 22050 / dt))
-# host-only cost: time to ISSUE the decoder launches (no sync)
-z = o["z"]
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(n): w = m.waveform_decoder.forward(z)
-t_issue = (time.perf_counter() - t0) / n
-torch.cuda.synchronize(); t_total = (time.perf_counter() - t0) / n
-print("decoder: host issue %.2f ms, total %.2f ms per call" % (t_issue * 1e3, t_total * 1e3))
+for mode, extra in (("eager tail (front end graphed)", {"no_graph_tail": True}), ("two graphs (front + tail)", {}),
+                    ("all eager", {"no_graph": True})):
+    aux = dict({"x_lengths": xl, "durations": dur, "run_duration_predictor": True, "ragged_exact": B > 1}, **extra)
+    if "no_graph_tail" in extra:
+        m.graph_tail_max_frames = 0
+    else:
+        m.graph_tail_max_frames = 1 << 20
+    for _ in range(4):
+        m.inference(x, aux)
+    torch.cuda.synchronize()
+    n, t_issue = 20, 0.0
+    t0 = time.perf_counter()
+    for _ in range(n):
+        t1 = time.perf_counter()
+        o = m.inference(x, aux)
+        t_issue += time.perf_counter() - t1
+        o["model_outputs"].cpu()
+    dt = (time.perf_counter() - t0) / n
+    print("B=%d %-32s %.2f ms per request (waveform on the host), %.2f ms inside inference() [includes the duration sync], rtf_x=%.0f"
+          % (B, mode, dt * 1e3, t_issue / n * 1e3, B * 197120 / 22050 / dt), flush=True)

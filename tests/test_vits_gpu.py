@@ -368,3 +368,45 @@ def test_vits_bench_batch32_rows_match_oracle(gpu):
                               noise_z=torch.zeros(1, 192, 1))["logw"]
         assert _errs(logw[r:r + 1], lw)[1] < 1e-5, r
     print("B=32 bench step, 8 rows vs oracle: worst waveform rms %.2e rel %.2e" % worst)
+
+
+def test_vits_small_request_tail_graph_equals_eager(gpu):
+    """B = 1 requests (the reference's call pattern) replay everything after the one host sync as a hipGraph at a decoder
+    length padded to a multiple of 32 frames, ragged-exact: bit-identical to the eager launches at the true length — for
+    several lengths sharing one capture, with pinned and with self-drawn noise, and for a ragged batch."""
+    args = dict(upsample_initial_channel_decoder=64)
+    sd = W.make_vits_state(args, seed=12)
+    m = _model(args, sd, gpu)
+    g = torch.Generator().manual_seed(9)
+    T = 29
+    for rep in range(4):
+        x = torch.randint(0, 100, (1, T), generator=g).to(gpu)
+        dur = (1 + torch.randint(0, 3, (1, T), generator=g)).float()
+        t_dec = int(dur.sum())
+        aux = {"x_lengths": torch.tensor([T], device=gpu), "durations": dur.to(gpu), "run_duration_predictor": True,
+               "noise_dp": torch.randn(1, 2, T, generator=g).to(gpu), "noise_z": torch.randn(1, 192, t_dec, generator=g).to(gpu)}
+        want = m.inference(x, dict(aux, no_graph=True))
+        for _ in range(3):                       # eager, capture, replay
+            got = m.inference(x, aux)
+            for k in ("model_outputs", "alignments", "z", "z_p", "m_p", "logs_p", "y_mask", "durations"):
+                assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (rep, k)
+    assert m._tail.stats["captures"] >= 1 and m._tail.stats["replays"] >= 4, m._tail.stats
+    assert len(m._tail.entries) <= 3            # lengths 29..87 frames fall into at most three 32-frame buckets
+    out = m.inference(x, {k: v for k, v in aux.items() if k != "noise_z"})          # own randn draw inside the graph
+    assert out["model_outputs"].shape == want["model_outputs"].shape and bool(torch.isfinite(out["model_outputs"]).all())
+    # ragged batch (Synthesizer.tts_batch path)
+    B, xl = 3, [29, 17, 8]
+    x = torch.randint(0, 100, (B, T), generator=g).to(gpu)
+    dur = (1 + torch.randint(0, 3, (B, T), generator=g)).float()
+    for b in range(B):
+        dur[b, xl[b]:] = 0
+    t_dec = int(dur.sum(1).max())
+    aux = {"x_lengths": torch.tensor(xl, device=gpu), "durations": dur.to(gpu), "ragged_exact": True,
+           "noise_z": torch.randn(B, 192, t_dec, generator=g).to(gpu)}
+    want = m.inference(x, dict(aux, no_graph=True))
+    for _ in range(3):
+        got = m.inference(x, aux)
+        lens = got["y_lengths"].tolist()
+        assert lens == want["y_lengths"].tolist()
+        for b in range(B):
+            assert torch.equal(got["model_outputs"][b, :, : lens[b] * 256], want["model_outputs"][b, :, : lens[b] * 256]), b

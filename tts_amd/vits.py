@@ -95,6 +95,14 @@ class Vits:
         # shape; set `use_graphs = False` for eager launches
         self.use_graphs = True
         self._front = graphs.GraphCache(self._front_eager)
+        # Small requests (the reference's own call pattern is ONE sentence at a time, synthesizer.py:384) are launch-bound
+        # end to end: everything after the one host sync (prior expansion, flows, waveform decoder: ~110 launches on three
+        # streams) replays as a second hipGraph.  The decoder length is padded to a multiple of 32 frames so that requests
+        # share captures, and runs ragged-exact (every conv treats the row as ending at its own length), which reproduces
+        # the unpadded run bit for bit.
+        self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
+        self._tail_cfg = None
+        self.graph_tail_max_frames = 2048      # B * padded frames up to which the tail is captured
 
     # ---- plug-in surface ---------------------------------------------------------------------------
     @staticmethod
@@ -140,8 +148,9 @@ class Vits:
         if self.device.type != "cuda":
             raise _lib.TtsAmdError("tts_amd.Vits runs only on a GPU (no CPU fallback)")
         a, sd, dev = self.args, self._sd, self.device
-        # captured front-end graphs hold raw pointers to the weight tensors replaced below: drop them first
+        # captured graphs hold raw pointers to the weight tensors replaced below: drop them first
         self._front.clear()
+        self._tail.clear()
         self.text_encoder = layers.TextEncoder(sd, "text_encoder.", dev, a.hidden_channels, a.num_layers_text_encoder,
                                                a.num_heads_text_encoder, a.kernel_size_text_encoder)
         spk = self.embedded_speaker_dim
@@ -181,6 +190,21 @@ class Vits:
         else:
             logw = self.duration_predictor(h, x_mask, g=g, lang=lang)
         return h, stats, logw.contiguous()
+
+    def _tail_eager(self, stats, cum, x_mask, y_lengths, noise_z, g):
+        """Everything after the output extent is known (vits.py:1152-1161) at the padded length `self._tail_cfg[0]`:
+        prior expansion (+ the randn draw when no noise is passed), alignment path, flows, waveform decoder (ragged-exact).
+        noise_z / g: tensors or empty tensors."""
+        t_pad, noise_scale = self._tail_cfg
+        B, H = stats.shape[0], self.args.hidden_channels
+        if noise_z.numel() == 0:
+            noise_z = torch.randn(B, H, t_pad, device=stats.device, dtype=torch.float32)
+        g = g if g.numel() else None
+        pri = ops.expand_prior(stats[:, :H], stats[:, H:], noise_z, cum, x_mask, y_lengths, t_pad, noise_scale, second_copy=True)
+        attn = ops.generate_path(cum, x_mask, y_lengths, t_pad)
+        z = self.flow(pri["z_p2"], pri["y_mask"], g=g)
+        o = self.waveform_decoder.forward(z, g=g, in_mask=pri["y_mask"], lengths=y_lengths)
+        return o, attn, z, pri["z_p"], pri["m_p"], pri["logs_p"], pri["y_mask"]
 
     def _speaker_g(self, aux_input, B, dev):
         """_set_cond_input / _set_speaker_input (vits.py:873-905,1112-1117): g [B, C_spk, 1] or None."""
@@ -286,6 +310,38 @@ class Vits:
             w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d)
         t_dec = int(y_lengths.max().item())                                       # one D2H sync: output extent
         noise_z = aux_input.get("noise_z") if aux_input else None
+        ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
+        no_graph = bool((aux_input or {}).get("no_graph", False))
+        t_pad = -(-t_dec // 32) * 32
+        if (self.use_graphs and not no_graph and (B == 1 or ragged) and self.interpolate_factor is None
+                and self.max_inference_len is None and B * t_pad <= self.graph_tail_max_frames):
+            if noise_z is not None:                       # a pinned draw: zero-extended to the padded length (masked there)
+                nz = torch.zeros(B, H, t_pad, device=dev, dtype=torch.float32)
+                nz[:, :, :t_dec] = noise_z.to(dev, torch.float32)
+            else:
+                nz = torch.empty(0, device=dev)
+            self._tail.enabled = True
+            self._tail_cfg = (t_pad, float(self.inference_noise_scale))
+            o, attn, z, z_p, m_p, logs_p, y_mask = self._tail(
+                stats.contiguous(), cum, x_mask, y_lengths, nz, g if g is not None else torch.empty(0, device=dev),
+                key=self._tail_cfg)
+            hop = o.shape[-1] // t_pad
+            # the graph's outputs are static buffers (overwritten by its next replay): hand out copies, cut to the true extent
+            outputs = {
+                "model_outputs": o[:, :, : t_dec * hop].clone(),
+                "alignments": attn[:, :, :t_dec].clone(),
+                "durations": w_ceil.unsqueeze(1).clone(),
+                "z": z[:, :, :t_dec].clone(),
+                "z_p": z_p[:, :, :t_dec].clone(),
+                "m_p": m_p[:, :, :t_dec].clone(),
+                "logs_p": logs_p[:, :, :t_dec].clone(),
+                "y_mask": y_mask[:, :t_dec].unsqueeze(1).clone(),
+            }
+            if ragged:
+                outputs["y_lengths"] = y_lengths.clone()
+            if aux_input and aux_input.get("return_extras"):
+                outputs.update(x=h.clone(), logw=None if logw is None else logw.clone().unsqueeze(1), y_lengths=y_lengths.clone())
+            return outputs
         if noise_z is None:
             noise_z = torch.randn(B, H, t_dec, device=dev, dtype=torch.float32)
         noise_z = noise_z.to(dev, torch.float32).contiguous()
@@ -306,7 +362,6 @@ class Vits:
         zd = z if self.max_inference_len is None else z[:, :, : self.max_inference_len].contiguous()
         md = y_mask if self.max_inference_len is None else y_mask[:, : self.max_inference_len].contiguous()
         # "ragged_exact": every decoder conv treats row b as ending at y_lengths[b] -> row b equals a B=1 run
-        ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
         o = self.waveform_decoder.forward(zd, g=g, in_mask=md, lengths=dec_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
         outputs = {
             "model_outputs": o,
