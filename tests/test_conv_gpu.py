@@ -258,3 +258,24 @@ def test_split_bf16_tiny_activations_flush_bound(gpu, conv_precision):
     xm[:, ::3] = x[:, ::3]                                       # a third of the channels tiny, the rest ordinary
     ops.conv1d(ops.PackedConv(w, None, gpu), xm.to(gpu), y)
     assert _rel(y, _conv64(xm, w, None, K, 1)) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 32, 5001, True, True), (3, 8, 250, False, True), (1, 32, 3, True, False), (2, 64, 247, True, True),
+                                  (1, 16, 249, False, False), (2, 32, 1, True, True), (1, 32, 100000, False, True)])
+def test_single_output_channel_streaming_conv(gpu, case, conv_precision):
+    """C -> 1, k = 7 (HiFiGAN conv_post) takes the streaming kernel (conv_post.hip: 16-byte row loads, neighbour columns by
+    DPP shifts, exact fp32 FMA chain): leaky-ReLU(0.01) in, tanh out, optional length mask and bias; lengths around the
+    248-column wave tile, shorter than one lane's 4 columns, and rows whose 16-byte loads are not 16-byte aligned."""
+    B, C, T, has_mask, has_bias = case
+    g = torch.Generator().manual_seed(sum(case[:3]))
+    x = torch.randn(B, C, T, generator=g)
+    w = torch.randn(1, C, 7, generator=g) / np.sqrt(C * 7)
+    b = torch.randn(1, generator=g) if has_bias else None
+    lens = torch.tensor([max(1, T - 61 * i) for i in range(B)])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float() if has_mask else None
+    xin = x * mask[:, None] if has_mask else x
+    want = torch.tanh(F.conv1d(F.leaky_relu(xin, 0.01), w, b, padding=3))
+    y = torch.full((B, 1, T), float("nan"), device=gpu)
+    ops.conv1d(ops.PackedConv(w, b, gpu), x.to(gpu), y, in_act=ops.ACT_LRELU, in_slope=0.01, out_act=ops.ACT_TANH,
+               in_mask=None if mask is None else mask.to(gpu))
+    assert float((y.cpu() - want).abs().max()) < 2e-6

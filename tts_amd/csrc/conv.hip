@@ -140,6 +140,7 @@ extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
         return TTSAMD_ERR_UNSUPPORTED;
     }
     hipStream_t st = as_stream(stream);
+    if (conv_post_eligible(a)) return conv_post_launch(a, st);   // C -> 1 (HiFiGAN conv_post): pure HBM streaming
     switch (a.kernel) {
         case 1: return conv1d_launch_k1(a, st);
         case 2: return conv1d_launch_k2(a, st);

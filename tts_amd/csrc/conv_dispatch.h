@@ -48,6 +48,10 @@ int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
     return conv1d_mode_unsupported(a);
 }
 
+// single-output-channel streaming kernel (conv_post.hip)
+bool conv_post_eligible(const ttsamd_conv1d_args &a);
+int conv_post_launch(const ttsamd_conv1d_args &a, hipStream_t st);
+
 // one translation unit per kernel size (conv_k*.hip) so hipcc compiles them in parallel
 int conv1d_launch_k1(const ttsamd_conv1d_args &a, hipStream_t st);
 int conv1d_launch_k2(const ttsamd_conv1d_args &a, hipStream_t st);
