@@ -152,10 +152,10 @@ def base_line(args, ctx, metric, value, unit, elapsed_max, workload, dtype, high
             "config": dict({"workload": workload, "parallelism": "replicas x%d" % ctx.world}, **cfg)}
 
 
-def load_pmc(name):
-    """HBM bytes per launch from the committed PMC passes (profiles/<name>, scripts/gpu_pmc_round.sh), or None."""
+def load_pmc(name, key="hbm_bytes_per_launch"):
+    """A figure from the committed PMC passes (profiles/<name>, written by scripts/gpu_round2.sh + pmc_round.py), or None."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get(key)
     except Exception:
         return None
 
@@ -209,10 +209,18 @@ def cpu_baseline_vits(sd, n_chars, seconds_budget=20.0):
             t_used += time.time() - t0
             samples += out["model_outputs"].shape[-1]
             n += 1
+        # batched mode (x_lengths batches): one pass over 4 utterances
+        xb, xlb, durb = synthetic_batch(4, n_chars, 1, "cpu")
+        t0 = time.time()
+        O.vits_inference(sd, xb, xlb, {}, noise_dp=torch.randn(4, 2, xb.shape[1]), stop_after="prior")
+        ob = O.vits_inference(sd, xb, xlb, {}, durations=durb.view(4, 1, -1))
+        tb = time.time() - t0
     return {"value": samples / t_used, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "%d x 1 utterance of %d chars (%d samples each), B=1 sentence loop as the reference does; "
-                      "torch fp32 CPU ops, %d threads of %d host cores; rtf_x=%.1f"
-                      % (n, n_chars, out["model_outputs"].shape[-1], threads, cores, samples / t_used / SAMPLE_RATE)}
+            "batched_b4_value": ob["model_outputs"].numel() / tb,
+            "sample": "%d x 1 utterance of %d chars (%d samples each), B=1 sentence loop as the reference does "
+                      "(`batched_b4_value`: one batch of 4 such utterances); torch fp32 CPU ops, %d threads of %d host "
+                      "cores; rtf_x=%.1f" % (n, n_chars, out["model_outputs"].shape[-1], threads, cores,
+                                             samples / t_used / SAMPLE_RATE)}
 
 
 def wl_vits_e2e(args, ctx):
@@ -311,6 +319,10 @@ def wl_vits_e2e(args, ctx):
                   + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
         "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
         "frac": ach / conv_peak(args.precision), "traffic": load_pmc("pmc_dominant_%s.json" % args.precision),
+        # from the same committed PMC passes: fraction of kernel cycles the matrix pipe is busy, and the shader clock the
+        # chip sustains under this kernel (power-limited: 2.4 GHz is the nominal clock the peak is quoted at)
+        "pmc_mfma_busy_frac": load_pmc("pmc_dominant_%s.json" % args.precision, "mfma_busy_frac"),
+        "pmc_kernel_cycles": load_pmc("pmc_dominant_%s.json" % args.precision, "kernel_cycles"),
         "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B per launch) / launch time; peak = bf16 dense "
                       "MFMA peak 2500 TF / 6 bf16 products per fp32 product; on the matrix pipe itself: %.0f of "
                       "2500 bf16 TFLOP/s" % (ach * X3_PRODUCTS)) if args.precision == "x3" else
@@ -512,7 +524,10 @@ def wl_hifigan_v1(args, ctx):
     ach = r["flops"] / elapsed_max / 1e12
     line["roofline"] = {"bound": "mfma", "kernel": "all conv launches of the generator (%s)" % conv_kernel_name(args.precision, "..."),
                         "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
-                        "frac": ach / conv_peak(args.precision), "traffic": load_pmc("pmc_hifigan_v1_%s.json" % args.precision),
+                        "frac": ach / conv_peak(args.precision),
+                        "traffic": load_pmc("pmc_hifigan_v1_%s_resblock.json" % args.precision),
+                        "traffic_note": "PMC HBM bytes per launch of the fused ResBlock kernels (41 % of the launches' time), "
+                                        "one 29-item slab; their algorithmic bytes per launch: see hbm_subset",
                         "algorithmic_gbps": r["bytes"] / elapsed_max / 1e9, "launches_timed": r["launches"],
                         "measured": "algorithmic conv FLOP of the timed steps / wall time of the timed region",
                         "hbm_subset": {"note": "launches bound by HBM, not the matrix pipe (SURVEY App. A): algorithmic bytes "

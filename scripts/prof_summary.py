@@ -8,6 +8,7 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"void ttsamd::conv1d_(mfma|x3)_kernel<(.*?)>.*", r"conv1d_\1_kernel<\2>", name)
+    name = re.sub(r"void ttsamd::resblock_pair_x3_kernel<(.*?)>.*", r"resblock_pair_x3_kernel<\1>", name)
     name = re.sub(r"^void ", "", name)
     return re.sub(r"\(.*", "", name)[:70]
 

@@ -5,7 +5,8 @@ steps = float(sys.argv[2])
 agg = collections.OrderedDict()
 for r in rows:
     nm = re.sub(r"void ttsamd::conv1d_(mfma|x3)_kernel<(.*?)>.*", r"conv_\1<\2>", r['Kernel_Name'])
-    nm = re.sub(r"\(.*", "", nm)[:42]
+    nm = re.sub(r"void ttsamd::resblock_pair_x3_kernel<(.*?)>.*", r"resblock_x3<\1>", nm)
+    nm = re.sub(r"^void ", "", re.sub(r"\(.*", "", nm)).replace("ttsamd::", "")[:42]
     key = (nm, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), int(r['Grid_Size_Y']), int(r['Grid_Size_Z']))
     a = agg.setdefault(key, [0, 0.0])
     a[0] += 1; a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3

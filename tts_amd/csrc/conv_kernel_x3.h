@@ -268,7 +268,10 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
         // 6 + 6 — LDS has 4x the L1 bandwidth (scripts/ubench/x3_tiles.hip: 0.54 -> 0.56 of peak at the throttled clock,
         // 0.70 -> 0.79 on zero operands)
         // measured end to end (bench.py, two runs each): <2,2,2,2> 91.1 ms/step, <1,4,4,1> 87.3; 256-row blocks
-        // (<2,4,4,1>) for the 2-tap polyphase ConvTranspose launches: +-0
+        // (<2,4,4,1>) for the 2-tap polyphase ConvTranspose launches: +-0.  Round 2, same method: 64x128 wave tiles
+        // (<2,4,2,1>, half the L1 bytes per MFMA, 20 spilled VGPRs) 79.5 -> 81.7 ms/step; 256-row blocks of 8 waves (<1,4,8,1>,
+        // the 256-channel layers stage their tile once instead of twice) 77.5 -> 77.9; the conflict-free planar LDS image
+        // (TTSAMD_X3_PLANAR) +-0 on the 128/256-row layers (SQ_LDS_BANK_CONFLICT 0, but LDS was not the limiter).
         if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
     }
     if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
