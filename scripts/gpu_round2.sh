@@ -14,7 +14,7 @@ BENCH="$R/bench.py --serial-branches --lanes 1 --steps 2 --warmup 1 --no-cpu-bas
 PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --serial-branches --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/prof.log 2>&1; echo "prof rc=$?"
 S=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); T=$(find $OUT/prof -name '*kernel_trace.csv' | head -1)
 python $R/scripts/prof_summary.py stats $S > $OUT/kernel_stats.txt; head -14 $OUT/kernel_stats.txt
-python $R/scripts/trace_shapes.py $T 8 70 > $OUT/per_shape.txt; head -5 $OUT/per_shape.txt
+python $R/scripts/trace_shapes.py $T 10 70 > $OUT/per_shape.txt; head -5 $OUT/per_shape.txt
 rm -rf $OUT/prof
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
@@ -23,8 +23,8 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_W
   cp $(find $OUT/pmc$i -name '*counter_collection.csv' | head -1) $OUT/pmc$i.csv 2>/dev/null; rm -rf $OUT/pmc$i
 done
 python $R/scripts/pmc_round.py $OUT/pmc_dominant_x3.json "conv1d_x3_kernel<11,1,1,4,4,1,0>" $OUT/pmc1.csv $OUT/pmc2.csv $OUT/pmc3.csv > $OUT/pmc_table.txt; cat $OUT/pmc_table.txt
-# configs[2]: one 29-item slab (the slab size of the 256-item run)
-V1="$R/bench.py --workload hifigan_v1 --items 29 --steps 1 --warmup 1 --no-cpu-baseline"
+# configs[2]: 16-item launches (the size of the hbm_subset pass; every launch of this run has that size)
+V1="$R/bench.py --workload hifigan_v1 --items 16 --steps 1 --warmup 1 --no-cpu-baseline"
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
   PYTHONPATH=$R timeout 600 rocprofv3 --pmc $P --output-format csv -d $OUT/v1$P -o p -- python $V1 > $OUT/v1$P.log 2>&1; echo "v1 $P rc=$?"
   cp $(find $OUT/v1$P -name '*counter_collection.csv' | head -1) $OUT/v1_$P.csv 2>/dev/null; rm -rf $OUT/v1$P
