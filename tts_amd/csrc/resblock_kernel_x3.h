@@ -176,6 +176,22 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
 #pragma unroll
         for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp1[mi][q * 64];
 
+    // conv2's accumulators start from the residual x — the tile's own columns, requested NOW: the lines were fetched for
+    // the staging pass microseconds ago (L2 hits; requested after conv1 they had been evicted: PMC fetch 2.1x the tensor)
+    // and their latency hides behind conv1's main loop
+    f32x16 acc2[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row0 = (wm * MI + mi) * 32;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int o = (wn * NI + ni) * 32 + j;
+            const int t = t0 + o;
+            const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+        }
+    }
     // operands of the mid epilogue, requested here so that their latency hides behind conv1's main loop
     float mk[NI];
 #pragma unroll
@@ -237,26 +253,14 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
             }
     }
 
-    // ---- conv2: accumulators start from the residual x (the tile's own columns: L2 hits) -------------------------------
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row0 = (wm * MI + mi) * 32;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int o = (wn * NI + ni) * 32 + j;
-            const int t = t0 + o;
-            const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-        }
-    }
+    // ---- conv2 (its accumulators hold the residual x, requested before conv1) ---------------------------------------------
     float bia2[MI][16];      // output bias: requested ahead of conv2's main loop
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bia2[mi][r] = a.bias2 ? a.bias2[(wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
     __syncthreads();                                                   // the mid tile is complete
-    res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc, wp2, a_cur, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
+    res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc2, wp2, a_cur, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
 
     // ---- output epilogue: + bias2 (+ accum) (/ div) -------------------------------------------------------------------
     {
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[mi][ni][r] + bia2[mi][r];
+                    float v = acc2[mi][ni][r] + bia2[mi][r];
                     v += 0.f;                    // (the unfused epilogue's absent-operand add: keeps -0.0 handling identical)
                     v = e2[r] + v;
                     if (out_div != 0.f) v = v / out_div;
@@ -312,7 +316,8 @@ int resblock_pair_launch_cfg(const ttsamd_resblock_args &a, hipStream_t st)
 // Tile per channel count (a.variant selects alternatives for A/B measurements; 0 = default):
 //   C = 32 : 4 waves as 1x4, NI = 2 -> 256 mid columns, 59 KB LDS at K=11 D=5 (2 blocks / CU)
 //   C = 64 : 4 waves as 2x2, NI = 2 -> 128 mid columns, 68 KB (2 blocks / CU);  variant 1: 8 waves 2x4, 256 columns, 117 KB
-//            (measured at the benchmark shape, us per pair, 4-wave / 8-wave: k=3 988 / 1088, k=7 1784 / 1835, k=11 2691 / 2721)
+//            (measured at the benchmark shape, us per pair, 4-wave / 8-wave: k=3 988 / 1088, k=7 1760 / 1773, k=11 2686 / 2605:
+//            k = 11 takes the 8-wave tile by default, variant 1 flips the choice)
 //   C = 128: 8 waves as 4x2, NI = 2 -> 128 mid columns, 137 KB (1 block / CU)
 template <int K, int D>
 int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
@@ -320,7 +325,8 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
     switch (a.c) {
         case 32: return resblock_pair_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:
-            if (a.variant == 1) return resblock_pair_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
+            // k = 11: the 8-wave / 256-column tile (4 % halo work instead of 8 %) wins by 3 %; k = 3, 7: the 4-wave tile
+            if ((a.variant == 1) != (K == 11)) return resblock_pair_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
             return resblock_pair_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
         case 128: return resblock_pair_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
     }
