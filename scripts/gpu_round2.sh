@@ -9,12 +9,13 @@ timeout 1200 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "be
 for B in 32 256; do timeout 300 python bench.py --workload mas --mas-batch $B --steps 20 > $OUT/bench_mas_b$B.json 2>/dev/null; cut -c1-300 $OUT/bench_mas_b$B.json; done
 timeout 300 python bench.py --workload xtts_stream --steps 5 > $OUT/bench_xtts_stream.json 2>/dev/null; cut -c1-300 $OUT/bench_xtts_stream.json
 timeout 300 python scripts/b1_latency.py 1 2>&1 | grep -v amdgpu.ids > $OUT/b1_latency.txt; cat $OUT/b1_latency.txt
+timeout 600 python scripts/resblock_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/resblock_ab.txt; tail -5 $OUT/resblock_ab.txt
 cd /tmp && export TMPDIR=/tmp
 BENCH="$R/bench.py --serial-branches --lanes 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
-PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --serial-branches --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/prof.log 2>&1; echo "prof rc=$?"
+PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/bench.py --serial-branches --lanes 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras > $OUT/prof.log 2>&1; echo "prof rc=$?"
 S=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); T=$(find $OUT/prof -name '*kernel_trace.csv' | head -1)
 python $R/scripts/prof_summary.py stats $S > $OUT/kernel_stats.txt; head -14 $OUT/kernel_stats.txt
-python $R/scripts/trace_shapes.py $T 10 70 > $OUT/per_shape.txt; head -5 $OUT/per_shape.txt
+python $R/scripts/trace_shapes.py $T 16 70 > $OUT/per_shape.txt; head -5 $OUT/per_shape.txt
 rm -rf $OUT/prof
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
