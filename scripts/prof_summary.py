@@ -17,6 +17,9 @@ def stats(path, top=45):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print("# rocprofv3 --kernel-trace --stats : %d kernels, %.3f ms total GPU time" % (len(rows), tot / 1e6))
+    print("# NOTE avg_us is the MEAN over every launch of the process, including each kernel's first launches (code-object upload:"
+          " one launch of tens of ms for the 137 KB-LDS fused kernel, 2x slower launches during the first two steps); the "
+          "steady-state per-launch figure is the MEDIAN in the per-shape table next to this file (trace_shapes.py)")
     print("%-72s %6s %11s %11s %11s %7s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "pct"))
     for r in rows[:top]:
         print("%-72s %6s %11.3f %11.1f %11.1f %7.2f" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
