@@ -1,5 +1,7 @@
 """GPU parity: HIP HiFiGAN generator vs the CPU oracle (oracle/tts_oracle.py, pinned to the
 reference modules).  Tolerance: 1e-4 absolute RMS (north_star) AND 1e-5 relative RMS (internal bar)."""
+import os
+
 import pytest
 import torch
 
@@ -24,7 +26,7 @@ def _make(cfg, in_ch, gpu, sd, **kw):
     return m.to(gpu)
 
 
-@pytest.mark.parametrize("variant", ["v1_c64", "v2", "rb2", "v1_full"])
+@pytest.mark.parametrize("variant", ["v1_c64", "v2", "rb2", "v1_full", "v1_full_long"])
 def test_hifigan_inference_matches_oracle(gpu, variant):
     torch.set_num_threads(8)
     cfg = dict(W.HIFIGAN_V1)
@@ -35,6 +37,9 @@ def test_hifigan_inference_matches_oracle(gpu, variant):
         cfg = dict(W.HIFIGAN_V2)
     elif variant == "rb2":
         cfg.update(upsample_initial_channel=64, resblock_type="2", resblock_dilation_sizes=[[1, 3]] * 3)
+    elif variant == "v1_full_long":       # full-width v1 (512 channels), several time tiles at every stage, two items
+        T, B = 150, 2
+        torch.set_num_threads(min(64, os.cpu_count() or 8))
     else:
         T, B = 24, 1
     sd = O.make_hifigan_state(cfg, 80, seed=5)

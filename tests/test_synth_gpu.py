@@ -174,3 +174,16 @@ def test_vits_multispeaker_multilingual_request(gpu, tmp_path, speakers):
         syn.tts(text, speaker_name="bob")
     with pytest.raises(ValueError, match="not in the available languages"):
         syn.tts(text, speaker_name="bob", language_name="xx")
+    # TTS.api surface (api.py:84-117,215-288): multi-speaker / multi-lingual flags and name lists come from the loaded model's
+    # managers, speaker= / language= reach the Synthesizer, and the reference's argument errors are raised
+    margs2 = dict(vargs, language_ids_file=lang_file, **({"d_vector_file": spk_file} if dv else {"speakers_file": spk_file}))
+    ck2, cf2 = _write(tmp_path, "vits_ms_api", sd, dict(cfg, model_args=margs2))
+    api = TTS(model_path=ck2, config_path=cf2, gpu=True)
+    assert api.is_multi_speaker and api.is_multi_lingual
+    assert api.speakers == ["alice", "bob", "carol"] and api.languages == ["en", "fr-fr", "pt-br"]
+    via_api = np.asarray(api.tts(text, speaker="bob", language="fr-fr"), dtype=np.float32)
+    assert via_api.shape == flat.shape and float(np.abs(via_api - flat).max()) < 1e-6
+    with pytest.raises(ValueError, match="multi-speaker but no `speaker`"):
+        api.tts(text, language="en")
+    with pytest.raises(ValueError, match="multi-lingual but no `language`"):
+        api.tts(text, speaker="bob")
