@@ -3,22 +3,22 @@
 // Replaces TTS/tts/utils/monotonic_align/core.pyx:11-47 (maximum_path_each / maximum_path_c) and
 // the host glue of TTS/tts/utils/helpers.py:178-194 (value*mask, lengths from the mask, D2H/H2D).
 //
-// Design (one workgroup of 8 wavefronts per batch item; integer/fp32 add-compare work, HBM/latency
-// bound — deliberately NOT reshaped into a GEMM):
-//   * forward DP  — wave 0 sweeps the columns y=0..t_y-1.  Lane l owns rows x = r*64 + l
-//     (r < R = ceil(t_x/64)); the previous column lives in registers and the x-1 neighbour
-//     comes from a wavefront shuffle (`__shfl_up`; lane 0 takes lane 63 of the previous row
-//     group).  Waves 1..7 stream [T_x x 32]-column tiles HBM -> LDS with coalesced 128-byte
-//     row segments, transposing into a [y][x] LDS image (row pitch 64R+1 => conflict-free both
-//     ways), double-buffered against the DP wave, and stream finished tiles back.
-//     Each cell is ONE fp32 add on the same operands as the reference, so values and therefore
-//     the path are bit-exact for any traversal order.
-//   * the backtrack needs only `value[x,y-1] < value[x-1,y-1]`; the DP wave gets that predicate
-//     for free (it already holds both operands) and stores it as ballot bit-planes
-//     dirs[b][y][r] (8 bytes per 64 rows) instead of re-reading 4-byte values.
-//   * backtrack — per 64-column chunk every lane extracts a 64-row window of its column's
-//     bit-plane around the current index, then wave 0 walks the chunk with scalar readlane ops;
-//     all waves then write complete 256-byte path row segments (zeros included).
+// Design (one workgroup per batch item; integer/fp32 add-compare work, dependency-latency bound — deliberately NOT
+// reshaped into a GEMM):
+//   * forward DP (T_x <= 512: mas_forward_mw_kernel) — lane l of DP wave r owns row x = 64 r + l; the R = ceil(T_x/64) row
+//     groups sweep the columns as a skewed pipeline of R waves.  The previous column lives in one register per lane, the
+//     x-1 neighbour comes from a DPP wave shift inside a group and from an 8-byte {value, column} LDS ring slot between
+//     groups.  The other waves of the block stream [T_x x 32]-column tiles HBM -> LDS with coalesced 128-byte row segments,
+//     transposing into a [y][x] LDS image (row pitch 64R+1 => conflict-free both ways), double-buffered against the DP
+//     waves, and stream finished tiles back.  Each cell is ONE fp32 add on the same operands as the reference, so values
+//     and therefore the path are bit-exact for any traversal order.  (T_x > 512: mas_forward_kernel, one DP wave holding
+//     all row groups in registers.)
+//   * the backtrack needs only `value[x,y-1] < value[x-1,y-1]`; the DP waves get that predicate for free (they already
+//     hold both operands) and store it as ballot bit-planes dirs[b][y][r] (8 bytes per 64 rows) instead of re-reading
+//     4-byte values.
+//   * backtrack — per 64-column chunk every lane extracts a 64-row window of its column's bit-plane around the current
+//     index, then wave 0 walks the chunk with scalar readlane ops while the other waves write the previous chunk's
+//     256-byte path row segments (zeros included).
 #include "common.h"
 
 #include <cstdlib>

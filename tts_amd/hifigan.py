@@ -4,9 +4,12 @@
 
 Same constructor arguments, same `forward(x, g=None)`, `inference(c)` (replicate pad, no crop),
 `load_checkpoint(config, path, eval)` and state_dict key layout (weight-norm parametrised or
-stripped).  78 fused conv launches per call: leaky-ReLU lives in each conv's prologue, bias /
+stripped).  Every launch is a fused conv: leaky-ReLU lives in each conv's prologue, bias /
 residual add / MRF accumulate-and-average / tanh in its epilogue; ConvTranspose1d runs as a
-polyphase 2-tap conv with a pixel-shuffle epilogue.  No elementwise passes over HBM remain.
+polyphase 2-tap conv with a pixel-shuffle epilogue; a whole ResBlock1 iteration
+(lrelu -> conv(k,d) -> lrelu -> conv(k,1) -> +x) is ONE launch on the 32/64-channel stages (and the
+128-channel stage's k=3 blocks) with its intermediate tensor kept in LDS; conv_post is an HBM-streaming
+kernel.  v1: 78 conv launches unfused, 54 with fusion.  No elementwise passes over HBM remain.
 """
 import os
 
