@@ -139,6 +139,9 @@ typedef struct ttsamd_conv1d_args {
                             * fp32 rounding of it); NULL = fp32-input MFMA kernels reading w_packed. */
 } ttsamd_conv1d_args;
 
+/* Dispatch notes: c_out == 1, kernel 7, dilation 1, NORMAL mode without residual / accumulate / masks on the output
+ * (HiFiGAN conv_post, hifigan_generator.py:262-264) runs as an HBM-streaming kernel in exact fp32 whatever w_split is;
+ * everything else runs on the matrix pipe as described above. */
 int ttsamd_conv1d(const ttsamd_conv1d_args *args /* host */, void *stream);
 
 /* Number of floats of the packed image of a [c_out, c_in, kernel] weight. */
