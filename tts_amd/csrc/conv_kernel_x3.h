@@ -33,6 +33,9 @@
 #ifndef TTSAMD_X3_CFG64
 #define TTSAMD_X3_CFG64 1, 4, 2, 2
 #endif
+namespace ttsamd {
+constexpr long kConvSmallGridBlocks = 96;   // below this many 128x128-class blocks a launch takes the small-grid tiles
+}
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
 #endif
@@ -261,6 +264,25 @@ template <int K, int D, int MODE>
 int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     const int mtiles = (a.c_out + 31) / 32;
+    // Small grids (a B = 1 request: text encoder / duration predictor / flow layers at T = 257..770 launch 6-40 of the
+    // default blocks on a 256-CU chip, and every block walks its serial K loop alone on its CU): 64-column tiles with ONE
+    // 32x32 tile per wave — a quarter of the MFMA and staging work per k-step and 2-4x the blocks.  Same products in the same
+    // order per output, so results do not change.  Only instantiated where those layers live (dilation 1, kernel <= 7).
+    if constexpr (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_NORMAL || MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP ||
+                                       MODE == TTSAMD_CONV_COUPLE)) {
+        constexpr bool paired = (MODE == TTSAMD_CONV_GATE);
+        const long tiles_n = (a.t_out + 127) / 128;
+        const long blocks_default = tiles_n * ((mtiles + 3) / 4) * a.batch;      // 128x128-class blocks
+        if (blocks_default <= kConvSmallGridBlocks && a.t_out <= 4096) {
+            if constexpr (paired) {
+                if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, 2, 1, 2, 2, MODE>(a, st);      // 128 rows x 64 columns
+                return conv1d_x3_launch_cfg<K, D, 2, 1, 1, 2, MODE>(a, st);                            // 64 rows x 64 columns
+            } else {
+                if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE>(a, st);      // 64 rows x 64 columns
+                return conv1d_x3_launch_cfg<K, D, 1, 1, 1, 2, MODE>(a, st);                            // 32 rows x 64 columns
+            }
+        }
+    }
     if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
         if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
     } else {
