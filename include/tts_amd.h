@@ -156,6 +156,11 @@ size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kernel);
 int ttsamd_conv1d_pack_weights_split(void *dst, const float *w, int c_out, int c_in, int kernel);
 /* 1 if (kernel, dilation) has a tuned instantiation. */
 int ttsamd_conv1d_supported(int kernel, int dilation);
+/* Launches that would put fewer than ~100 blocks on the chip (single-sentence requests): 0 = the large-grid tiles
+ * everywhere, 1 = 64-column tiles with one 32x32 tile per wave (same summation order: bitwise the large-grid result),
+ * 2 (default) = those tiles plus, for c_in >= 128, wave groups that split the block's K loop and are reduced in a fixed
+ * order (deterministic; fp32 reassociation relative to modes 0 / 1).  Returns the previous mode. */
+int ttsamd_conv1d_set_small_grid(int mode);
 
 /* One ResBlock1 iteration of the HiFiGAN MRF as a single launch — replaces the body of the loop in
  * TTS/vocoder/models/hifigan_generator.py:90-98 (ResBlock1.forward):

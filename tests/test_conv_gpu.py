@@ -279,3 +279,42 @@ def test_single_output_channel_streaming_conv(gpu, case, conv_precision):
     ops.conv1d(ops.PackedConv(w, b, gpu), x.to(gpu), y, in_act=ops.ACT_LRELU, in_slope=0.01, out_act=ops.ACT_TANH,
                in_mask=None if mask is None else mask.to(gpu))
     assert float((y.cpu() - want).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(1, 768, 192, 3, 257, 0), (1, 192, 768, 3, 257, 0), (1, 192, 384, 5, 770, 1), (2, 192, 192, 1, 159, 0),
+                                  (1, 200, 100, 7, 300, 0), (1, 144, 64, 3, 65, 0), (3, 256, 256, 3, 40, 0)])
+def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
+    """Launches that underfill the chip (single-sentence shapes): mode 1 (64-column tiles, one 32x32 tile per wave) is
+    bitwise the large-grid result; mode 2 adds wave groups that split the K loop (chunk counts that do not divide by the
+    group count included) and stays within the conv tolerance of torch and of mode 0."""
+    B, Cin, Cout, K, T, gate = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / np.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, T, generator=g)
+    pre = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=(K - 1) // 2)
+    if gate:
+        H = Cout // 2
+        want = torch.tanh(pre[:, :H]) * torch.sigmoid(pre[:, H:])
+        wp, bp = ops.gate_permute(w, b, H)
+        pc = ops.PackedConv(wp, bp, gpu)
+    else:
+        want = pre + res
+        pc = ops.PackedConv(w, b, gpu)
+    outs = {}
+    for mode in (0, 1, 2):
+        was = ops.set_conv_small_grid(mode)
+        try:
+            y = torch.full(want.shape, float("nan"), device=gpu)
+            if gate:
+                ops.conv1d(pc, x.to(gpu), y, in_act=ops.ACT_LRELU, in_slope=0.1, mode=ops.CONV_GATE)
+            else:
+                ops.conv1d(pc, x.to(gpu), y, in_act=ops.ACT_LRELU, in_slope=0.1, res=res.to(gpu))
+        finally:
+            ops.set_conv_small_grid(was)
+        assert _rel(y, want) < TOL, mode
+        outs[mode] = y
+    if conv_precision == "x3":
+        assert torch.equal(outs[0], outs[1])
+        assert _rel(outs[2], outs[0]) < 2e-6

@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 SLOPE = 0.1
 
 
+@pytest.fixture(autouse=True)
+def same_summation_order():
+    """The bitwise comparisons below need the two-launch baseline to sum in the fused kernel's order: small test tensors
+    would otherwise take the K-split small-grid kernels (a different, equally valid, fp32 summation order)."""
+    was = ops.set_conv_small_grid(1)
+    yield
+    ops.set_conv_small_grid(was)
+
+
 def _pair(C, K, D, seed, gpu):
     g = torch.Generator().manual_seed(seed)
     w1 = torch.randn(C, C, K, generator=g) / np.sqrt(C * K)

@@ -5,6 +5,17 @@
 
 using namespace ttsamd;
 
+namespace ttsamd {
+int g_conv_small_grid = 2;
+}
+
+extern "C" int ttsamd_conv1d_set_small_grid(int mode)
+{
+    const int was = g_conv_small_grid;
+    g_conv_small_grid = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    return was;
+}
+
 extern "C" int ttsamd_conv1d_supported(int kernel, int dilation)
 {
     switch (kernel) {

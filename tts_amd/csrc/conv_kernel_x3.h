@@ -35,6 +35,7 @@
 #endif
 namespace ttsamd {
 constexpr long kConvSmallGridBlocks = 96;   // below this many 128x128-class blocks a launch takes the small-grid tiles
+extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = small tiles + K-split groups (default)
 }
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
@@ -72,13 +73,19 @@ __device__ __forceinline__ void conv_split3(float x, unsigned &p1, unsigned &p2,
     p3 = __builtin_bit_cast(unsigned short, a3);
 }
 
-template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kOcc)) void conv1d_x3_kernel(const ttsamd_conv1d_args a)
+// KS > 1 (small-grid launches only): the block carries KS wave groups of WM x WN waves; group g reduces the channel chunks
+// g, g + KS, ... into its own accumulators through its own LDS double buffer (the serial K loop of a block — what a launch
+// of a few blocks is bound by — becomes KS times shorter), and group 0 adds the partial tiles of groups 1..KS-1 (in that
+// order: deterministic) from LDS before the epilogue.
+template <int K, int D, int MI, int NI, int WM, int WN, int MODE, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : ConvGeomX3<K, D, MI, NI, WM, WN>::kOcc)) void conv1d_x3_kernel(const ttsamd_conv1d_args a)
 {
     using G = ConvGeomX3<K, D, MI, NI, WM, WN>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char xs3[];  // [2][3 parts][XW][16 ch] bf16
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs3_all[];  // per group: [2][3 parts][2 halves][XW][8 ch] bf16
+    const int grp = (KS > 1) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::kThreads) : 0;
+    unsigned char *const xs3 = xs3_all + (size_t)grp * G::kLdsBytes;
 
-    const int tid = threadIdx.x;
+    const int tid = (int)threadIdx.x - grp * G::kThreads;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): row offsets become scalar soffsets, no waterfall loops
     const int wm = wave / WN;
@@ -174,10 +181,21 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp[mi][q * 64];
+        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp[mi][(KS > 1 && grp < nchunks ? (long)grp * K * (3 * 64) : 0) + q * 64];
 
-    stage_load(0);
-    const bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, mb, t0, wm, wn, h, j);
+    const int niter = (nchunks + KS - 1) / KS;            // chunk steps of every group (a group's last step may be empty)
+    stage_load(grp);                                       // chunks beyond c_in read as zeros (buffer range check)
+    bool folded = false;
+    if (KS == 1 || grp == 0) {
+        folded = conv_acc_init<MODE, MI, NI, WM, WN>(acc, a, b, mb, t0, wm, wn, h, j);
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
     stage_store(xs3);
     __syncthreads();
 #ifdef TTSAMD_PHASE_CLOCKS
@@ -191,42 +209,75 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
     constexpr int kColBytes = 32;
     const int bbyte = (wn * (32 * NI) + j) * 32 + h * 16;
 #endif
-    for (int c = 0; c < nchunks; ++c) {
-        const unsigned char *cur = xs3 + (c & 1) * G::kBufBytes + bbyte;
-        if (c + 1 < nchunks) stage_load(c + 1);
+    for (int it = 0; it < niter; ++it) {
+        const int c = grp + it * KS;
+        const unsigned char *cur = xs3 + (it & 1) * G::kBufBytes + bbyte;
+        if (it + 1 < niter) stage_load(c + KS);
+        if (KS == 1 || c < nchunks) {
 #pragma unroll
-        for (int tap = 0; tap < K; ++tap) {
-            // next tap's weights (the packed image ends with one group of slack)
-            const long g = ((long)c * K + tap + 1) * (3 * 64);
+            for (int tap = 0; tap < K; ++tap) {
+                // next weights: the next tap, or the first tap of this group's next chunk (the packed image ends with one
+                // group of slack; a group whose chunks are exhausted re-reads its current fragment)
+                long g = (tap + 1 < K) ? ((long)c * K + tap + 1) : ((long)(c + KS) * K);
+                if (KS > 1 && tap + 1 == K && c + KS >= nchunks) g = (long)c * K + tap;
+                g *= 3 * 64;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a_nxt[mi][q] = wp[mi][g + q * 64];
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
+                    for (int q = 0; q < 3; ++q) a_nxt[mi][q] = wp[mi][g + q * 64];
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                u32x4 bq[3];
+                for (int ni = 0; ni < NI; ++ni) {
+                    u32x4 bq[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * kColBytes);
+                    for (int q = 0; q < 3; ++q)
+                        bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * kColBytes);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    constexpr int pa[6] = {2, 1, 0, 1, 0, 0};   // smallest products first
-                    constexpr int pb[6] = {0, 1, 2, 0, 1, 0};
+                    for (int mi = 0; mi < MI; ++mi) {
+                        constexpr int pa[6] = {2, 1, 0, 1, 0, 0};   // smallest products first
+                        constexpr int pb[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[mi][pa[t]]),
-                                                                              __builtin_bit_cast(bf16x8, bq[pb[t]]),
-                                                                              acc[mi][ni], 0, 0, 0);
+                        for (int t = 0; t < 6; ++t)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[mi][pa[t]]),
+                                                                                  __builtin_bit_cast(bf16x8, bq[pb[t]]),
+                                                                                  acc[mi][ni], 0, 0, 0);
+                    }
                 }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) a_cur[mi][q] = a_nxt[mi][q];
             }
+        }
+        if (it + 1 < niter) stage_store(xs3 + ((it + 1) & 1) * G::kBufBytes);
+        __syncthreads();
+    }
+
+    if constexpr (KS > 1) {
+        // partial tiles of groups 1..KS-1 -> LDS -> group 0 (fixed order), which alone runs the epilogue
+        float *red = reinterpret_cast<float *>(xs3_all + (size_t)KS * G::kLdsBytes);
+        constexpr int kTile = MI * NI * 16 * 64;            // floats of one wave's accumulators
+        if (grp > 0) {
+            float *dst = red + ((size_t)(grp - 1) * (WM * WN) + wave) * kTile + lane;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a_cur[mi][q] = a_nxt[mi][q];
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((mi * NI + ni) * 16 + r) * 64] = acc[mi][ni][r];
         }
-        if (c + 1 < nchunks) stage_store(xs3 + ((c + 1) & 1) * G::kBufBytes);
         __syncthreads();
+        if (grp > 0) return;
+#pragma unroll 1
+        for (int g = 1; g < KS; ++g) {
+            const float *src = red + ((size_t)(g - 1) * (WM * WN) + wave) * kTile + lane;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += src[((mi * NI + ni) * 16 + r) * 64];
+        }
     }
 
 #ifdef TTSAMD_PHASE_CLOCKS
@@ -245,17 +296,18 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvGeomX3<K, D, MI, NI, WM, WN>::kO
 #endif
 }
 
-template <int K, int D, int MI, int NI, int WM, int WN, int MODE>
+template <int K, int D, int MI, int NI, int WM, int WN, int MODE, int KS = 1>
 int conv1d_x3_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     using G = ConvGeomX3<K, D, MI, NI, WM, WN>;
-    auto kern = conv1d_x3_kernel<K, D, MI, NI, WM, WN, MODE>;
+    auto kern = conv1d_x3_kernel<K, D, MI, NI, WM, WN, MODE, KS>;
+    constexpr size_t kLds = (size_t)KS * G::kLdsBytes + (size_t)(KS - 1) * (WM * WN) * MI * NI * 16 * 64 * sizeof(float);
     static std::atomic<unsigned long long> lds_attr_done{0};   // per device, see ensure_dynamic_lds
-    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)G::kLdsBytes, lds_attr_done));
+    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)kLds, lds_attr_done));
     const int mtiles = (a.c_out + 31) / 32;
     const int mblocks = (mtiles + MI * WM - 1) / (MI * WM);
     const int nblocks = (a.t_out + G::kBN - 1) / G::kBN;
-    hipLaunchKernelGGL(kern, dim3(nblocks, mblocks, a.batch), dim3(G::kThreads), G::kLdsBytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(nblocks, mblocks, a.batch), dim3(G::kThreads * KS), kLds, st, a);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
@@ -266,19 +318,29 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     const int mtiles = (a.c_out + 31) / 32;
     // Small grids (a B = 1 request: text encoder / duration predictor / flow layers at T = 257..770 launch 6-40 of the
     // default blocks on a 256-CU chip, and every block walks its serial K loop alone on its CU): 64-column tiles with ONE
-    // 32x32 tile per wave — a quarter of the MFMA and staging work per k-step and 2-4x the blocks.  Same products in the same
-    // order per output, so results do not change.  Only instantiated where those layers live (dilation 1, kernel <= 7).
+    // 32x32 tile per wave — a quarter of the MFMA and staging work per k-step and 2-4x the blocks; with >= 8 channel chunks
+    // four wave groups per block also split the K loop (fixed-order reduction through LDS: deterministic, but a different
+    // summation order than the large-grid tiles — the usual fp32 reassociation, within every parity tolerance).  Only
+    // instantiated where those layers live (dilation 1, kernel <= 7).
     if constexpr (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_NORMAL || MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP ||
                                        MODE == TTSAMD_CONV_COUPLE)) {
         constexpr bool paired = (MODE == TTSAMD_CONV_GATE);
         const long tiles_n = (a.t_out + 127) / 128;
         const long blocks_default = tiles_n * ((mtiles + 3) / 4) * a.batch;      // 128x128-class blocks
-        if (blocks_default <= kConvSmallGridBlocks && a.t_out <= 4096) {
+        if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks && a.t_out <= 4096) {
+            // >= 8 channel chunks (c_in >= 128): four wave groups split the chunks of the block's K loop between them
+            const bool ksplit = g_conv_small_grid > 1 && a.c_in >= 8 * kConvCK;
             if constexpr (paired) {
-                if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, 2, 1, 2, 2, MODE>(a, st);      // 128 rows x 64 columns
+                if (mtiles % 4 == 0) {                                                                 // 128 rows x 64 columns
+                    if (ksplit) return conv1d_x3_launch_cfg<K, D, 2, 1, 2, 2, MODE, 2>(a, st);   // 2 groups: 4 would cap the kernel at 128 VGPRs (spills)
+                    return conv1d_x3_launch_cfg<K, D, 2, 1, 2, 2, MODE>(a, st);
+                }
                 return conv1d_x3_launch_cfg<K, D, 2, 1, 1, 2, MODE>(a, st);                            // 64 rows x 64 columns
             } else {
-                if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE>(a, st);      // 64 rows x 64 columns
+                if (mtiles % 2 == 0) {                                                                 // 64 rows x 64 columns
+                    if (ksplit) return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE, 4>(a, st);
+                    return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE>(a, st);
+                }
                 return conv1d_x3_launch_cfg<K, D, 1, 1, 1, 2, MODE>(a, st);                            // 32 rows x 64 columns
             }
         }

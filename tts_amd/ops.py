@@ -87,6 +87,11 @@ def conv_precision():
     return _PRECISION
 
 
+def set_conv_small_grid(mode):
+    """0 / 1 / 2, see ttsamd_conv1d_set_small_grid (include/tts_amd.h); returns the previous mode."""
+    return int(lib().ttsamd_conv1d_set_small_grid(int(mode)))
+
+
 class PackedConv:
     """A conv layer's weights in MFMA fragment order on the device (+ bias in packed-row order): the fp32 image and
     the split-bf16 image."""

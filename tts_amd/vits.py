@@ -99,7 +99,8 @@ class Vits:
         # end to end: everything after the one host sync (prior expansion, flows, waveform decoder: ~110 launches on three
         # streams) replays as a second hipGraph.  The decoder length is padded to a multiple of 32 frames so that requests
         # share captures, and runs ragged-exact (every conv treats the row as ending at its own length), which reproduces
-        # the unpadded run bit for bit.
+        # the unpadded run bit for bit (as long as padding does not move a launch across the small-grid threshold of
+        # ttsamd_conv1d_set_small_grid, where the fp32 summation order changes).
         self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
         self._tail_cfg = None
         self.graph_tail_max_frames = 2048      # B * padded frames up to which the tail is captured
