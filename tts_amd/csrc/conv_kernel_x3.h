@@ -34,7 +34,7 @@
 #define TTSAMD_X3_CFG64 1, 4, 2, 2
 #endif
 namespace ttsamd {
-constexpr long kConvSmallGridBlocks = 96;   // below this many 128x128-class blocks a launch takes the small-grid tiles
+constexpr long kConvSmallGridBlocks = 128;  // up to this many 128x128-class blocks a launch takes the small-grid tiles
 extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = small tiles + K-split groups (default)
 }
 #ifndef TTSAMD_X3_PLANAR
@@ -321,13 +321,14 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     // 32x32 tile per wave — a quarter of the MFMA and staging work per k-step and 2-4x the blocks; with >= 8 channel chunks
     // four wave groups per block also split the K loop (fixed-order reduction through LDS: deterministic, but a different
     // summation order than the large-grid tiles — the usual fp32 reassociation, within every parity tolerance).  Only
-    // instantiated where those layers live (dilation 1, kernel <= 7).
-    if constexpr (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_NORMAL || MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP ||
-                                       MODE == TTSAMD_CONV_COUPLE)) {
+    // instantiated where such launches occur: every NORMAL-mode conv (text side, flows, and the waveform decoder's 512/256-
+    // channel stages of a single utterance) and the dilation-1 gate / res-skip / coupling convs of the flows.
+    if constexpr (MODE == TTSAMD_CONV_NORMAL ||
+                  (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE))) {
         constexpr bool paired = (MODE == TTSAMD_CONV_GATE);
         const long tiles_n = (a.t_out + 127) / 128;
         const long blocks_default = tiles_n * ((mtiles + 3) / 4) * a.batch;      // 128x128-class blocks
-        if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks && a.t_out <= 4096) {
+        if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks) {
             // >= 8 channel chunks (c_in >= 128): four wave groups split the chunks of the block's K loop between them
             const bool ksplit = g_conv_small_grid > 1 && a.c_in >= 8 * kConvCK;
             if constexpr (paired) {
