@@ -10,7 +10,8 @@ sys.path.insert(0, ".")
 from tts_amd import ops  # noqa: E402
 
 SHAPES = {32: 197120, 64: 98560, 128: 49280}
-B = 32
+import os
+B = int(os.environ.get("AB_BATCH", "32"))
 
 
 def timeit(f, n=4):

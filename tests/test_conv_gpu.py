@@ -282,11 +282,16 @@ def test_single_output_channel_streaming_conv(gpu, case, conv_precision):
 
 
 @pytest.mark.parametrize("case", [(1, 768, 192, 3, 257, 0), (1, 192, 768, 3, 257, 0), (1, 192, 384, 5, 770, 1), (2, 192, 192, 1, 159, 0),
-                                  (1, 200, 100, 7, 300, 0), (1, 144, 64, 3, 65, 0), (3, 256, 256, 3, 40, 0)])
+                                  (1, 200, 100, 7, 300, 0), (1, 144, 64, 3, 65, 0), (3, 256, 256, 3, 40, 0),
+                                  (1, 192, 576, 1, 257, 0), (1, 256, 192, 1, 257, 0), (2, 208, 64, 1, 130, 0), (1, 400, 128, 1, 70, 0),
+                                  (1, 192, 192, 5, 257, 0), (1, 130, 64, 5, 64, 0), (1, 192, 384, 3, 300, 1), (2, 256, 256, 5, 63, 1),
+                                  (1, 512, 256, 3, 770, 0), (1, 256, 256, 3, 6000, 0), (1, 192, 256, 1, 5000, 0)])
 def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
     """Launches that underfill the chip (single-sentence shapes): mode 1 (64-column tiles, one 32x32 tile per wave) is
     bitwise the large-grid result; mode 2 adds wave groups that split the K loop (chunk counts that do not divide by the
-    group count included) and stays within the conv tolerance of torch and of mode 0."""
+    group count included); modes 3 / 4 take the latency-tuned kernels (conv_kernel_x3s.h: single-iteration 1x1 convs at
+    <= 192 channels, multi-iteration ones with a partly filled last iteration, halo rounds of k = 3 / 5, paired gate rows).
+    All stay within the conv tolerance of torch and of mode 0."""
     B, Cin, Cout, K, T, gate = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, T, generator=g)
@@ -303,7 +308,7 @@ def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
         want = pre + res
         pc = ops.PackedConv(w, b, gpu)
     outs = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3, 4):
         was = ops.set_conv_small_grid(mode)
         try:
             y = torch.full(want.shape, float("nan"), device=gpu)
@@ -317,4 +322,5 @@ def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
         outs[mode] = y
     if conv_precision == "x3":
         assert torch.equal(outs[0], outs[1])
-        assert _rel(outs[2], outs[0]) < 2e-6
+        for mode in (2, 3, 4):
+            assert _rel(outs[mode], outs[0]) < 2e-6, mode

@@ -2,6 +2,7 @@
 #pragma once
 #include "conv_kernel.h"
 #include "conv_kernel_x3.h"
+#include "conv_kernel_x3s.h"
 
 namespace ttsamd {
 

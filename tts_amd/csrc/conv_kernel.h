@@ -133,20 +133,42 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
     const ttsamd_conv1d_args __attribute__((address_space(4))) *ep =
         (const ttsamd_conv1d_args __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ep) : : "memory");
+    // Every argument the epilogue can need is requested HERE, as one batch of scalar loads behind one wait (the empty asm
+    // below pins them to this point).  Left to itself the compiler sinks each load next to its first use, behind the
+    // wave-uniform branch that guards it: ten dependent s_load -> s_waitcnt -> branch hops in a row, ~2 us of a small
+    // launch's ~8 us block time (scripts/phase_clocks.py).
     float *const y = ep->y;
     const long y_bs = ep->y_bstride, y_rs = ep->y_rstride;
     const int c_out = ep->c_out, t_out = ep->t_out;
-    const float *bias = ep->bias;
-    const float *rbias = ep->row_bias ? ep->row_bias + (long)b * c_out : nullptr;
-    const float *omask = ep->out_mask ? ep->out_mask + (long)b * t_out : nullptr;
-    const float *res = ep->res ? ep->res + (long)b * ep->res_bstride : nullptr;
-    const long res_rs = ep->res_rstride;
+    const float *const bias = ep->bias;
+    const float *const rbias0 = ep->row_bias;
+    const float *const omask0 = ep->out_mask;
+    const float *const res0 = ep->res;
+    const long res_bs = ep->res_bstride, res_rs = ep->res_rstride;
+    const float *const accum0 = ep->accum;
+    const long accum_bs = ep->accum_bstride, accum_rs = ep->accum_rstride;
+    const int out_act = ep->out_act;
+    const float out_div = ep->out_div;
+    constexpr bool kUsesSplit = (MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD);
+    const int split_row = kUsesSplit ? ep->split_row : 0;
+    float *const y2_0 = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2 : nullptr;
+    const long y2_bs = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2_bstride : 0, y2_rs = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2_rstride : 0;
+    const int shuffle_u = (MODE == TTSAMD_CONV_SHUFFLE) ? ep->shuffle_u : 1;
+    const int shuffle_pad = (MODE == TTSAMD_CONV_SHUFFLE) ? ep->shuffle_pad : 0;
+    const int shuffle_t_out = (MODE == TTSAMD_CONV_SHUFFLE) ? ep->shuffle_t_out : 0;
+    asm volatile("" : : "s"(y), "s"(y_bs), "s"(y_rs), "s"(c_out), "s"(t_out), "s"(bias), "s"(rbias0), "s"(omask0), "s"(res0),
+                 "s"(res_bs), "s"(res_rs), "s"(accum0), "s"(accum_bs), "s"(accum_rs), "s"(out_act),
+                 "s"(__builtin_bit_cast(int, out_div)), "s"(split_row), "s"(y2_0), "s"(y2_bs), "s"(y2_rs), "s"(shuffle_u),
+                 "s"(shuffle_pad), "s"(shuffle_t_out));
+    const float *rbias = rbias0 ? rbias0 + (long)b * c_out : nullptr;
+    const float *omask = omask0 ? omask0 + (long)b * t_out : nullptr;
+    const float *res = res0 ? res0 + (long)b * res_bs : nullptr;
 
     if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
         static_assert(MI == 2, "paired-row epilogues need MI == 2");
         const long pair = (long)mb * WM + wm;
         constexpr bool gate = (MODE == TTSAMD_CONV_GATE);
-        const int nvalid = gate ? c_out / 2 : ep->split_row;  // output channels
+        const int nvalid = gate ? c_out / 2 : split_row;  // output channels
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int t = t0 + wn * (32 * NI) + ni * 32 + j;
@@ -176,28 +198,26 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
     } else {
         // Branch-free passes: every optional operand is fetched by a whole pass of buffer loads behind ONE
         // wave-uniform branch (never a branch + wait per element); validity lives in the offsets (kOob).
-        const int out_act = ep->out_act;
-        const float out_div = ep->out_div;
-        const int split = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->split_row : 0;
-        const int y_rs4 = (int)y_rs * 4, res_rs4 = (int)res_rs * 4, acc_rs4 = (int)ep->accum_rstride * 4;
+        const int split = (MODE == TTSAMD_CONV_RES_SKIP) ? split_row : 0;
+        const int y_rs4 = (int)y_rs * 4, res_rs4 = (int)res_rs * 4, acc_rs4 = (int)accum_rs * 4;
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(
             y + (long)b * y_bs, (MODE == TTSAMD_CONV_SHUFFLE)
-                                    ? ((long)((c_out - 1) / ep->shuffle_u) * y_rs + ep->shuffle_t_out) * 4
+                                    ? ((long)((c_out - 1) / shuffle_u) * y_rs + shuffle_t_out) * 4
                                     : ((long)((MODE == TTSAMD_CONV_RES_SKIP ? split : c_out) - 1) * y_rs + t_out) * 4);
         const __amdgpu_buffer_rsrc_t rres = make_rsrc(res, res ? ((long)(c_out - 1) * res_rs + t_out) * 4 : 0);
         const __amdgpu_buffer_rsrc_t racc = make_rsrc(
-            ep->accum ? ep->accum + (long)b * ep->accum_bstride : nullptr,
-            ep->accum ? ((long)(c_out - split - 1) * ep->accum_rstride + t_out) * 4 : 0);
+            accum0 ? accum0 + (long)b * accum_bs : nullptr,
+            accum0 ? ((long)(c_out - split - 1) * accum_rs + t_out) * 4 : 0);
         const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(
-            (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2 + (long)b * ep->y2_bstride : nullptr,
-            (MODE == TTSAMD_CONV_RES_SKIP) ? ((long)(c_out - split - 1) * ep->y2_rstride + t_out) * 4 : 0);
-        const int y2_rs4 = (MODE == TTSAMD_CONV_RES_SKIP) ? (int)ep->y2_rstride * 4 : 0;
-        const bool has_accum = ep->accum != nullptr;
+            (MODE == TTSAMD_CONV_RES_SKIP) ? y2_0 + (long)b * y2_bs : nullptr,
+            (MODE == TTSAMD_CONV_RES_SKIP) ? ((long)(c_out - split - 1) * y2_rs + t_out) * 4 : 0);
+        const int y2_rs4 = (MODE == TTSAMD_CONV_RES_SKIP) ? (int)y2_rs * 4 : 0;
+        const bool has_accum = accum0 != nullptr;
         // polyphase ConvTranspose with a stride that is a multiple of 4 (HiFiGAN ups[0], ups[1]: 8): 16-byte stores
-        const bool shuffle_vec = (MODE == TTSAMD_CONV_SHUFFLE) && (ep->shuffle_u % 4 == 0) && (ep->shuffle_pad % 4 == 0) &&
+        const bool shuffle_vec = (MODE == TTSAMD_CONV_SHUFFLE) && (shuffle_u % 4 == 0) && (shuffle_pad % 4 == 0) &&
                                  (c_out % 4 == 0) && ((y_rs & 3) == 0) && ((y_bs & 3) == 0) &&
                                  ((reinterpret_cast<unsigned long long>(y) & 15ull) == 0);
-        const bool shuffle_vec2 = (MODE == TTSAMD_CONV_SHUFFLE) && ep->shuffle_u == 2 && ep->shuffle_pad == 1 && (c_out % 2 == 0);
+        const bool shuffle_vec2 = (MODE == TTSAMD_CONV_SHUFFLE) && shuffle_u == 2 && shuffle_pad == 1 && (c_out % 2 == 0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int row0 = ((mb * WM + wm) * MI + mi) * 32;
@@ -250,14 +270,28 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                 }
                 const int voy = tv ? (4 * h * y_rs4 + t * 4) : kOob;
                 const int voy2 = tv ? (4 * h * y2_rs4 + t * 4) : kOob;
+                const bool has_div = out_div != 0.f;
+                if constexpr (MODE == TTSAMD_CONV_NORMAL) {
+                    // bias + activation in place on the accumulators; out_act is wave-uniform: its branches sit outside the
+                    // unrolled element loop
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += radd[r];
+                    if (out_act == TTSAMD_ACT_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+                    } else if (out_act == TTSAMD_ACT_TANH) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = tanhf(acc[mi][ni][r]);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rb = row0 + (r & 3) + 8 * (r >> 2);
                     const int row = rb + 4 * h;
                     const bool rok = row < c_out;
-                    float v = acc[mi][ni][r] + radd[r];
+                    float v = (MODE == TTSAMD_CONV_NORMAL) ? acc[mi][ni][r] : acc[mi][ni][r] + radd[r];
                     if constexpr (MODE == TTSAMD_CONV_SHUFFLE) {
-                        const int u = ep->shuffle_u;
+                        const int u = shuffle_u;
                         if (shuffle_vec) {
                             // stride u % 4 == 0: a lane's four consecutive packed rows (r & 3 = 0..3) are four consecutive
                             // phases of one output channel = four consecutive output samples: ONE 16-byte store per group
@@ -266,8 +300,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                                 const int rowg = rb + 4 * h;                    // first row of the group (rb is row r&~3 ... + (r&3))
                                 const int row_first = rowg - 3;
                                 const int co = row_first / u;
-                                const int n = t * u + (row_first - co * u) - ep->shuffle_pad;
-                                const bool ok = tv && (row_first + 3 < c_out) && n >= 0 && n + 3 < ep->shuffle_t_out;
+                                const int n = t * u + (row_first - co * u) - shuffle_pad;
+                                const bool ok = tv && (row_first + 3 < c_out) && n >= 0 && n + 3 < shuffle_t_out;
                                 f32x4s q;
                                 q[0] = acc[mi][ni][r - 3] + radd[r - 3];
                                 q[1] = acc[mi][ni][r - 2] + radd[r - 2];
@@ -282,21 +316,21 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                                 const int co = (row - 1) >> 1;
                                 const int n = t * 2 - 1;                        // sample of phase 0 (pad = 1)
                                 const float v0 = acc[mi][ni][r - 1] + radd[r - 1];
-                                if (tv && rok && n >= 0 && n + 1 < ep->shuffle_t_out) {
+                                if (tv && rok && n >= 0 && n + 1 < shuffle_t_out) {
                                     f32x2u q;
                                     q[0] = v0;
                                     q[1] = v;
                                     *reinterpret_cast<f32x2u *>(y + (long)b * y_bs + (long)co * y_rs + n) = q;
                                 } else if (tv && rok) {
-                                    if (n >= 0 && n < ep->shuffle_t_out) y[(long)b * y_bs + (long)co * y_rs + n] = v0;
-                                    if (n + 1 >= 0 && n + 1 < ep->shuffle_t_out) y[(long)b * y_bs + (long)co * y_rs + n + 1] = v;
+                                    if (n >= 0 && n < shuffle_t_out) y[(long)b * y_bs + (long)co * y_rs + n] = v0;
+                                    if (n + 1 >= 0 && n + 1 < shuffle_t_out) y[(long)b * y_bs + (long)co * y_rs + n + 1] = v;
                                 }
                             }
                         } else {
                             const int co = row / u;
                             const int rr = row - co * u;
-                            const int n = t * u + rr - ep->shuffle_pad;
-                            const bool ok = tv && rok && n >= 0 && n < ep->shuffle_t_out;
+                            const int n = t * u + rr - shuffle_pad;
+                            const bool ok = tv && rok && n >= 0 && n < shuffle_t_out;
                             st_buf(ry, v, ok ? (co * y_rs4 + n * 4) : kOob, 0);
                         }
                     } else if constexpr (MODE == TTSAMD_CONV_COUPLE) {
@@ -312,12 +346,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                             st_buf(ry2, v, rok ? voy2 : kOob, (rb - split) * y2_rs4);
                         }
                     } else {
-                        if (out_act == TTSAMD_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (out_act == TTSAMD_ACT_TANH) v = tanhf(v);
                         v += e1[r];              // 0 when absent / folded
                         v = e2[r] + v;
                         v *= om;
-                        if (out_div != 0.f) v = v / out_div;
+                        if (has_div) v = v / out_div;
                         st_buf(ry, v, rok ? voy : kOob, rb * y_rs4);
                     }
                 }

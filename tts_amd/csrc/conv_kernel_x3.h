@@ -35,7 +35,9 @@
 #endif
 namespace ttsamd {
 constexpr long kConvSmallGridBlocks = 128;  // up to this many 128x128-class blocks a launch takes the small-grid tiles
-extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = small tiles + K-split groups (default)
+constexpr long kConvWaveTileBlocks = 1024;  // up to this many 32x32 tiles those kernels run a wave per tile and K slice
+constexpr long kConvLatencyBlocks = 64;     // up to this many default blocks mode 3 takes the latency-tuned kernels (conv_kernel_x3s.h)
+extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = + K-split groups, 3 / 4 = + conv_kernel_x3s.h kernels
 }
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
@@ -312,6 +314,9 @@ int conv1d_x3_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
     return TTSAMD_OK;
 }
 
+template <int K, int D, int MI, int MODE>
+bool conv1d_x3s_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc);   // conv_kernel_x3s.h
+
 template <int K, int D, int MODE>
 int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
 {
@@ -331,6 +336,13 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
         if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks) {
             // >= 8 channel chunks (c_in >= 128): four wave groups split the chunks of the block's K loop between them
             const bool ksplit = g_conv_small_grid > 1 && a.c_in >= 8 * kConvCK;
+            if constexpr (D == 1 && K <= 5) {
+                // latency-tuned small-grid kernels (conv_kernel_x3s.h): mode 3 up to kConvLatencyBlocks default blocks, mode 4 always
+                if (ksplit && (g_conv_small_grid >= 4 || (g_conv_small_grid == 3 && blocks_default <= kConvLatencyBlocks))) {
+                    int rc = TTSAMD_OK;
+                    if (conv1d_x3s_launch<K, D, (paired ? 2 : 1), MODE>(a, st, &rc)) return rc;
+                }
+            }
             if constexpr (paired) {
                 if (mtiles % 4 == 0) {                                                                 // 128 rows x 64 columns
                     if (ksplit) return conv1d_x3_launch_cfg<K, D, 2, 1, 2, 2, MODE, 2>(a, st);   // 2 groups: 4 would cap the kernel at 128 VGPRs (spills)

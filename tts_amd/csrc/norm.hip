@@ -12,6 +12,8 @@
 
 namespace ttsamd {
 
+constexpr int kNormSmallT = 2048;   // up to this many columns the 16-column tiles are used
+
 template <int NC, int kNormGroups>  // channels per thread, channel groups per block (C <= NC * kNormGroups)
 __global__ __launch_bounds__(64 * kNormGroups) void channel_norm_kernel(const ttsamd_norm_args a)
 {
@@ -88,6 +90,111 @@ __global__ __launch_bounds__(64 * kNormGroups) void channel_norm_kernel(const tt
     }
 }
 
+// Text-length tensors (T of a few hundred columns: every norm of the text encoder / duration predictors): the launch is a
+// handful of blocks and its time is one block's dependent chain, so the tile is 16 time columns x 64 channel groups — a
+// thread owns C/64 channels (3 at C = 192) instead of C/16, four times the blocks — and the depthwise prologue walks the
+// taps in the OUTER loop (one column index, validity and mask value per tap instead of one per tap and channel).
+// A wavefront = 16 time lanes x 4 channel groups: group sums first meet across the wave (two shuffles), then across the 16
+// waves through LDS in a fixed order (deterministic).
+template <int NC>   // channels per thread (C <= 64 * NC)
+__global__ __launch_bounds__(1024) void channel_norm_small_kernel(const ttsamd_norm_args a)
+{
+    __shared__ float red[2][16][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int tl = lane & 15;
+    const int grp = wave * 4 + (lane >> 4);     // channel group: channels grp, grp + 64, ...
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 16 + tl;
+    const bool tv = t < a.t;
+    const float *xb = a.x + (long)b * a.x_bstride;
+    const float *im = a.in_mask ? a.in_mask + (long)b * a.t : nullptr;
+
+    float v[NC];
+    bool cv[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        cv[i] = tv && (grp + i * 64 < a.c);
+        v[i] = 0.f;
+    }
+    if (a.dw_w) {
+        const int half = (a.dw_kernel - 1) / 2;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            if (cv[i] && a.dw_bias) v[i] = a.dw_bias[grp + i * 64];
+        for (int k = 0; k < a.dw_kernel; ++k) {
+            const int tt = t + (k - half) * a.dw_dilation;
+            const bool ok = tt >= 0 && tt < a.t;
+            const float mk = (ok && im) ? im[tt] : 1.f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (cv[i] && ok) {
+                    const int c = grp + i * 64;
+                    float xv = xb[(long)c * a.x_rstride + tt];
+                    if (im) xv *= mk;
+                    v[i] += a.dw_w[c * a.dw_kernel + k] * xv;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            if (cv[i]) v[i] = xb[(long)(grp + i * 64) * a.x_rstride + t];
+    }
+    if (a.pre_res) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            if (cv[i]) v[i] += a.pre_res[(long)b * a.pre_bstride + (long)(grp + i * 64) * a.pre_rstride + t];
+    }
+    // epilogue operands requested before the statistics passes (their latency hides under the two reductions)
+    float gam[NC], bet[NC], pres[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = grp + i * 64;
+        gam[i] = cv[i] ? a.gamma[c] : 0.f;
+        bet[i] = cv[i] ? a.beta[c] : 0.f;
+        pres[i] = (cv[i] && a.post_res) ? a.post_res[(long)b * a.post_bstride + (long)c * a.post_rstride + t] : 0.f;
+    }
+    const float om = (a.out_mask && tv) ? a.out_mask[(long)b * a.t + t] : 1.f;
+
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) s += cv[i] ? v[i] : 0.f;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (lane < 16) red[0][wave][tl] = s;
+    __syncthreads();
+    float tot = red[0][0][tl];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) tot += red[0][w][tl];
+    const float mean = tot / (float)a.c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const float d = v[i] - mean;
+        q += cv[i] ? d * d : 0.f;
+    }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (lane < 16) red[1][wave][tl] = q;
+    __syncthreads();
+    float tot2 = red[1][0][tl];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) tot2 += red[1][w][tl];
+    const float rstd = 1.0f / sqrtf(tot2 / (float)a.c + a.eps);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (cv[i]) {
+            float o = (v[i] - mean) * rstd * gam[i] + bet[i];
+            if (a.act == TTSAMD_ACT_RELU) o = fmaxf(o, 0.f);
+            else if (a.act == TTSAMD_ACT_GELU) o = o * 0.5f * (1.0f + erff(o * 0.70710678118654752440f));
+            if (a.post_res) o = pres[i] + o;
+            if (a.out_mask) o *= om;
+            a.y[(long)b * a.y_bstride + (long)(grp + i * 64) * a.y_rstride + t] = o;
+        }
+    }
+}
+
 }  // namespace ttsamd
 using namespace ttsamd;
 
@@ -107,8 +214,17 @@ extern "C" int ttsamd_channel_norm(const ttsamd_norm_args *args, void *stream)
     }
     if (a.batch == 0 || a.t == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(a.batch <= 65535, "channel_norm: batch > 65535");
-    const dim3 grid((a.t + 63) / 64, a.batch);
     hipStream_t st = as_stream(stream);
+    // text-length tensors: 16-column tiles (chosen by T alone, never by the batch: row b of a batch stays bitwise the B = 1 run)
+    if (a.t <= kNormSmallT) {
+        const dim3 sgrid((a.t + 15) / 16, a.batch);
+        if (a.c <= 192) hipLaunchKernelGGL((channel_norm_small_kernel<3>), sgrid, dim3(1024), 0, st, a);
+        else if (a.c <= 256) hipLaunchKernelGGL((channel_norm_small_kernel<4>), sgrid, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((channel_norm_small_kernel<8>), sgrid, dim3(1024), 0, st, a);
+        TTSAMD_LAUNCH_CHECK();
+        return TTSAMD_OK;
+    }
+    const dim3 grid((a.t + 63) / 64, a.batch);
     // 16 channel groups x 64 time lanes = 1024 threads per block: the launch is latency-bound (a few MB), so the
     // per-thread dependent chain is kept short (12..32 channels) rather than the block count high
     if (a.c <= 192) hipLaunchKernelGGL((channel_norm_kernel<12, 16>), grid, dim3(64, 16), 0, st, a);
