@@ -159,10 +159,9 @@ int ttsamd_conv1d_supported(int kernel, int dilation);
 /* Launches that would put fewer than ~100 blocks on the chip (single-sentence requests): 0 = the large-grid tiles
  * everywhere, 1 = 64-column tiles with one 32x32 tile per wave (same summation order: bitwise the large-grid result),
  * 2 = those tiles plus, for c_in >= 128, wave groups that split the block's K loop and are reduced in a fixed order
- * (deterministic; fp32 reassociation relative to modes 0 / 1), 3 = as 2, with the latency-tuned kernels of
- * conv_kernel_x3s.h (weights requested a whole K iteration ahead, straight-line request streams) for kernel sizes <= 5
- * at dilation 1 on launches of up to 64 default blocks, 4 = those kernels on every small-grid launch.
- * Returns the previous mode. */
+ * (deterministic; fp32 reassociation relative to modes 0 / 1), 3 (default) = as 2, with the small-grid kernels of
+ * conv_kernel_x3s.h for kernel sizes <= 5 at dilation 1: a wave per 32x32 tile and K slice, weights requested a whole
+ * K iteration ahead, straight-line request streams.  Returns the previous mode. */
 int ttsamd_conv1d_set_small_grid(int mode);
 
 /* One ResBlock1 iteration of the HiFiGAN MRF as a single launch — replaces the body of the loop in

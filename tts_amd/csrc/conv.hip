@@ -7,18 +7,18 @@
 using namespace ttsamd;
 
 namespace ttsamd {
-// small-grid policy (see ttsamd_conv1d_set_small_grid); TTSAMD_CONV_SMALL_GRID=<0..4> overrides the default for A/B runs
+// small-grid policy (see ttsamd_conv1d_set_small_grid); TTSAMD_CONV_SMALL_GRID=<0..3> overrides the default for A/B runs
 int g_conv_small_grid = [] {
     const char *e = getenv("TTSAMD_CONV_SMALL_GRID");
-    const int m = e ? atoi(e) : 2;
-    return m < 0 ? 0 : (m > 4 ? 4 : m);
+    const int m = e ? atoi(e) : 3;
+    return m < 0 ? 0 : (m > 3 ? 3 : m);
 }();
 }
 
 extern "C" int ttsamd_conv1d_set_small_grid(int mode)
 {
     const int was = g_conv_small_grid;
-    g_conv_small_grid = mode < 0 ? 0 : (mode > 4 ? 4 : mode);
+    g_conv_small_grid = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
     return was;
 }
 

@@ -36,8 +36,7 @@
 namespace ttsamd {
 constexpr long kConvSmallGridBlocks = 128;  // up to this many 128x128-class blocks a launch takes the small-grid tiles
 constexpr long kConvWaveTileBlocks = 1024;  // up to this many 32x32 tiles those kernels run a wave per tile and K slice
-constexpr long kConvLatencyBlocks = 64;     // up to this many default blocks mode 3 takes the latency-tuned kernels (conv_kernel_x3s.h)
-extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = + K-split groups, 3 / 4 = + conv_kernel_x3s.h kernels
+extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = + K-split groups, 3 = + conv_kernel_x3s.h kernels (default)
 }
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
@@ -337,8 +336,8 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
             // >= 8 channel chunks (c_in >= 128): four wave groups split the chunks of the block's K loop between them
             const bool ksplit = g_conv_small_grid > 1 && a.c_in >= 8 * kConvCK;
             if constexpr (D == 1 && K <= 5) {
-                // latency-tuned small-grid kernels (conv_kernel_x3s.h): mode 3 up to kConvLatencyBlocks default blocks, mode 4 always
-                if (ksplit && (g_conv_small_grid >= 4 || (g_conv_small_grid == 3 && blocks_default <= kConvLatencyBlocks))) {
+                // mode 3 (default): the small-grid kernels of conv_kernel_x3s.h
+                if (ksplit && g_conv_small_grid >= 3) {
                     int rc = TTSAMD_OK;
                     if (conv1d_x3s_launch<K, D, (paired ? 2 : 1), MODE>(a, st, &rc)) return rc;
                 }

@@ -88,7 +88,7 @@ def conv_precision():
 
 
 def set_conv_small_grid(mode):
-    """0 .. 4, see ttsamd_conv1d_set_small_grid (include/tts_amd.h); returns the previous mode."""
+    """0 .. 3, see ttsamd_conv1d_set_small_grid (include/tts_amd.h); returns the previous mode."""
     return int(lib().ttsamd_conv1d_set_small_grid(int(mode)))
 
 
