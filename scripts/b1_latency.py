@@ -10,6 +10,20 @@ import bench  # noqa: E402
 from tts_amd import synthetic as W  # noqa: E402
 from tts_amd.vits import Vits  # noqa: E402
 
+# time the host spends BLOCKED in the request's one device sync (y_lengths.max().item()): "inside inference()" minus this is
+# what the host itself costs (issue of the launches / graph replays, output clones)
+_item = torch.Tensor.item
+_blocked = [0.0]
+
+
+def _timed_item(self):
+    t = time.perf_counter()
+    v = _item(self)
+    _blocked[0] += time.perf_counter() - t
+    return v
+
+
+torch.Tensor.item = _timed_item
 dev = torch.device("cuda:0")
 m = Vits({"model_args": {}})
 m.load_state_dict(W.make_vits_state({}, seed=1))
@@ -27,6 +41,7 @@ for mode, extra in (("eager tail (front end graphed)", {"no_graph_tail": True}),
         m.inference(x, aux)
     torch.cuda.synchronize()
     n, t_issue = 20, 0.0
+    _blocked[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(n):
         t1 = time.perf_counter()
@@ -34,5 +49,7 @@ for mode, extra in (("eager tail (front end graphed)", {"no_graph_tail": True}),
         t_issue += time.perf_counter() - t1
         o["model_outputs"].cpu()
     dt = (time.perf_counter() - t0) / n
-    print("B=%d %-32s %.2f ms per request (waveform on the host), %.2f ms inside inference() [includes the duration sync], rtf_x=%.0f"
-          % (B, mode, dt * 1e3, t_issue / n * 1e3, B * 197120 / 22050 / dt), flush=True)
+    print("B=%d %-32s %.2f ms per request (waveform on the host), %.2f ms inside inference() of which %.2f blocked in the duration "
+          "sync => host issue %.2f ms, rtf_x=%.0f"
+          % (B, mode, dt * 1e3, t_issue / n * 1e3, _blocked[0] / n * 1e3, (t_issue - _blocked[0]) / n * 1e3,
+             B * 197120 / 22050 / dt), flush=True)
