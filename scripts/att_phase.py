@@ -1,5 +1,6 @@
-"""Phase clocks of the relative-position attention kernel (debug build, scripts/build_dbg.sh):
-TTSAMD_LIB_PATH=tts_amd/build_dbg/libtts_amd_dbg.so python scripts/att_phase.py [B T heads dk]"""
+"""Phase clocks of the relative-position attention kernel (debug build):
+  TTSAMD_BUILD_TAG=dbg TTSAMD_EXTRA_FLAGS=-DTTSAMD_PHASE_CLOCKS python -m tts_amd.build
+  TTSAMD_LIB_PATH=tts_amd/libtts_amd_dbg.so python scripts/att_phase.py [B T heads dk]"""
 import ctypes, sys
 import torch
 sys.path.insert(0, '.')

@@ -1,3 +1,8 @@
+"""Same-box A/B of library variants on the headline bench line (each variant twice, interleaved):
+  TTSAMD_BUILD_TAG=<tag> TTSAMD_EXTRA_FLAGS="<flags>" python -m tts_amd.build      # -> tts_amd/libtts_amd_<tag>.so
+  python scripts/bench_ab.py tts_amd/libtts_amd.so tts_amd/libtts_amd_<tag>.so ...
+e.g. <flags> = -fno-slp-vectorize (scalar instead of packed f32 VALU ops in the staging code) or a
+-DTTSAMD_X3_CFG128=... tile arrangement."""
 import sys, time, os, subprocess, json
 libs = sys.argv[1:]
 for rep in range(2):
