@@ -74,6 +74,27 @@ __device__ __forceinline__ void conv_split3(float x, unsigned &p1, unsigned &p2,
     p3 = __builtin_bit_cast(unsigned short, a3);
 }
 
+// Build-time experiment (TTSAMD_EXTRA_FLAGS=-DTTSAMD_SPLIT_PAIRS=1, A/B through TTSAMD_LIB_PATH): split TWO values per
+// conversion instruction and keep the parts packed — the same round-to-nearest-even conversions and exact residuals as
+// conv_split3, bit for bit, without the 12 v_or_b32_sdwa per 8 values that re-pack separately converted halves
+// (80 -> 62 VALU instructions per 8 staged values, compile-only count; not yet measured on a GPU).
+#ifndef TTSAMD_SPLIT_PAIRS
+#define TTSAMD_SPLIT_PAIRS 0
+#endif
+__device__ __forceinline__ void conv_split3x2(float x0, float x1, unsigned &w1, unsigned &w2, unsigned &w3)
+{
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f32x2 v = {x0, x1};
+    const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r1 = {x0 - __builtin_bit_cast(float, u1 << 16), x1 - __builtin_bit_cast(float, u1 & 0xffff0000u)};       // exact
+    const unsigned u2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    const f32x2 r2 = {r1[0] - __builtin_bit_cast(float, u2 << 16), r1[1] - __builtin_bit_cast(float, u2 & 0xffff0000u)};  // exact
+    w1 = u1;
+    w2 = u2;
+    w3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
 // KS > 1 (small-grid launches only): the block carries KS wave groups of WM x WN waves; group g reduces the channel chunks
 // g, g + KS, ... into its own accumulators through its own LDS double buffer (the serial K loop of a block — what a launch
 // of a few blocks is bound by — becomes KS times shorter), and group 0 adds the partial tiles of groups 1..KS-1 (in that
@@ -148,17 +169,32 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : C
             const int half = e / G::kXW;
             const int col = e - half * G::kXW;
             if (e < G::kItems) {
+#if TTSAMD_SPLIT_PAIRS
+                unsigned pw[3][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    conv_split3x2(conv_in_act(st[i][2 * c] * smask[i], a.in_act, a.in_slope),
+                                  conv_in_act(st[i][2 * c + 1] * smask[i], a.in_act, a.in_slope), pw[0][c], pw[1][c], pw[2][c]);
+#else
                 unsigned p[3][8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
                     conv_split3(conv_in_act(st[i][c] * smask[i], a.in_act, a.in_slope), p[0][c], p[1][c], p[2][c]);
+#endif
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     u32x4 w;
+#if TTSAMD_SPLIT_PAIRS
+                    w.x = pw[q][0];
+                    w.y = pw[q][1];
+                    w.z = pw[q][2];
+                    w.w = pw[q][3];
+#else
                     w.x = p[q][0] | (p[q][1] << 16);
                     w.y = p[q][2] | (p[q][3] << 16);
                     w.z = p[q][4] | (p[q][5] << 16);
                     w.w = p[q][6] | (p[q][7] << 16);
+#endif
 #if TTSAMD_X3_PLANAR
                     *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + half * (G::kXW * 16) + col * 16) = w;
 #else

@@ -116,15 +116,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS * WM * WN >= 4 ? KS * WM * W
         for (int cc = 0; cc < CPI; ++cc)
 #pragma unroll
             for (int r = 0; r < G::kRounds; ++r) {
+#if TTSAMD_SPLIT_PAIRS
+                unsigned pw[3][2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    conv_split3x2(conv_in_act(st[cc][r][2 * c] * smask[r], a.in_act, a.in_slope),
+                                  conv_in_act(st[cc][r][2 * c + 1] * smask[r], a.in_act, a.in_slope), pw[0][c], pw[1][c], pw[2][c]);
+#else
                 unsigned p[3][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     conv_split3(conv_in_act(st[cc][r][c] * smask[r], a.in_act, a.in_slope), p[0][c], p[1][c], p[2][c]);
+#endif
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     u32x2 w;
+#if TTSAMD_SPLIT_PAIRS
+                    w.x = pw[q][0];
+                    w.y = pw[q][1];
+#else
                     w.x = p[q][0] | (p[q][1] << 16);
                     w.y = p[q][2] | (p[q][3] << 16);
+#endif
                     unsigned char *dst = buf + cc * G::kChunkBytes + q * G::kPartBytes + loff[r];
                     if (G::kPartial && r == G::kRounds - 1) dst = last_valid ? dst : dump;
                     *reinterpret_cast<u32x2 *>(dst) = w;

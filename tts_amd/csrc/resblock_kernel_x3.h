@@ -144,17 +144,32 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                 const int pl = e / G::kXW;
                 const int col = e - pl * G::kXW;
                 if (e < G::kItems) {
+#if TTSAMD_SPLIT_PAIRS
+                    unsigned pw[3][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        conv_split3x2(conv_in_act(st[rr][2 * i] * sm[rr], TTSAMD_ACT_LRELU, a.slope),
+                                      conv_in_act(st[rr][2 * i + 1] * sm[rr], TTSAMD_ACT_LRELU, a.slope), pw[0][i], pw[1][i], pw[2][i]);
+#else
                     unsigned p[3][8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         conv_split3(conv_in_act(st[rr][i] * sm[rr], TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
+#endif
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         u32x4 w;
+#if TTSAMD_SPLIT_PAIRS
+                        w.x = pw[q][0];
+                        w.y = pw[q][1];
+                        w.z = pw[q][2];
+                        w.w = pw[q][3];
+#else
                         w.x = p[q][0] | (p[q][1] << 16);
                         w.y = p[q][2] | (p[q][3] << 16);
                         w.z = p[q][4] | (p[q][5] << 16);
                         w.w = p[q][6] | (p[q][7] << 16);
+#endif
                         *reinterpret_cast<u32x4 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneX + col * 16) = w;
                     }
                 }
@@ -234,19 +249,35 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                 const int col = (wn * NI + ni) * 32 + j;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+#if TTSAMD_SPLIT_PAIRS
+                    unsigned pw[3][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float v0 = (acc[mi][ni][rg * 4 + 2 * i] + bia[mi][rg * 4 + 2 * i]) * mk[ni];
+                        const float v1 = (acc[mi][ni][rg * 4 + 2 * i + 1] + bia[mi][rg * 4 + 2 * i + 1]) * mk[ni];
+                        conv_split3x2(conv_in_act(v0, TTSAMD_ACT_LRELU, a.slope), conv_in_act(v1, TTSAMD_ACT_LRELU, a.slope), pw[0][i],
+                                      pw[1][i], pw[2][i]);
+                    }
+#else
                     unsigned p[3][4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float v = (acc[mi][ni][rg * 4 + i] + bia[mi][rg * 4 + i]) * mk[ni];
                         conv_split3(conv_in_act(v, TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
                     }
+#endif
                     // rows 8*rg + 4*h + i of m-tile (wm*MI + mi): chunk 2*mtile + rg/2, 8-channel half rg%2, channels 4h..4h+3
                     const int pl = (2 * (wm * MI + mi) + (rg >> 1)) * 2 + (rg & 1);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         u32x2 w;
+#if TTSAMD_SPLIT_PAIRS
+                        w.x = pw[q][0];
+                        w.y = pw[q][1];
+#else
                         w.x = p[q][0] | (p[q][1] << 16);
                         w.y = p[q][2] | (p[q][3] << 16);
+#endif
                         *reinterpret_cast<u32x2 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneM + col * 16 + h * 8) = w;
                     }
                 }
