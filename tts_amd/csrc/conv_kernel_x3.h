@@ -41,6 +41,12 @@ extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tile
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
 #endif
+// Build-time experiment (TTSAMD_EXTRA_FLAGS=-DTTSAMD_X3S_ALL=1): the conv_kernel_x3s.h kernels for EVERY kernel size / dilation
+// on small grids (the waveform decoder's 512/256-channel stages of a single utterance, conv_pre), not only k <= 5 at
+// dilation 1.  Builds; not yet measured on a GPU.
+#ifndef TTSAMD_X3S_ALL
+#define TTSAMD_X3S_ALL 0
+#endif
 
 namespace ttsamd {
 
@@ -371,7 +377,7 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
         if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks) {
             // >= 8 channel chunks (c_in >= 128): four wave groups split the chunks of the block's K loop between them
             const bool ksplit = g_conv_small_grid > 1 && a.c_in >= 8 * kConvCK;
-            if constexpr (D == 1 && K <= 5) {
+            if constexpr (TTSAMD_X3S_ALL || (D == 1 && K <= 5)) {
                 // mode 3 (default): the small-grid kernels of conv_kernel_x3s.h
                 if (ksplit && g_conv_small_grid >= 3) {
                     int rc = TTSAMD_OK;

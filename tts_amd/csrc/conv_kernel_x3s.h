@@ -343,7 +343,7 @@ bool conv1d_x3s_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc)
     // rows never get here with a small grid (their 32-column tiling has 8x the default blocks, the unpaired one 16x).
     if constexpr (MI == 1) {
         if (mtiles % 2 == 0) {
-            *rc = conv1d_x3s_launch_geom<K, D, 1, 2, 2, MODE, 4, CPI>(a, st);
+            *rc = conv1d_x3s_launch_geom<K, D, 1, 2, 2, MODE, (K > 5 ? 2 : 4), CPI>(a, st);   // k = 7 / 11 (TTSAMD_X3S_ALL): K weight slots need > 128 VGPRs
             return true;
         }
     }
