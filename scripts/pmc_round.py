@@ -8,8 +8,11 @@ SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over all SIMDs (256 CUs x 4); GRBM
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def load(path):
@@ -64,5 +67,8 @@ if sel:
     for key in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch", "mfma_busy_frac", "kernel_cycles"):
         if any(key in r for r in sel):
             res[key] = avg(key)
+    import bench          # code_stamp: sha256 of the kernel sources these counters were recorded with (bench.py checks it)
+
+    res["code_stamp"] = bench.code_stamp()
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))

@@ -60,8 +60,14 @@ def test_bench_self_launch_world2_gloo():
                         "--backend", "gloo", "--steps", "3"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout
-    r = json.loads(lines[0])
+    # output contract: bulky {"detail": ...} tables first, the headline line LAST and compact (the driver keeps ~10 KB of
+    # tail: round 2's single 21 KB line lost its head and nothing parsed), carrying roofline.frac and cpu_baseline
+    assert len(lines) >= 2 and all("detail" in json.loads(ln) for ln in lines[:-1]), p.stdout[-2000:]
+    assert len(lines[-1]) < 4096 and p.stdout.rstrip().endswith(lines[-1])
+    assert sum(len(ln) for ln in lines[:-1]) > 10000            # the filler table really is bulky
+    r = json.loads(lines[-1])
+    assert isinstance(r["roofline"]["frac"], float) and "traffic" in r["roofline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(r["cpu_baseline"])
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["config"]["parallelism"] == "replicas x2"
     assert r["config"]["weights_identical"] and r["config"]["weight_broadcast_bytes"] > 1e6
     assert r["config"]["units_per_step_all_ranks"] == 2001.0                  # SUM over ranks
@@ -70,3 +76,22 @@ def test_bench_self_launch_world2_gloo():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "launch_check"],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0"), cwd=ROOT, timeout=120)
     assert p.returncode != 0 and "--gpus 1" in (p.stderr + p.stdout)
+
+
+def test_bench_headline_stays_compact():
+    """bench.headline_json: whatever explanatory strings a workload attaches, the last line stays under the limit and no
+    number is dropped."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    line = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+            "config": {"workload": "w", "weights": "x" * 3000},
+            "roofline": {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "frac": 0.5, "traffic": None, "peak_note": "y" * 3000,
+                         "measured": "z" * 500},
+            "cpu_baseline": {"value": 1.0, "unit": "u", "cores": 8, "kind": "port", "sample": "s" * 3000}}
+    out = bench.headline_json(line)
+    assert len(out) <= bench.HEADLINE_MAX_BYTES
+    r = json.loads(out)
+    assert r["roofline"]["frac"] == 0.5 and r["cpu_baseline"]["value"] == 1.0 and r["value"] == 1.0
+    # the stamp that ties a committed PMC file to the running kernel sources is stable and 16 hex digits
+    assert bench.code_stamp() == bench.code_stamp() and len(bench.code_stamp()) == 16
