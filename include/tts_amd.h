@@ -31,6 +31,14 @@ const char *ttsamd_last_error(void);
 int ttsamd_abi_version(void);
 const char *ttsamd_arch(void);
 
+/* Streams owned by the caller through the library: a dedicated HIP stream on the current device (priority 0 = normal,
+ * -1 = high, 1 = low; clamped to the device's range).  The host side uses these for request lanes and for the MRF branch
+ * streams of a HiFiGAN generator, so that no two of them can ever be the same underlying stream (a framework stream pool
+ * hands its streams out round-robin and re-uses them).  replaces: the `torch.cuda.Stream()` objects around
+ * TTS/utils/synthesizer.py:384's sentence loop a torch caller would create. */
+int ttsamd_stream_create(int priority, void **stream_out);
+int ttsamd_stream_destroy(void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Monotonic alignment search
  * replaces: TTS/tts/utils/monotonic_align/core.pyx:42-47  maximum_path_c(paths, values, t_xs,

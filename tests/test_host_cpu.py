@@ -148,6 +148,10 @@ def test_split_into_sentences_reference_golden_strings():
         assert Synthesizer.split_into_sentences(text) == want, text
     assert Synthesizer.split_into_sentences("Dr. Green is in. Mr. Smith left.") == ["Dr. Green is in.", "Mr. Smith left."]
     assert Synthesizer.split_into_sentences("   ") == []
+    # abbreviation tables (pysbd keeps these whole; round 2 split after "U.S." and "fig.")
+    assert Synthesizer.split_into_sentences("The U.S. Army is big.") == ["The U.S. Army is big."]
+    assert Synthesizer.split_into_sentences("See fig. 2 for details. It is clear.") == ["See fig. 2 for details.", "It is clear."]
+    assert Synthesizer.split_into_sentences("He lives in the U.S. The next day he left.") == ["He lives in the U.S.", "The next day he left."]
 
 
 def test_audio_processor_norm_denorm_known_answers():

@@ -392,8 +392,15 @@ def test_vits_small_request_tail_graph_equals_eager(gpu):
                 assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (rep, k)
     assert m._tail.stats["captures"] >= 1 and m._tail.stats["replays"] >= 4, m._tail.stats
     assert len(m._tail.entries) <= 3            # lengths 29..87 frames fall into at most three 32-frame buckets
-    out = m.inference(x, {k: v for k, v in aux.items() if k != "noise_z"})          # own randn draw inside the graph
+    # the model's own randn draw (no noise_z): made outside the captured segment at the reference's shape, so with a fixed
+    # torch seed the graphed replay, a fresh capture and the eager launches produce the same audio bit for bit
+    free = {k: v for k, v in aux.items() if k != "noise_z"}
+    torch.manual_seed(77)
+    out = m.inference(x, free)
+    torch.manual_seed(77)
+    out_eager = m.inference(x, dict(free, no_graph=True))
     assert out["model_outputs"].shape == want["model_outputs"].shape and bool(torch.isfinite(out["model_outputs"]).all())
+    assert torch.equal(out["model_outputs"], out_eager["model_outputs"])
     # ragged batch (Synthesizer.tts_batch path)
     B, xl = 3, [29, 17, 8]
     x = torch.randint(0, 100, (B, T), generator=g).to(gpu)

@@ -65,6 +65,31 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class OwnedStream:
+    """A dedicated HIP stream created through the C ABI (ttsamd_stream_create) and wrapped for torch
+    (`torch.cuda.ExternalStream`): unlike `torch.cuda.Stream()`, whose objects are handed out round-robin from a pool of
+    32 per priority and therefore alias each other in a long-lived process, two OwnedStreams are never the same
+    underlying stream.  `.stream` is the torch view; destroyed with the owner (queued work still completes)."""
+
+    def __init__(self, device=None, priority=0):
+        import torch
+
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = ctypes.c_void_p(0)
+        with torch.cuda.device(self.device):
+            check(lib().ttsamd_stream_create(int(priority), ctypes.byref(h)), "stream_create")
+        self.handle = h.value
+        self.stream = torch.cuda.ExternalStream(self.handle, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.ttsamd_stream_destroy(ctypes.c_void_p(self.handle))
+                self.handle = None
+        except Exception:
+            pass
+
+
 def require_gpu(t, name="tensor"):
     if not t.is_cuda:
         raise TtsAmdError(

@@ -17,3 +17,21 @@ void set_error(const char *fmt, ...)
 extern "C" const char *ttsamd_last_error(void) { return ttsamd::g_err; }
 extern "C" int ttsamd_abi_version(void) { return 1; }
 extern "C" const char *ttsamd_arch(void) { return "gfx950"; }
+
+extern "C" int ttsamd_stream_create(int priority, void **stream_out)
+{
+    TTSAMD_CHECK_ARG(stream_out != nullptr, "stream_create: stream_out is NULL");
+    int lo = 0, hi = 0;                                   // lo = least priority (largest number), hi = greatest
+    TTSAMD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int pr = priority < hi ? hi : (priority > lo ? lo : priority);
+    hipStream_t st = nullptr;
+    TTSAMD_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr));
+    *stream_out = reinterpret_cast<void *>(st);
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_stream_destroy(void *stream)
+{
+    if (stream) TTSAMD_HIP(hipStreamDestroy(ttsamd::as_stream(stream)));
+    return TTSAMD_OK;
+}

@@ -213,9 +213,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
             (MODE == TTSAMD_CONV_RES_SKIP) ? ((long)(c_out - split - 1) * y2_rs + t_out) * 4 : 0);
         const int y2_rs4 = (MODE == TTSAMD_CONV_RES_SKIP) ? (int)y2_rs * 4 : 0;
         const bool has_accum = accum0 != nullptr;
-        // polyphase ConvTranspose with a stride that is a multiple of 4 (HiFiGAN ups[0], ups[1]: 8): 16-byte stores
+        // polyphase ConvTranspose with a stride that is a multiple of 4 (HiFiGAN ups[0], ups[1]: 8): 16-byte stores.  Groups
+        // start at sample indices that are multiples of 4, so with shuffle_t_out % 4 == 0 no group straddles the row end
+        // (a C-ABI caller's odd output length takes the dword path below instead of losing its last partial group)
         const bool shuffle_vec = (MODE == TTSAMD_CONV_SHUFFLE) && (shuffle_u % 4 == 0) && (shuffle_pad % 4 == 0) &&
-                                 (c_out % 4 == 0) && ((y_rs & 3) == 0) && ((y_bs & 3) == 0) &&
+                                 (c_out % 4 == 0) && ((y_rs & 3) == 0) && ((y_bs & 3) == 0) && ((shuffle_t_out & 3) == 0) &&
                                  ((reinterpret_cast<unsigned long long>(y) & 15ull) == 0);
         const bool shuffle_vec2 = (MODE == TTSAMD_CONV_SHUFFLE) && shuffle_u == 2 && shuffle_pad == 1 && (c_out % 2 == 0);
 #pragma unroll

@@ -127,7 +127,8 @@ class GlowTTS:
     def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None}):  # noqa: B006
         """glow_tts.py:341-374.  Optional aux keys: "noise" [B,C,T_dec] pins the randn_like(y_mean) draw;
         "ragged_exact": padded tokens own no frames (the reference gives each PADDED token one frame via clamp_min,
-        which only matters in batches) so that row b equals a B=1 run on sentence b."""
+        which only matters in batches) so that row b equals a B=1 run on sentence b (up to the conv launcher's batch-dependent
+        tile choice: fp32 reassociation, ~1e-6 relative)."""
         if self.encoder is None:
             raise _lib.TtsAmdError("tts_amd.GlowTTS: no weights loaded / not moved to the GPU")
         _lib.require_gpu(x, "x")

@@ -63,7 +63,7 @@ class HifiganGenerator:
         self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
         self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "32,64,128").split(",") if c)
         self.fuse_max_kernel = {128: 3}     # channel count -> largest kernel size fused (absent = all)
-        self._side_streams = []
+        self._side_streams = {}     # current stream handle -> its MRF branch streams
 
     def hop_length(self):
         return _cumprod(self.upsample_factors)[-1]
@@ -144,9 +144,14 @@ class HifiganGenerator:
         return sum(p.nbytes() for p in self._packed.values())
 
     def _streams(self, n):
-        while len(self._side_streams) < n:
-            self._side_streams.append(torch.cuda.Stream(device=self.device))
-        return self._side_streams[:n]
+        """MRF branch streams of the CURRENT stream: every request lane (parallel.Lanes) and every capture stream gets its
+        own set, so that two requests in flight never queue work on a common stream (round 2 shared one set between the
+        lanes: one lane's branch launches then sat behind the other lane's event waits)."""
+        key = torch.cuda.current_stream().cuda_stream
+        pool = self._side_streams.setdefault(key, [])
+        while len(pool) < n:
+            pool.append(_lib.OwnedStream(self.device))
+        return [o.stream for o in pool[:n]]
 
     # ---- forward (hifigan_generator.py:236-265) ----------------------------------------------------
     @torch.no_grad()
@@ -154,7 +159,10 @@ class HifiganGenerator:
         """`in_mask` [B,T] (optional) multiplies x inside conv_pre's load: VITS feeds `z * y_mask` (vits.py:1161).
         `lengths` [B] (optional, frames): ragged-exact batching — every conv of every stage reads item b as if its
         tensor ended at lengths[b] (positions beyond are zero, exactly the zero padding a stand-alone run of that item
-        sees), so the first lengths[b]*hop samples of row b equal a B=1 run on that item alone."""
+        sees), so the first lengths[b]*hop samples of row b equal a B=1 run on that item alone — bit for bit when every
+        conv launch of the two runs takes the same tile family, to fp32 reassociation (~1e-6 relative) otherwise: the
+        launcher picks the small-grid kernels (K loop split over wave groups, a different fp32 summation order) from the
+        launch's total block count, which grows with the batch (conv_kernel_x3.h: conv1d_x3_launch_tiles)."""
         if self._packed is None:
             raise _lib.TtsAmdError("HifiganGenerator: no weights loaded / not moved to the GPU")
         _lib.require_gpu(x, "x")
@@ -264,7 +272,8 @@ class HifiganGenerator:
     def inference_slabbed(self, c, out=None, max_live_bytes=48 << 30):
         """`inference` over a batch too large to hold layer-by-layer (BASELINE config 3: [256, 80, 8192] mels would need
         6 live tensors of 69 GB each): the batch is cut into slabs whose live activations fit `max_live_bytes`; items are
-        independent, so slabbing changes nothing numerically.  c may live on the host or the device; `out`
+        independent, so slabbing changes nothing but — when a slab is small enough for the launcher to pick the small-grid
+        tile family where the full batch would not — the fp32 summation order inside a conv (~1e-6 relative).  c may live on the host or the device; `out`
         ([B,1,(T+2p)*hop], host or device) receives the waveforms (allocated on c's device if None)."""
         B, C, T = c.shape
         hop = 1

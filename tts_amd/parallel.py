@@ -89,7 +89,10 @@ class Lanes:
         # High-priority lane streams: a request's own launches (text front end, flows, up-sampling convs) then win free CU
         # slots over the other lane's resblock convs, which run on the generator's normal-priority branch streams —
         # otherwise every one of the front end's ~170 dependent launches queues behind a chip-filling decoder kernel.
-        self.streams = [torch.cuda.Stream(device=device, priority=priority) for _ in range(max(1, int(n)))]
+        from . import _lib
+
+        self._owned = [_lib.OwnedStream(device, priority) for _ in range(max(1, int(n)))]    # dedicated, never pool-aliased
+        self.streams = [o.stream for o in self._owned]
         self._next = 0
         self._outs = [None] * len(self.streams)   # keep each lane's last result alive until the lane is reused
 

@@ -25,6 +25,15 @@ from .vits import Vits, _get
 
 _MODELS = {"vits": Vits, "glow_tts": GlowTTS}
 # titles that precede a name: a period after them never ends a sentence (pysbd English PREPOSITIVE_ABBREVIATIONS)
+# pysbd's English tables (restated): abbreviations that are followed by a NUMBER never end a sentence ("fig. 2", "no. 5");
+# any other known abbreviation ends one only when the next word is one of the usual sentence starters ("U.S. Army" stays
+# whole, "... in the U.S. The next day ..." splits).
+_NUMBER_ABBREVIATIONS = frozenset("art ext no nos p pp fig figs vol vols ch sec eq para".split())
+_OTHER_ABBREVIATIONS = frozenset(
+    "u.s u.k u.n e.g i.e a.m p.m a.d b.c etc inc ltd co corp jr sr bros approx dept est apt ave blvd rd no fig vs al "
+    "jan feb mar apr jun jul aug sep sept oct nov dec mon tue tues wed thu thurs fri sat sun univ assn mfg ft oz lb".split())
+_SENTENCE_STARTERS = frozenset("A Being Did For He How However I In It Millions More She That The There They We What When "
+                               "Where Who Why".split())
 _PREPOSITIVE_ABBREVIATIONS = frozenset("adm attys brig capt cmdr col cpl det dr gen gov ing lt maj mr mrs ms mt messrs mssrs prof ph rep reps rev sen sens sgt st supt v vs".split())
 
 
@@ -102,6 +111,8 @@ class Synthesizer:
           * titles that precede a name (dr., mr., mrs., ...) never end a sentence; other abbreviations (co., jr., U.K.)
             do when a capitalised word follows — pysbd's prepositive / other abbreviation split;
           * runs of list markers `1.) 2.)`, `1) 2)`, `1. 2.`, `a. b. c.` start a new segment each.
+          * abbreviations before a number ("fig. 2", "no. 5") and known abbreviations before a word that is not one of
+            pysbd's sentence starters ("The U.S. Army is big.") do not end a sentence.
         Known differences from pysbd: no per-language rule sets (`_get_segmenter(lang)`), no ellipsis / parenthetical /
         exclamation-word ("Yahoo!") tables beyond the lowercase-follows rule."""
         text = re.sub(r"\s+", " ", text.strip())
@@ -140,8 +151,15 @@ class Synthesizer:
                 if not nxt or nxt[0].islower():
                     continue
                 word = re.search(r"([A-Za-z.]+)$", seg[start:m.start()])
-                if word and seg[m.start()] == "." and word.group(1).lower().rstrip(".") in _PREPOSITIVE_ABBREVIATIONS:
-                    continue
+                if word and seg[m.start()] == "." and m.end() - m.start() == 1:
+                    abbr = word.group(1).lower().rstrip(".")
+                    if abbr in _PREPOSITIVE_ABBREVIATIONS:
+                        continue
+                    if abbr in _NUMBER_ABBREVIATIONS and nxt[0].isdigit():
+                        continue
+                    if abbr in _OTHER_ABBREVIATIONS and re.match(r"[A-Za-z]+", nxt) and \
+                            re.match(r"[A-Za-z]+", nxt).group(0) not in _SENTENCE_STARTERS:
+                        continue
                 out.append(seg[start:m.end()].strip())
                 start = m.end()
             if seg[start:].strip():

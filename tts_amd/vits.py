@@ -194,12 +194,10 @@ class Vits:
 
     def _tail_eager(self, stats, cum, x_mask, y_lengths, noise_z, g):
         """Everything after the output extent is known (vits.py:1152-1161) at the padded length `self._tail_cfg[0]`:
-        prior expansion (+ the randn draw when no noise is passed), alignment path, flows, waveform decoder (ragged-exact).
-        noise_z / g: tensors or empty tensors."""
+        prior expansion, alignment path, flows, waveform decoder (ragged-exact).  noise_z [B,C,t_pad] is drawn by the
+        caller (outside any capture); g: tensor or empty tensor."""
         t_pad, noise_scale = self._tail_cfg
         B, H = stats.shape[0], self.args.hidden_channels
-        if noise_z.numel() == 0:
-            noise_z = torch.randn(B, H, t_pad, device=stats.device, dtype=torch.float32)
         g = g if g.numel() else None
         pri = ops.expand_prior(stats[:, :H], stats[:, H:], noise_z, cum, x_mask, y_lengths, t_pad, noise_scale, second_copy=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_pad)
@@ -316,11 +314,14 @@ class Vits:
         t_pad = -(-t_dec // 32) * 32
         if (self.use_graphs and not no_graph and (B == 1 or ragged) and self.interpolate_factor is None
                 and self.max_inference_len is None and B * t_pad <= self.graph_tail_max_frames):
-            if noise_z is not None:                       # a pinned draw: zero-extended to the padded length (masked there)
-                nz = torch.zeros(B, H, t_pad, device=dev, dtype=torch.float32)
-                nz[:, :, :t_dec] = noise_z.to(dev, torch.float32)
-            else:
-                nz = torch.empty(0, device=dev)
+            # The draw happens OUTSIDE the captured segment, at the reference's shape [B, C, t_dec] (randn_like(m_p),
+            # vits.py:1155): with a fixed torch seed the audio is then the same whether the tail replays as a graph, runs
+            # eagerly, or was captured earlier (a draw inside the segment would be [B, C, t_pad] and the capture's warm-up
+            # runs would advance the generator).  Zero-extended to the padded length (masked there).
+            if noise_z is None:
+                noise_z = torch.randn(B, H, t_dec, device=dev, dtype=torch.float32)
+            nz = torch.zeros(B, H, t_pad, device=dev, dtype=torch.float32)
+            nz[:, :, :t_dec] = noise_z.to(dev, torch.float32)
             self._tail.enabled = True
             self._tail_cfg = (t_pad, float(self.inference_noise_scale))
             o, attn, z, z_p, m_p, logs_p, y_mask = self._tail(
@@ -362,7 +363,8 @@ class Vits:
             y_mask = ops.sequence_mask(dec_lengths, z.shape[2])
         zd = z if self.max_inference_len is None else z[:, :, : self.max_inference_len].contiguous()
         md = y_mask if self.max_inference_len is None else y_mask[:, : self.max_inference_len].contiguous()
-        # "ragged_exact": every decoder conv treats row b as ending at y_lengths[b] -> row b equals a B=1 run
+        # "ragged_exact": every decoder conv treats row b as ending at y_lengths[b] -> row b equals a B=1 run (bitwise
+        # when both runs take the same conv tile family, fp32 reassociation otherwise: see HifiganGenerator.forward)
         o = self.waveform_decoder.forward(zd, g=g, in_mask=md, lengths=dec_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
         outputs = {
             "model_outputs": o,
