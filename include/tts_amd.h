@@ -49,11 +49,13 @@ int ttsamd_stream_destroy(void *stream);
  * band, `paths` int32 [b,t_x,t_y] must be pre-zeroed by the caller (helpers.py:188) and receives
  * 1 on the chosen path.  t_xs/t_ys int32 [b] (device).  Bit-exact with the reference for every
  * valid input (1 <= t_xs[i] <= t_ys[i]); items with t_x<=0 or t_y<=0 are left untouched.
- * Limit: t_x <= 2048 (TTSAMD_ERR_UNSUPPORTED above). */
+ * No limit on t_x or t_y (core.pyx has none): up to 512 rows a skewed pipeline of DP waves, up to 2048 one DP wave with
+ * the column in registers, beyond that a column-stepping workgroup with its column state in LDS (<= 16 384 rows) or in
+ * the workspace. */
 int ttsamd_maximum_path_c(int32_t *paths, float *values, const int32_t *t_xs, const int32_t *t_ys,
                           int b, int t_x, int t_y, float max_neg_val, void *stream);
 
-/* Scratch bytes needed by ttsamd_maximum_path (direction bit-planes). */
+/* Scratch bytes needed by ttsamd_maximum_path (direction bit-planes; + two columns of state per item for t_x > 16 384). */
 size_t ttsamd_maximum_path_workspace_bytes(int b, int t_x, int t_y);
 
 /* Fused form of helpers.maximum_path_cython (TTS/tts/utils/helpers.py:178-194):
@@ -247,7 +249,9 @@ int ttsamd_channel_norm(const ttsamd_norm_args *args /* host */, void *stream);
  *   all heads (heads_share=True) or NULL when rel_attn_window_size is None (window ignored).
  *   out [B, H*dk, T] contiguous.  QK^T and P.V run on the fp32-input MFMA (exact fp32 products).
  * Limits: dk <= 128 (any value: channels are zero-padded to the next multiple of 32 inside the kernel; multilingual
- * VITS has dk = 98), T <= 1024 (TTSAMD_ERR_UNSUPPORTED beyond). */
+ * VITS has dk = 98).  No limit on T: up to 1024 the [32][T] score strip of a query block lives in LDS; beyond that the
+ * scores are recomputed tile by tile around an online softmax (same results up to the summation order of the softmax
+ * denominator). */
 int ttsamd_rel_attention(float *out, const float *q, const float *k, const float *v, int64_t qkv_bstride,
                          const float *mask, const float *emb_rel_k, const float *emb_rel_v, int window,
                          int batch, int heads, int dk, int t, void *stream);

@@ -98,3 +98,60 @@ def test_mas_logp_and_attention_match_oracle(gpu):
     ref = mas.maximum_path(got.cpu().numpy(), mask, "c")
     assert np.array_equal(attn.cpu().numpy().astype(np.int32), ref)
     assert np.array_equal(attn.sum(1).cpu().numpy(), ym.numpy())      # every valid frame is aligned to exactly one token
+
+
+@pytest.mark.parametrize("shape", [(1, 2100, 2300), (2, 2500, 2560)])
+def test_maximum_path_beyond_2048_rows(gpu, shape):
+    """core.pyx:11-47 has no bound on t_x: beyond 32 row groups the column-stepping kernel takes over — bit-exact like
+    the others, ragged items, mask applied inside, in-place mirror included."""
+    rng = np.random.default_rng(shape[1])
+    v, mask, tx, ty = _problem(rng, *shape)
+    want = mas.maximum_path(v, mask, "c")
+    got = helpers.maximum_path(torch.from_numpy(v).to(gpu), torch.from_numpy(mask).to(gpu))
+    assert np.array_equal(got.cpu().numpy().astype(np.int32), want)
+    vm = v * mask
+    want_v, want_p = vm.copy(), np.zeros(v.shape, np.int32)
+    mas.maximum_path_c(want_p, want_v, tx, ty)
+    dv = torch.from_numpy(vm).to(gpu)
+    dp = torch.zeros(v.shape, dtype=torch.int32, device=gpu)
+    helpers.maximum_path_c(dp, dv, torch.from_numpy(tx).to(gpu), torch.from_numpy(ty).to(gpu))
+    assert np.array_equal(dp.cpu().numpy(), want_p)
+    assert np.array_equal(dv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_any_tx_kernel_on_the_small_cases(gpu, mode):
+    """The any-T_x kernel forced onto the ordinary shapes (TTSAMD_MAS_FORCE_BIG=1: column state in LDS, =2: in the
+    workspace, the T_x > 16 384 arrangement) in a fresh process: same bit-exact cases, ties, ragged items, the in-place mirror."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from oracle import mas
+from tts_amd import helpers
+from tests.test_mas_gpu import _problem
+gpu = torch.device("cuda:0")
+for shape in [(4, 17, 40), (3, 64, 64), (2, 65, 200), (5, 1, 9), (2, 7, 7), (1, 130, 257), (3, 1, 1), (2, 300, 641), (8, 257, 770)]:
+    for ties in (False, True):
+        rng = np.random.default_rng(sum(shape) * 2 + ties)
+        v, mask, tx, ty = _problem(rng, *shape, ties=ties)
+        want = mas.maximum_path(v, mask, "c")
+        got = helpers.maximum_path(torch.from_numpy(v).to(gpu), torch.from_numpy(mask).to(gpu))
+        assert np.array_equal(got.cpu().numpy().astype(np.int32), want), (shape, ties)
+    vm = v * mask
+    want_v, want_p = vm.copy(), np.zeros(v.shape, np.int32)
+    mas.maximum_path_c(want_p, want_v, tx, ty)
+    dv = torch.from_numpy(vm).to(gpu)
+    dp = torch.zeros(v.shape, dtype=torch.int32, device=gpu)
+    helpers.maximum_path_c(dp, dv, torch.from_numpy(tx).to(gpu), torch.from_numpy(ty).to(gpu))
+    assert np.array_equal(dp.cpu().numpy(), want_p), shape
+    assert np.array_equal(dv.cpu().numpy().view(np.uint32), want_v.view(np.uint32)), shape
+print("any-T_x kernel OK")
+''' % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280,
+                       env=dict(os.environ, TTSAMD_MAS_FORCE_BIG=mode), cwd=root)
+    assert p.returncode == 0 and "any-T_x kernel OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

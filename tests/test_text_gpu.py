@@ -29,7 +29,8 @@ def _mask(lengths, T):
     return (torch.arange(T)[None, :] < torch.tensor(lengths)[:, None]).float()
 
 
-@pytest.mark.parametrize("C,T,eps", [(192, 257, 1e-5), (256, 70, 1e-4), (80, 33, 1e-4), (384, 65, 1e-5)])
+@pytest.mark.parametrize("C,T,eps", [(192, 257, 1e-5), (256, 70, 1e-4), (80, 33, 1e-4), (384, 65, 1e-5), (520, 90, 1e-5),
+                                     (1024, 2100, 1e-5)])
 def test_channel_norm_plain_and_residual(gpu, C, T, eps):
     g = _g(C + T)
     B = 2
@@ -62,7 +63,8 @@ def test_dds_conv_matches_oracle(gpu):
 
 
 @pytest.mark.parametrize("window,T,lens,H", [(4, 257, [257, 200], 192), (None, 64, [64, 31], 192), (4, 3, [3, 2], 192),
-                                             (4, 40, [40, 1], 192), (4, 70, [70, 33], 196), (None, 50, [50, 9], 20)])
+                                             (4, 40, [40, 1], 192), (4, 70, [70, 33], 196), (None, 50, [50, 9], 20),
+                                             (4, 1100, [1100, 700], 192), (None, 1300, [1290, 1300], 64)])
 def test_rel_attention_matches_oracle(gpu, window, T, lens, H):
     """H=196 -> head size 98 (multilingual VITS: 192 + 4 language channels), H=20 -> head size 10: sizes that are not
     multiples of the 32-wide MFMA tile run zero-padded inside the kernel."""
@@ -90,6 +92,26 @@ def test_rel_attention_matches_oracle(gpu, window, T, lens, H):
     assert torch.isfinite(out).all()
     for b, n in enumerate(lens):
         assert _rel(out[b, :, :n], want[b, :, :n]) < TOL
+
+
+def test_rel_attention_long_kernel_on_the_short_cases(gpu):
+    """The any-T attention kernel (online softmax over key tiles; what T > 1024 takes) forced onto the ordinary shapes in a
+    fresh process (TTSAMD_ATT_FORCE_LONG=1): windows, ragged masks, T < 5, head sizes that are not multiples of 32."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from tests import test_text_gpu as t\n"
+            "gpu = torch.device('cuda:0')\n"
+            "for c in [(4, 257, [257, 200], 192), (None, 64, [64, 31], 192), (4, 3, [3, 2], 192), (4, 40, [40, 1], 192),\n"
+            "          (4, 70, [70, 33], 196), (None, 50, [50, 9], 20), (4, 129, [129, 128], 192)]:\n"
+            "    t.test_rel_attention_matches_oracle(gpu, *c)\n"
+            "print('long attention OK')\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280,
+                       env=dict(os.environ, TTSAMD_ATT_FORCE_LONG="1"), cwd=root)
+    assert p.returncode == 0 and "long attention OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 
 def test_text_encoder_matches_oracle(gpu):

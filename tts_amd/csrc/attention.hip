@@ -17,6 +17,8 @@
 //   4. band of relative-value terms added in registers, store.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace ttsamd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -232,6 +234,202 @@ __global__ __launch_bounds__(kAttThreads, (DK <= 96 ? 3 : 2)) void rel_attention
     ATT_STAMP(5);
 }
 
+
+// ---- any T (T > 1024: the [32][T] score strip no longer fits in LDS) ---------------------------------------------------
+// transformer.py:118-163 has no bound on T.  Same block = 32 query rows of one (batch, head), same fp32 MFMA contractions,
+// but the scores are never held for the whole row: pass 1 walks the key tiles (4 per iteration, one per wave) and keeps
+// only the running row maximum and sum (online softmax), pass 2 recomputes each score tile, turns it into probabilities
+// p = exp(s - max) / sum in four [32][33] LDS tiles, and the channel waves consume those for O^T += V^T P^T and the
+// relative-value band.  QK^T is computed twice — a fallback for long sequences, not the fast path.  Differs from the strip
+// kernel only in the summation order of the softmax denominator.
+template <int DK>
+__global__ __launch_bounds__(kAttThreads, 2) void rel_attention_long_kernel(
+    float *__restrict__ out, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, long qkv_bstride, const float *__restrict__ mask,
+    const float *__restrict__ emb_k, const float *__restrict__ emb_v, int window, int heads, int dk, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kP = 33;
+    const int ntiles = (T + 31) / 32;
+    const int niter = (ntiles + 3) / 4;
+    const int nrel = emb_k ? 2 * window + 1 : 0;
+    float *Pt = smem;                          // [4 waves][32][33] score / probability tiles
+    float *St = Pt + 4 * 32 * kP;              // [2][4][32] per-wave row maxima / sums, then [2][32] merged
+    float *EkL = St + 2 * 4 * 32;              // [nrel][DK]
+    float *EvL = EkL + nrel * DK;              // [nrel][DK]
+    float *Dk = EvL + nrel * DK;               // [nrel][32] relative-key logits of this block's rows (already / sqrt(dk))
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    const int j = lane & 31;
+    const int t0 = blockIdx.x * kAttRows;
+    const int head = blockIdx.y;
+    const int b = blockIdx.z;
+    const long hoff = (long)b * qkv_bstride + (long)head * dk * T;
+    const float *qh = q + hoff, *kh = k + hoff, *vh = v + hoff;
+    const float *mrow = mask ? mask + (long)b * T : nullptr;
+    const float scale = sqrtf((float)dk);
+    float *Pw = Pt + wave * 32 * kP;
+
+    for (int e = tid; e < nrel * DK; e += kAttThreads) {
+        const int r = e / DK, c = e - r * DK;
+        EkL[e] = (c < dk) ? emb_k[r * dk + c] : 0.f;
+        EvL[e] = (c < dk) ? emb_v[r * dk + c] : 0.f;
+    }
+    const long slab = (long)dk * T * 4;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(qh, slab), rk = make_rsrc(kh, slab), rv = make_rsrc(vh, slab);
+    float aq[DK / 2];
+    {
+        const bool qv = (t0 + j) < T;
+#pragma unroll
+        for (int ks = 0; ks < DK / 2; ++ks) {
+            const int ch = 2 * ks + hh;
+            aq[ks] = ld_buf(rq, (qv && ch < dk) ? (int)(((long)ch * T + t0 + j) * 4) : kBufOob, 0);
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < nrel; r += 4) {
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DK / 2; ++ks) part += aq[ks] * EkL[r * DK + 2 * ks + hh];
+        const float dot = part + __shfl_xor(part, 32);
+        if (hh == 0) Dk[r * 32 + j] = dot / scale;
+    }
+    const float mi = (mrow && t0 + j < T) ? mrow[t0 + j] : 1.f;     // query-row mask of row j (both half-waves)
+    __syncthreads();
+
+    // masked scores of key tile kt into this wave's LDS tile (rows = queries, columns = keys of the tile)
+    auto score_tile = [&](int kt) {
+        const int col = kt * 32 + j;
+        const bool kv = (kt < ntiles) && col < T;
+        float bk[DK / 2];
+#pragma unroll
+        for (int ks = 0; ks < DK / 2; ++ks) {
+            const int ch = 2 * ks + hh;
+            bk[ks] = ld_buf(rk, (kv && ch < dk) ? (int)(((long)ch * T + col) * 4) : kBufOob, 0);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[ks], bk[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2) + 4 * hh) * kP + j] = acc[r] / scale;
+    };
+    // band + mask fill on the wave's tile; lane (j, hh): row j, columns 16hh..16hh+15.  Returns nothing; tile stays in LDS.
+    auto band_mask = [&](int kt) {
+        for (int r = hh; r < nrel; r += 2) {
+            const int tj = t0 + j + r - window;
+            if (t0 + j < T && tj >= kt * 32 && tj < kt * 32 + 32 && tj < T) Pw[j * kP + tj - kt * 32] += Dk[r * 32 + j];
+        }
+    };
+
+    // ---- pass 1: running row maximum / sum ------------------------------------------------------------------------------
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int it = 0; it < niter; ++it) {
+        const int kt = it * 4 + wave;
+        score_tile(kt);
+        __syncthreads();
+        band_mask(kt);
+        __syncthreads();
+        if (kt < ntiles) {
+            float sv[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int col = kt * 32 + 16 * hh + c;
+                float x = Pw[j * kP + 16 * hh + c];
+                if (mrow && (mi == 0.f || mrow[col < T ? col : 0] == 0.f)) x = -1e4f;
+                sv[c] = (col < T) ? x : -INFINITY;
+                tmax = fmaxf(tmax, sv[c]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);         // finite: column kt*32 < T is valid
+            float ps = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) ps += expf(sv[c] - m_new);
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * expf(m_run - m_new) + ps;       // first tile: 0 * exp(-inf) = 0
+            m_run = m_new;
+        }
+        __syncthreads();
+    }
+    if (hh == 0) {
+        St[wave * 32 + j] = m_run;
+        St[4 * 32 + wave * 32 + j] = l_run;
+    }
+    __syncthreads();
+    float m_tot = St[j];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m_tot = fmaxf(m_tot, St[w * 32 + j]);
+    float l_tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float mw = St[w * 32 + j];
+        if (mw != -INFINITY) l_tot += St[4 * 32 + w * 32 + j] * expf(mw - m_tot);
+    }
+    __syncthreads();
+
+    // ---- pass 2: probabilities tile by tile, O^T += V^T P^T, relative-value band ----------------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rel[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rel[r] = 0.f;
+    const bool mma_wave = wave < DK / 32;
+    const int n = wave * 32 + j;
+    const int ti = t0 + j;
+    for (int it = 0; it < niter; ++it) {
+        const int kt = it * 4 + wave;
+        score_tile(kt);
+        __syncthreads();
+        band_mask(kt);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int col = kt * 32 + 16 * hh + c;
+            float x = Pw[j * kP + 16 * hh + c];
+            if (mrow && (mi == 0.f || mrow[col < T ? col : 0] == 0.f)) x = -1e4f;
+            Pw[j * kP + 16 * hh + c] = (kt < ntiles && col < T) ? expf(x - m_tot) / l_tot : 0.f;
+        }
+        __syncthreads();
+        if (mma_wave) {
+            for (int w = 0; w < 4; ++w) {
+                const int kw = it * 4 + w;
+                if (kw >= ntiles) break;
+                const float *P = Pt + w * 32 * kP;
+                float vv[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const int col = kw * 32 + 16 * hh + m;
+                    vv[m] = ld_buf(rv, (n < dk && col < T) ? (int)(((long)n * T + col) * 4) : kBufOob, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[ks], P[j * kP + 16 * hh + ks], acc, 0, 0, 0);
+                for (int d = 0; d < nrel; ++d) {
+                    const int tj = ti + d - window;
+                    if (tj >= kw * 32 && tj < kw * 32 + 32 && tj < T) {
+                        const float p = P[j * kP + tj - kw * 32];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rel[r] += p * EvL[d * DK + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (mma_wave && ti < T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (nn < dk) out[((long)b * heads * dk + (long)head * dk + nn) * T + ti] = acc[r] + rel[r];
+        }
+    }
+}
+
 template <int DK>
 static int launch_att(float *out, const float *q, const float *k, const float *v, long bstride, const float *mask,
                       const float *ek, const float *ev, int window, int batch, int heads, int dk, int T, hipStream_t st)
@@ -240,9 +438,21 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
     const int pitch = ntiles * 32 + 1;
     const int nrel = ek ? 2 * window + 1 : 0;
     const size_t lds = (size_t)(kAttRows * pitch + ntiles * 32 + 2 * nrel * DK) * sizeof(float);
-    if (lds > 160 * 1024) {
-        set_error("rel_attention: T=%d with window=%d needs %zu bytes of LDS", T, window, lds);
-        return TTSAMD_ERR_UNSUPPORTED;
+    static const bool force_long = getenv("TTSAMD_ATT_FORCE_LONG") != nullptr;     // test hook (tests/test_text_gpu.py)
+    if (lds > 160 * 1024 || T > 1024 || force_long) {
+        // the score strip does not fit: tile-by-tile online-softmax kernel (any T)
+        const size_t lds2 = (size_t)(4 * 32 * 33 + 2 * 4 * 32 + 2 * nrel * DK + nrel * 32) * sizeof(float);
+        if (lds2 > 160 * 1024) {
+            set_error("rel_attention: window=%d needs %zu bytes of LDS", window, lds2);
+            return TTSAMD_ERR_UNSUPPORTED;
+        }
+        auto kl = rel_attention_long_kernel<DK>;
+        static std::atomic<unsigned long long> lds_attr_long{0};
+        TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kl), (int)(160 * 1024), lds_attr_long));
+        hipLaunchKernelGGL(kl, dim3(ntiles, heads, batch), dim3(kAttThreads), lds2, st, out, q, k, v, bstride, mask, ek, ev,
+                           window, heads, dk, T);
+        TTSAMD_LAUNCH_CHECK();
+        return TTSAMD_OK;
     }
     auto kern = rel_attention_kernel<DK>;
     static std::atomic<unsigned long long> lds_attr_done{0};   // per device, see ensure_dynamic_lds
@@ -272,8 +482,8 @@ extern "C" int ttsamd_rel_attention(float *out, const float *q, const float *k, 
     TTSAMD_CHECK_ARG((emb_rel_k == nullptr) == (emb_rel_v == nullptr), "rel_attention: need both or neither rel embeddings");
     TTSAMD_CHECK_ARG(!emb_rel_k || window >= 0, "rel_attention: bad window");
     if (batch == 0 || t == 0) return TTSAMD_OK;
-    if (t > 1024 || dk > 128 || batch > 65535 || heads > 65535) {
-        set_error("rel_attention: unsupported shape (dk=%d <= 128, T=%d <= 1024)", dk, t);
+    if (dk > 128 || batch > 65535 || heads > 65535 || (int64_t)dk * t * 4 >= 0x7FFFFFF0ll) {
+        set_error("rel_attention: unsupported shape (dk=%d <= 128, one head's [dk, T] slab < 2 GiB)", dk);
         return TTSAMD_ERR_UNSUPPORTED;
     }
     hipStream_t st = as_stream(stream);

@@ -305,6 +305,74 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw_kernel(
     }
 }
 
+
+// ---- forward DP, any T_x (T_x > 2048) ----------------------------------------------------------------
+// The kernels above keep a [T_x x 32]-column tile (and the previous column) on the CU; core.pyx:11-47 has no bound on t_x, so
+// beyond 32 row groups this kernel takes over.  One workgroup of 16 waves per item; the previous column lives in a
+// double-buffered column array — in LDS up to 16 384 rows, in the caller's workspace (global memory, L1/L2 resident) beyond —
+// and the block steps column by column with one barrier per column.  A thread's cell of column y+1 is requested before the
+// barrier of column y (its row-major neighbour lines are re-used for 32 columns from L1/L2).  Same single fp32 add per
+// cell => bit-exact; the direction bit-planes have the layout the backtrack kernel reads.
+constexpr int kMasBigThreads = 1024;
+constexpr int kMasBigLdsRows = 16384;
+
+__global__ __launch_bounds__(kMasBigThreads) void mas_forward_big_kernel(
+    const float *in_values, const float *__restrict__ mask, float *dp_values, unsigned long long *__restrict__ dirs,
+    float *gcol /* [B][2][Tx] or nullptr (LDS) */, const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty,
+    int R, float neg)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int t_x = min(t_xs[b], Tx);
+    const int t_y = min(t_ys[b], Ty);
+    const long base = (long)b * Tx * Ty;
+    float *col = gcol ? gcol + (long)b * 2 * Tx : smem;        // generic pointer: LDS or global
+    const bool need_copy = (dp_values != nullptr);
+    const int nrow = R * 64;                                    // rows swept (whole 64-row groups: ballots are per group)
+    // When the caller wants the full value*mask matrix back (dp_values_out != values_in), cells outside the band are copied.
+    const bool copy_all = need_copy && (dp_values != in_values || mask != nullptr);
+    if (t_x <= 0 || t_y <= 0) {
+        if (copy_all)
+            for (long i = tid; i < (long)Tx * Ty; i += kMasBigThreads) dp_values[base + i] = mask ? in_values[base + i] * mask[base + i] : in_values[base + i];
+        return;
+    }
+    for (int x = tid; x < Tx; x += kMasBigThreads) col[x] = 0.f;
+    __syncthreads();
+    const int y_stop = copy_all ? Ty : t_y;
+    for (int y = 0; y < y_stop; ++y) {
+        const float *cp = col + (y & 1) * Tx;                   // column y-1
+        float *cn = col + ((y + 1) & 1) * Tx;                   // column y
+        const int x_lo = max(0, t_x + y - t_y);
+        const int x_hi = min(t_x, y + 1);
+        const bool dp_col = y < t_y;
+        for (int x = tid; x < nrow; x += kMasBigThreads) {
+            const bool xin = x < Tx;
+            float c = 0.f;
+            if (xin) {
+                const long o = base + (long)x * Ty + y;
+                c = mask ? in_values[o] * mask[o] : in_values[o];
+            }
+            const float prev = xin ? cp[x] : 0.f;
+            const float up = (x >= 1 && x - 1 < Tx) ? cp[x - 1] : 0.f;
+            if (dp_col && y > 0) {                               // direction bit-plane of column y-1
+                const unsigned long long bits = __ballot(xin && x >= 1 && prev < up);
+                if ((tid & 63) == 0) dirs[((long)b * Ty + (y - 1)) * R + (x >> 6)] = bits;
+            }
+            const float v_cur = (x == y) ? neg : prev;
+            const float v_prev = (x == 0) ? (y == 0 ? 0.f : neg) : up;
+            const float nv = fmaxf(v_cur, v_prev) + c;
+            const bool inb = dp_col && (x >= x_lo) && (x < x_hi);
+            const float keep = inb ? nv : c;
+            if (xin) {
+                cn[x] = keep;
+                if (need_copy && (inb || copy_all)) dp_values[base + (long)x * Ty + y] = keep;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- backtrack -------------------------------------------------------------------------------
 // Backtrack: wave 0 walks the columns from the last to the first in 64-column chunks (the index chain is serial:
 // core.pyx:34-37); per chunk every lane holds a 64-row window of its column's direction bit-plane around the index the
@@ -444,11 +512,26 @@ static int launch_forward(const float *in, const float *mask, float *dp, unsigne
 
 using namespace ttsamd;
 
+// test hooks: TTSAMD_MAS_FORCE_BIG=1 routes every shape through the any-T_x kernel, =2 also puts its column state in global
+// memory (what T_x > 16 384 does) — tests/test_mas_gpu.py runs the bit-exactness cases through both
+static int mas_force_big()
+{
+    static const int v = getenv("TTSAMD_MAS_FORCE_BIG") ? atoi(getenv("TTSAMD_MAS_FORCE_BIG")) : 0;
+    return v;
+}
+
+static size_t mas_dirs_bytes(int b, int t_x, int t_y)
+{
+    const size_t R = (size_t)(t_x + 63) / 64;
+    return (size_t)b * (size_t)t_y * R * sizeof(unsigned long long);
+}
+
 extern "C" size_t ttsamd_maximum_path_workspace_bytes(int b, int t_x, int t_y)
 {
     if (b <= 0 || t_x <= 0 || t_y <= 0) return 0;
-    const size_t R = (size_t)(t_x + 63) / 64;
-    return (size_t)b * (size_t)t_y * R * sizeof(unsigned long long);
+    // direction bit-planes (+ beyond 16 384 rows the any-T_x kernel's double-buffered column state)
+    const bool gstate = t_x > kMasBigLdsRows || mas_force_big() == 2;
+    return ((mas_dirs_bytes(b, t_x, t_y) + 15) & ~(size_t)15) + (gstate ? (size_t)b * 2 * (size_t)t_x * sizeof(float) : 0);
 }
 
 extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const float *mask,
@@ -460,10 +543,6 @@ extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const fl
     if (b == 0 || t_x == 0 || t_y == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(paths && values_in && t_xs && t_ys, "maximum_path: NULL pointer");
     const int R = (t_x + 63) / 64;
-    if (R > 32) {
-        set_error("maximum_path: t_x=%d exceeds the supported maximum of 2048", t_x);
-        return TTSAMD_ERR_UNSUPPORTED;
-    }
     const size_t need = ttsamd_maximum_path_workspace_bytes(b, t_x, t_y);
     TTSAMD_CHECK_ARG(workspace && workspace_bytes >= need, "maximum_path: workspace too small (%zu < %zu)",
                      workspace_bytes, need);
@@ -471,7 +550,22 @@ extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const fl
     auto *dirs = reinterpret_cast<unsigned long long *>(workspace);
     int rc;
     static const bool single_wave = getenv("TTSAMD_MAS_SINGLE_WAVE") != nullptr;   // A/B switch: the one-DP-wave kernel
-    if (R <= 8 && !single_wave) {
+    const int force_big = mas_force_big();
+    if (R > 32 || force_big) {
+        const bool gstate = t_x > kMasBigLdsRows || force_big == 2;
+        float *gcol = nullptr;
+        if (gstate) {
+            const size_t off = (mas_dirs_bytes(b, t_x, t_y) + 15) & ~(size_t)15;
+            gcol = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + off);
+        }
+        const size_t lds = gstate ? 0 : (size_t)2 * t_x * sizeof(float);
+        static std::atomic<unsigned long long> lds_attr_done{0};
+        TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_big_kernel), 2 * kMasBigLdsRows * (int)sizeof(float), lds_attr_done));
+        hipLaunchKernelGGL(mas_forward_big_kernel, dim3(b), dim3(kMasBigThreads), lds, st, values_in, mask, dp_values_out, dirs, gcol,
+                           t_xs, t_ys, t_x, t_y, R, max_neg_val);
+        rc = (hipGetLastError() == hipSuccess) ? TTSAMD_OK : TTSAMD_ERR_HIP;
+        if (rc != TTSAMD_OK) set_error("maximum_path: launch of the any-T_x kernel failed");
+    } else if (R <= 8 && !single_wave) {
         rc = launch_forward_mw(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
     } else
 #define TTSAMD_MAS_EXACT(n) \

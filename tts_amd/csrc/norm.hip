@@ -195,6 +195,72 @@ __global__ __launch_bounds__(1024) void channel_norm_small_kernel(const ttsamd_n
     }
 }
 
+// Any channel count (C > 512: no thread can keep its channels in registers): the same 64-column x 16-group tile, but the
+// value of a (channel, column) — input, depthwise prologue, pre-residual — is re-evaluated in each of the three passes
+// (mean, variance, apply).  Same formulas and the same fixed-order reductions as channel_norm_kernel; a fallback, not a
+// fast path (normalization.py:5-53 has no bound on `channels`).
+__global__ __launch_bounds__(64 * 16) void channel_norm_any_kernel(const ttsamd_norm_args a)
+{
+    constexpr int kG = 16;
+    __shared__ float red[kG][64];
+    const int lane = threadIdx.x;
+    const int grp = threadIdx.y;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + lane;
+    const bool tv = t < a.t;
+    const float *xb = a.x + (long)b * a.x_bstride;
+    const float *im = a.in_mask ? a.in_mask + (long)b * a.t : nullptr;
+    auto value = [&](int c) {
+        float u;
+        if (a.dw_w) {
+            u = a.dw_bias ? a.dw_bias[c] : 0.f;
+            const int half = (a.dw_kernel - 1) / 2;
+            for (int k = 0; k < a.dw_kernel; ++k) {
+                const int tt = t + (k - half) * a.dw_dilation;
+                if (tt >= 0 && tt < a.t) {
+                    float xv = xb[(long)c * a.x_rstride + tt];
+                    if (im) xv *= im[tt];
+                    u += a.dw_w[c * a.dw_kernel + k] * xv;
+                }
+            }
+        } else {
+            u = xb[(long)c * a.x_rstride + t];
+        }
+        if (a.pre_res) u += a.pre_res[(long)b * a.pre_bstride + (long)c * a.pre_rstride + t];
+        return u;
+    };
+    float s = 0.f;
+    if (tv)
+        for (int c = grp; c < a.c; c += kG) s += value(c);
+    red[grp][lane] = s;
+    __syncthreads();
+    float tot = red[0][lane];
+    for (int g2 = 1; g2 < kG; ++g2) tot += red[g2][lane];
+    const float mean = tot / (float)a.c;
+    __syncthreads();
+    float q = 0.f;
+    if (tv)
+        for (int c = grp; c < a.c; c += kG) {
+            const float d = value(c) - mean;
+            q += d * d;
+        }
+    red[grp][lane] = q;
+    __syncthreads();
+    float tot2 = red[0][lane];
+    for (int g2 = 1; g2 < kG; ++g2) tot2 += red[g2][lane];
+    const float rstd = 1.0f / sqrtf(tot2 / (float)a.c + a.eps);
+    const float om = (a.out_mask && tv) ? a.out_mask[(long)b * a.t + t] : 1.f;
+    if (tv)
+        for (int c = grp; c < a.c; c += kG) {
+            float o = (value(c) - mean) * rstd * a.gamma[c] + a.beta[c];
+            if (a.act == TTSAMD_ACT_RELU) o = fmaxf(o, 0.f);
+            else if (a.act == TTSAMD_ACT_GELU) o = o * 0.5f * (1.0f + erff(o * 0.70710678118654752440f));
+            if (a.post_res) o = a.post_res[(long)b * a.post_bstride + (long)c * a.post_rstride + t] + o;
+            if (a.out_mask) o *= om;
+            a.y[(long)b * a.y_bstride + (long)c * a.y_rstride + t] = o;
+        }
+}
+
 }  // namespace ttsamd
 using namespace ttsamd;
 
@@ -208,13 +274,15 @@ extern "C" int ttsamd_channel_norm(const ttsamd_norm_args *args, void *stream)
                      "channel_norm: depthwise prologue needs an odd kernel and dilation > 0");
     TTSAMD_CHECK_ARG(a.act == TTSAMD_ACT_NONE || a.act == TTSAMD_ACT_RELU || a.act == TTSAMD_ACT_GELU,
                      "channel_norm: bad act %d", a.act);
-    if (a.c > 512) {
-        set_error("channel_norm: C=%d > 512 unsupported", a.c);
-        return TTSAMD_ERR_UNSUPPORTED;
-    }
     if (a.batch == 0 || a.t == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(a.batch <= 65535, "channel_norm: batch > 65535");
     hipStream_t st = as_stream(stream);
+    if (a.c > 512) {   // y must not alias x here: the passes re-read x (the register-resident kernels read it once)
+        TTSAMD_CHECK_ARG(a.y != a.x, "channel_norm: C > 512 cannot run in place");
+        hipLaunchKernelGGL(channel_norm_any_kernel, dim3((a.t + 63) / 64, a.batch), dim3(64, 16), 0, st, a);
+        TTSAMD_LAUNCH_CHECK();
+        return TTSAMD_OK;
+    }
     // text-length tensors: 16-column tiles (chosen by T alone, never by the batch: row b of a batch stays bitwise the B = 1 run)
     if (a.t <= kNormSmallT) {
         const dim3 sgrid((a.t + 15) / 16, a.batch);
