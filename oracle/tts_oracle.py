@@ -792,6 +792,40 @@ def mas_logp(z, m, logs, glow_order=False):
     return (logp1 + logp2 + logp3 + logp4) if glow_order else (logp2 + logp3 + logp1 + logp4)
 
 
+def vits_forward_mas(z_p, m_p, logs_p, x_mask, y_mask, maximum_path, use_sdp=True):
+    """Vits.forward_mas, vits.py:909-936 — the alignment half (the duration LOSS of :921-941 is training code):
+    attn_mask, logp, `attn = maximum_path(logp, attn_mask.squeeze(1)).unsqueeze(1)`, `attn_durations = attn.sum(3)` and,
+    for the deterministic predictor, `attn_log_durations = log(attn_durations + 1e-6) * x_mask`.
+    x_mask [B,1,T_x], y_mask [B,1,T_y]; maximum_path(value [B,T_x,T_y], mask) -> path (test infrastructure: the C oracle)."""
+    attn_mask = torch.unsqueeze(x_mask, -1) * torch.unsqueeze(y_mask, 2)
+    logp = mas_logp(z_p, m_p, logs_p, glow_order=False)
+    attn = maximum_path(logp, attn_mask.squeeze(1)).unsqueeze(1)
+    out = {"logp": logp, "attn": attn, "attn_durations": attn.sum(3)}
+    if not use_sdp:
+        out["attn_log_durations"] = torch.log(out["attn_durations"] + 1e-6) * x_mask
+    return out
+
+
+def vits_forward_align(sd, tokens, x_lengths, y, y_lengths, maximum_path, args=None, noise=None, g=None, lang_emb=None):
+    """The alignment pass of Vits.forward, vits.py:1018-1031: text encoder -> posterior encoder -> flow (forward) ->
+    forward_mas -> prior expanded along the path (`einsum("klmn, kjm -> kjn", attn, m_p)`).  y [B, C_spec, T_y]."""
+    a = dict(VITS_DEFAULTS)
+    a.update(args or {})
+    h = a["hidden_channels"]
+    x, m_p, logs_p, x_mask = text_encoder(sd, "text_encoder.", tokens, x_lengths, a, lang_emb=lang_emb)
+    z, m_q, logs_q, y_mask = posterior_encoder(sd, "posterior_encoder.", y, y_lengths, h, a.get("kernel_size_posterior_encoder", 5),
+                                               a.get("dilation_rate_posterior_encoder", 1),
+                                               a.get("num_layers_posterior_encoder", 16), g=g, noise=noise)
+    flow_cfg = dict(hidden=h, kernel_size=a["kernel_size_flow"], dilation_rate=a["dilation_rate_flow"],
+                    num_layers=a["num_layers_flow"])
+    z_p = residual_coupling_blocks_forward(sd, "flow.", z, y_mask, flow_cfg, g=g)
+    out = vits_forward_mas(z_p, m_p, logs_p, x_mask, y_mask, maximum_path, use_sdp=a.get("use_sdp", True))
+    out.update(x=x, z=z, z_p=z_p, m_q=m_q, logs_q=logs_q, x_mask=x_mask, y_mask=y_mask,
+               m_p=torch.einsum("klmn, kjm -> kjn", [out["attn"], m_p]),
+               logs_p=torch.einsum("klmn, kjm -> kjn", [out["attn"], logs_p]))
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # seeded weight factory: lives in the product package (bench.py needs synthetic checkpoints too and may not
 # import oracle/); re-exported here for the tests.

@@ -82,3 +82,39 @@ def test_oracle_handle_chunks_matches_reference(overlap):
         cb, pb, ob = O.xtts_handle_chunks(wb, pb, ob, overlap)
         assert torch.equal(ca, cb) and torch.equal(pa, pb)
         assert (oa is None) == (ob is None) and (oa is None or torch.equal(oa, ob))
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree absent (GPU box)")
+def test_oracle_forward_mas_matches_reference_method():
+    """oracle.vits_forward_mas against the body of the reference's `Vits.forward_mas` (vits.py:909-942) compiled straight
+    from the reference file (the class itself needs coqpit / trainer to import) with a stub `self` whose duration predictor
+    returns zeros — the alignment half is all that is restated — and the reference's own `maximum_path`."""
+    import ast
+    import math
+    import types
+
+    from oracle import mas
+    from oracle import tts_oracle as O
+
+    src = open(os.path.join(ref_shim.REF_ROOT, "TTS/tts/models/vits.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "forward_mas")
+    ref_helpers = ref_shim.ref("TTS.tts.utils.helpers")
+    ns = {"torch": torch, "math": math, "maximum_path": ref_helpers.maximum_path}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "vits.forward_mas", "exec"), ns)  # noqa: S102
+    stub = types.SimpleNamespace(args=types.SimpleNamespace(use_sdp=True, detach_dp_input=True),
+                                 duration_predictor=lambda x, x_mask, *a, **k: torch.zeros(x.shape[0]))
+    g = torch.Generator().manual_seed(4)
+    B, C, Tx, Ty = 3, 16, 11, 37
+    z_p = torch.randn(B, C, Ty, generator=g)
+    m_p = torch.randn(B, C, Tx, generator=g)
+    logs_p = 0.3 * torch.randn(B, C, Tx, generator=g)
+    x_mask = O.sequence_mask(torch.tensor([11, 7, 3]), Tx).unsqueeze(1).float()
+    y_mask = O.sequence_mask(torch.tensor([37, 20, 9]), Ty).unsqueeze(1).float()
+    _, attn = ns["forward_mas"](stub, {}, z_p, m_p, logs_p, torch.zeros(B, C, Tx), x_mask, y_mask, None, None)
+
+    def cpu_mas(value, mask):
+        return torch.from_numpy(mas.maximum_path(value.numpy(), mask.numpy(), "c")).to(value.dtype)
+
+    out = O.vits_forward_mas(z_p, m_p, logs_p, x_mask, y_mask, cpu_mas)
+    assert torch.equal(out["attn"], attn)
+    assert torch.equal(out["attn_durations"], attn.sum(3))

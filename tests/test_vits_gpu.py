@@ -261,6 +261,51 @@ def test_vits_voice_conversion_matches_reference_golden(gpu):
     assert rms < 1e-4 and rel < 1e-5, (rms, rel)
 
 
+def test_vits_forward_mas_and_align_match_oracle(gpu):
+    """Vits.forward_mas (vits.py:909-936) and the alignment pass of Vits.forward (:1018-1031) as ONE device-resident method:
+    text encoder -> posterior encoder -> flow forward -> logp -> MAS -> durations -> prior expanded along the path.
+    Float stages to fp32 tolerance against the oracle; the path is bit-exact with the CPU MAS run on the SAME logp (MAS is
+    exact given its input) and equals the oracle's own path; durations and expansion follow exactly."""
+    from oracle import mas
+    from tests.golden import cases
+    from tts_amd import helpers
+
+    def cpu_mas(value, mask):
+        return torch.from_numpy(mas.maximum_path(value.numpy(), mask.numpy(), "c")).float()
+
+    args = dict(cases.VITS_VC, speaker_embedding_channels=24)
+    sd = W.make_vits_state(cases.VITS_VC, seed=556, with_posterior=True)
+    m = _model(args, sd, gpu)
+    g = torch.Generator().manual_seed(21)
+    B, Tx, Ty = 3, 19, 57
+    x = torch.randint(0, 100, (B, Tx), generator=g)
+    xl = torch.tensor([19, 12, 5])
+    y = torch.randn(B, 65, Ty, generator=g)
+    yl = torch.tensor([57, 40, 11])
+    noise = torch.randn(B, 192, Ty, generator=g)
+    sid = torch.tensor([0, 2, 1])
+    want = O.vits_forward_align(sd, x, xl, y, yl, cpu_mas, args, noise=noise, g=O.vits_speaker_g(sd, speaker_ids=sid))
+    got = m.align(x.to(gpu), xl.to(gpu), y.to(gpu), yl.to(gpu), {"speaker_ids": sid}, noise=noise.to(gpu))
+    for k in ("z", "z_p"):
+        assert _errs(got[k], want[k])[1] < 1e-5, k
+    # logp on the device vs the oracle's, then the path: exact on the same logp, and the same path as the oracle's
+    logp = helpers.mas_logp(got["z_p"], *[t.contiguous() for t in m.text_encoder(x.to(gpu), got["x_mask"][:, 0])[1].split(192, 1)])
+    assert _errs(logp, want["logp"])[1] < 1e-5
+    mask = (got["x_mask"][:, 0, :, None] * got["y_mask"][:, 0, None, :]).cpu()
+    assert torch.equal(got["alignments"][:, 0].cpu(), cpu_mas(logp.cpu(), mask))
+    assert torch.equal(got["alignments"].cpu(), want["attn"])
+    assert torch.equal(got["attn_durations"].cpu(), want["attn_durations"])
+    assert torch.equal(got["attn_durations"].sum((1, 2)).cpu().long(), yl)           # every valid frame owned by one token
+    for k in ("m_p", "logs_p"):                                                       # gather == the 0/1 matmul
+        assert _errs(got[k], want[k])[1] < 1e-5, k
+    # forward_mas alone, reference signature: (outputs, attn)
+    out, attn = m.forward_mas({}, want["z_p"].to(gpu), *[t.contiguous().to(gpu) for t in
+                                                          O.text_encoder(sd, "text_encoder.", x, xl, dict(O.VITS_DEFAULTS, **args))[1:3]],
+                              None, got["x_mask"], got["y_mask"])
+    assert attn.shape == (B, 1, Tx, Ty) and torch.equal(attn.cpu(), want["attn"])
+    assert torch.equal(out["attn_durations"].cpu(), want["attn_durations"])
+
+
 def test_vits_encoder_sample_rate_interpolates_latent(gpu):
     """encoder_sample_rate < audio.sample_rate (vits.py:806-812,944-959): z is linearly interpolated by the rate ratio
     before the waveform decoder and y_mask is recomputed."""

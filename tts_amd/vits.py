@@ -251,6 +251,55 @@ class Vits:
         o_hat = self.waveform_decoder.forward(z_hat, g=g_tgt, in_mask=mask)
         return o_hat, mask.unsqueeze(1), (z, z_p, z_hat)
 
+    # ---- alignment (vits.py:909-936, 1018-1031) --------------------------------------------------------
+    @torch.no_grad()
+    def forward_mas(self, outputs, z_p, m_p, logs_p, x, x_mask, y_mask, g=None, lang_emb=None):
+        """vits.py:909-942, the alignment half: log-likelihood matrix (MFMA kernel, stays on the device), monotonic
+        alignment search (bit-exact HIP kernels; the reference copies logp to the host and runs Cython), durations of the
+        path.  x_mask [B,1,T_x] or [B,T_x], y_mask likewise.  Returns (outputs, attn [B,1,T_x,T_y]) like the reference;
+        `outputs` gains "attn_durations" [B,1,T_x] (= attn.sum(3), :922).  The duration-predictor LOSS of :921-941
+        (incl. its log-duration target) is training code and is not computed; x, g, lang_emb are accepted for signature
+        parity and unused."""
+        attn = helpers.mas_attention(z_p, m_p, logs_p, x_mask, y_mask)                 # [B, T_x, T_y]
+        dur = ops.row_sum(attn).unsqueeze(1)                                            # attn.sum(3) -> [B, 1, T_x]
+        outputs["attn_durations"] = dur
+        return outputs, attn.unsqueeze(1)
+
+    @torch.no_grad()
+    def align(self, x, x_lengths, y, y_lengths, aux_input=None, noise=None):
+        """The alignment pass of Vits.forward (vits.py:1018-1031) without its losses: text encoder -> posterior encoder ->
+        flow (forward) -> forward_mas -> prior statistics expanded along the path.  x int64 [B,T_x], y [B,C_spec,T_y]
+        linear spectrogram (the STFT front end is training-side DSP: pass the spectrogram), `noise` [B,C,T_y] pins the
+        posterior's randn_like draw.  -> dict(alignments [B,1,T_x,T_y], attn_durations, z, z_p, m_p, logs_p (expanded),
+        x_mask, y_mask)."""
+        if self.text_encoder is None or self.posterior_encoder is None:
+            raise _lib.TtsAmdError("Vits.align needs text_encoder.* and posterior_encoder.* weights on the GPU")
+        _lib.require_gpu(x, "x")
+        dev = x.device
+        x = x.to(torch.int64).contiguous()
+        y = y.to(dev, torch.float32).contiguous()
+        B, Tx = x.shape
+        Ty = y.shape[2]
+        g = self._speaker_g(aux_input, B, dev)
+        lang = self._language_emb(aux_input, B, dev)
+        x_mask = ops.sequence_mask(x_lengths.to(dev), Tx)
+        y_mask = ops.sequence_mask(y_lengths.to(dev), Ty)
+        h, stats = self.text_encoder(x, x_mask, lang=None if lang is None else lang[:, :, 0])
+        H = self.args.hidden_channels
+        m_p, logs_p = stats[:, :H].contiguous(), stats[:, H:].contiguous()
+        if noise is None:
+            noise = torch.randn(B, H, Ty, device=dev, dtype=torch.float32)
+        z, _ = self.posterior_encoder(y, y_mask, noise.to(dev, torch.float32), g=g)
+        z_p = self.flow.forward_flow(z.clone(), y_mask, g=g)
+        outputs, attn = self.forward_mas({}, z_p, m_p, logs_p, h, x_mask, y_mask, g=g, lang_emb=lang)
+        # einsum("klmn, kjm -> kjn", attn, m_p) (vits.py:1029-1030): multiplying by a 0/1 monotonic path is a gather along
+        # it — the prior-expansion kernel of the inference path, fed with the path's cumulative durations
+        _, cum, ylen = ops.durations(None, x_mask, 1.0, durations_in=outputs["attn_durations"].reshape(B, Tx).contiguous())
+        pri = ops.expand_prior(m_p, logs_p, None, cum, x_mask, ylen, Ty, 0.0)
+        outputs.update(alignments=attn, z=z, z_p=z_p, x=h, x_mask=x_mask.unsqueeze(1), y_mask=y_mask.unsqueeze(1),
+                       m_p=pri["m_p"], logs_p=pri["logs_p"])
+        return outputs
+
     # ---- inference (vits.py:1088-1173) ---------------------------------------------------------------
     def _language_emb(self, aux_input, B, dev):
         """vits.py:886-887,1119-1122: lang_emb = emb_l(language_ids).unsqueeze(-1) -> [B, L, 1] or None."""
