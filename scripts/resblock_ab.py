@@ -49,7 +49,7 @@ def main():
                 tu = timeit(unfused)
                 flops = 2 * 2.0 * C * C * K * T * B
                 byts = 4.0 * C * T * B * 2
-                for variant in ((0, 1) if C == 64 else (0,)):
+                for variant in ((0, 1, 2) if (C == 64 and K == 3) else (0, 1) if C == 64 else (0, 2) if (C == 32 and K == 3) else (0,)):
                     tf = timeit(lambda: ops.resblock_pair(pc1, pc2, x, y, slope=0.1, variant=variant))
                     print("c%d k%d d%d v%d %s %10.1f %10.1f %7.2f %8.1f %6.3f %9.0f %6.3f"
                           % (C, K, D, variant, " " * (4 - len(str(C)) - len(str(K))), tu, tf, tu / tf, flops / tf / 1e6,

@@ -139,6 +139,8 @@ extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_RES_SKIP || (a.res && a.y2 && a.split_row > 0 && a.split_row % 32 == 0),
                      "conv1d: RES_SKIP needs res, y2 and split_row %% 32 == 0");
     TTSAMD_CHECK_ARG(a.mode >= 0 && a.mode <= TTSAMD_CONV_COUPLE_AFFINE_FWD, "conv1d: unknown mode %d", a.mode);
+    TTSAMD_CHECK_ARG(a.in_act != TTSAMD_ACT_LRELU || (a.in_slope >= 0.f && a.in_slope <= 1.f),
+                     "conv1d: leaky-ReLU slope %g outside [0, 1] (the kernels evaluate it as max(v, v * slope))", (double)a.in_slope);
     if (a.batch == 0 || a.t_out == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(a.batch <= 65535, "conv1d: batch > 65535");
     {   // the kernel addresses every per-item slab with 32-bit byte offsets (buffer resources)

@@ -73,9 +73,21 @@ __device__ __forceinline__ ConvTile conv_tile_of_block()
     return t;
 }
 
+// leaky ReLU as max(v, v * slope): for 0 <= slope <= 1 (checked on the host: ttsamd_conv1d / ttsamd_resblock_pair refuse
+// other slopes) this is v > 0 ? v : v * slope value for value, signed zeros included — one v_max instead of a compare + select
+// (the instruction itself: through fmaxf() hipcc first canonicalises both operands — a v_max v, v, v each — for sNaN inputs)
+__device__ __forceinline__ float conv_lrelu(float v, float slope)
+{
+    float r;
+    const float vs = v * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(vs));
+    return r;
+}
+// No activation = slope 1 (v * 1 and max(v, v) are exact): the choice is one scalar select per launch, not a compare + select
+// per staged element.
 __device__ __forceinline__ float conv_in_act(float v, int act, float slope)
 {
-    return (act == TTSAMD_ACT_LRELU) ? (v > 0.f ? v : v * slope) : v;
+    return conv_lrelu(v, (act == TTSAMD_ACT_LRELU) ? slope : 1.f);
 }
 
 // Accumulator initial value, shared by the fp32-MFMA and the split-bf16 kernels.
@@ -285,6 +297,21 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = tanhf(acc[mi][ni][r]);
                     }
+                    // residual, accumulate, mask, division: each behind ONE wave-uniform branch around its whole pass (inside
+                    // the element loop hipcc evaluates the IEEE division sequence — 12 VALU instructions — for every element of
+                    // every launch and selects afterwards).  Same operations in the same order as before.
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += e1[r];              // 0 when absent / folded
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = e2[r] + acc[mi][ni][r];
+                    if (omask) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= om;
+                    }
+                    if (has_div) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = acc[mi][ni][r] / out_div;
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -348,11 +375,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                             st_buf(ry2, v, rok ? voy2 : kOob, (rb - split) * y2_rs4);
                         }
                     } else {
-                        v += e1[r];              // 0 when absent / folded
-                        v = e2[r] + v;
-                        v *= om;
-                        if (has_div) v = v / out_div;
-                        st_buf(ry, v, rok ? voy : kOob, rb * y_rs4);
+                        st_buf(ry, v, rok ? voy : kOob, rb * y_rs4);      // NORMAL: finished above
                     }
                 }
             }

@@ -48,6 +48,21 @@ extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tile
 #define TTSAMD_X3S_ALL 0
 #endif
 
+// Staging pipeline of the large-grid kernel (build-time, A/B through TTSAMD_LIB_PATH):
+//   0  round-1/2 form: the next chunk's loads are issued behind `if (it + 1 < niter)` at the top of the iteration and
+//      converted / written to LDS after the tap loop.  Behind that wave-uniform branch hipcc cannot count the requests in
+//      flight and makes the FIRST MFMA of every iteration wait for all of them (`s_waitcnt vmcnt(3)`: an exposed HBM round
+//      trip per 16-channel chunk — the device assembly shows it).
+//   1  the same schedule with the loads issued unconditionally (a chunk index past c_in reads zeros through the buffer
+//      range check without touching memory): exact wait counts.
+//   2  (default) the staging work is spread over the taps: item i of the next chunk is requested at the start of tap
+//      LT(i) — after that tap's weight requests, so the in-order vmcnt does not force it home before tap LT(i) + 2 — and
+//      converted, split and written into the OTHER LDS buffer at the start of tap LT(i) + 2, between that tap's MFMAs.
+//      No phase of the iteration is VALU-only or memory-only any more.
+#ifndef TTSAMD_X3_PIPE
+#define TTSAMD_X3_PIPE 2
+#endif
+
 namespace ttsamd {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -60,7 +75,9 @@ struct ConvGeomX3 {
     static constexpr int kBN = 32 * NI * WN;
     static constexpr int kHalo = (K - 1) * D;
     static constexpr int kXW = kBN + kHalo;                  // staged columns
-    static constexpr int kPartBytes = kXW * 32;              // [column][16 ch] bf16
+    static constexpr int kXWp = kXW + 1;                     // + one dump column per plane: where the idle lanes of the last
+                                                             // staging round write (no branch around the split / LDS writes)
+    static constexpr int kPartBytes = kXWp * 32;             // [half][column][8 ch] bf16 (planar) / [column][16 ch]
     static constexpr int kBufBytes = 3 * kPartBytes;
     static constexpr int kItems = 2 * kXW;                   // (column, 8-channel half) work items per chunk
     static constexpr int kNStage = (kItems + kThreads - 1) / kThreads;
@@ -80,12 +97,11 @@ __device__ __forceinline__ void conv_split3(float x, unsigned &p1, unsigned &p2,
     p3 = __builtin_bit_cast(unsigned short, a3);
 }
 
-// Build-time experiment (TTSAMD_EXTRA_FLAGS=-DTTSAMD_SPLIT_PAIRS=1, A/B through TTSAMD_LIB_PATH): split TWO values per
-// conversion instruction and keep the parts packed — the same round-to-nearest-even conversions and exact residuals as
-// conv_split3, bit for bit, without the 12 v_or_b32_sdwa per 8 values that re-pack separately converted halves
-// (80 -> 62 VALU instructions per 8 staged values, compile-only count; not yet measured on a GPU).
+// Split TWO values per conversion instruction and keep the parts packed — the same round-to-nearest-even conversions and
+// exact residuals as conv_split3, bit for bit, without the 12 v_or_b32_sdwa per 8 values that re-pack separately converted
+// halves.  Default since round 3 (TTSAMD_SPLIT_PAIRS=0 builds the one-value-at-a-time form for A/B).
 #ifndef TTSAMD_SPLIT_PAIRS
-#define TTSAMD_SPLIT_PAIRS 0
+#define TTSAMD_SPLIT_PAIRS 1
 #endif
 __device__ __forceinline__ void conv_split3x2(float x0, float x1, unsigned &w1, unsigned &w2, unsigned &w3)
 {
@@ -161,55 +177,61 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : C
     }
     const int row_bytes = (int)a.x_rstride * 4;
     float st[G::kNStage][8];
-    auto stage_load = [&](int chunk) {
+    auto stage_load_item = [&](int i, int chunk) {
         const int cb = chunk * kConvCK * row_bytes;
 #pragma unroll
-        for (int i = 0; i < G::kNStage; ++i)
+        for (int c = 0; c < 8; ++c) st[i][c] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb + c * row_bytes, 0);
+    };
+    auto stage_store_item = [&](int i, unsigned char *buf) {
+        // straight-line: idle lanes (e >= kItems, last round) loaded zeros through the range check and write them into
+        // the dump column of plane 1
+        const int e = tid + i * G::kThreads;
+        const int half = (e < G::kItems) ? e / G::kXW : 1;
+        const int col = (e < G::kItems) ? e - half * G::kXW : G::kXW;
+#if TTSAMD_SPLIT_PAIRS
+        unsigned pw[3][4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) st[i][c] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb + c * row_bytes, 0);
+        for (int c = 0; c < 4; ++c)
+            conv_split3x2(conv_in_act(st[i][2 * c] * smask[i], a.in_act, a.in_slope),
+                          conv_in_act(st[i][2 * c + 1] * smask[i], a.in_act, a.in_slope), pw[0][c], pw[1][c], pw[2][c]);
+#else
+        unsigned p[3][8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            conv_split3(conv_in_act(st[i][c] * smask[i], a.in_act, a.in_slope), p[0][c], p[1][c], p[2][c]);
+#endif
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            u32x4 w;
+#if TTSAMD_SPLIT_PAIRS
+            w.x = pw[q][0];
+            w.y = pw[q][1];
+            w.z = pw[q][2];
+            w.w = pw[q][3];
+#else
+            w.x = p[q][0] | (p[q][1] << 16);
+            w.y = p[q][2] | (p[q][3] << 16);
+            w.z = p[q][4] | (p[q][5] << 16);
+            w.w = p[q][6] | (p[q][7] << 16);
+#endif
+#if TTSAMD_X3_PLANAR
+            *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + half * (G::kXWp * 16) + col * 16) = w;
+#else
+            *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + col * 32 + half * 16) = w;
+#endif
+        }
+    };
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) stage_load_item(i, chunk);
     };
     auto stage_store = [&](unsigned char *buf) {
 #pragma unroll
-        for (int i = 0; i < G::kNStage; ++i) {
-            const int e = tid + i * G::kThreads;
-            const int half = e / G::kXW;
-            const int col = e - half * G::kXW;
-            if (e < G::kItems) {
-#if TTSAMD_SPLIT_PAIRS
-                unsigned pw[3][4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    conv_split3x2(conv_in_act(st[i][2 * c] * smask[i], a.in_act, a.in_slope),
-                                  conv_in_act(st[i][2 * c + 1] * smask[i], a.in_act, a.in_slope), pw[0][c], pw[1][c], pw[2][c]);
-#else
-                unsigned p[3][8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    conv_split3(conv_in_act(st[i][c] * smask[i], a.in_act, a.in_slope), p[0][c], p[1][c], p[2][c]);
-#endif
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    u32x4 w;
-#if TTSAMD_SPLIT_PAIRS
-                    w.x = pw[q][0];
-                    w.y = pw[q][1];
-                    w.z = pw[q][2];
-                    w.w = pw[q][3];
-#else
-                    w.x = p[q][0] | (p[q][1] << 16);
-                    w.y = p[q][2] | (p[q][3] << 16);
-                    w.z = p[q][4] | (p[q][5] << 16);
-                    w.w = p[q][6] | (p[q][7] << 16);
-#endif
-#if TTSAMD_X3_PLANAR
-                    *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + half * (G::kXW * 16) + col * 16) = w;
-#else
-                    *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + col * 32 + half * 16) = w;
-#endif
-                }
-            }
-        }
+        for (int i = 0; i < G::kNStage; ++i) stage_store_item(i, buf);
     };
+    // pipelined staging (TTSAMD_X3_PIPE == 2): item i is requested at tap kLT(i) and converted at tap kLT(i) + 2 (K = "after the taps")
+    constexpr bool kPipe = (TTSAMD_X3_PIPE == 2) && KS == 1 && K >= 3;
+    auto lt_of = [](int i) constexpr { return (i * K) / G::kNStage; };
 
     f32x16 acc[MI][NI];
 
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : C
 
 #if TTSAMD_X3_PLANAR
     constexpr int kColBytes = 16;
-    const int bbyte = h * (G::kXW * 16) + (wn * (32 * NI) + j) * 16;   // this lane's fragment inside a part, tap 0, ni 0
+    const int bbyte = h * (G::kXWp * 16) + (wn * (32 * NI) + j) * 16;  // this lane's fragment inside a part, tap 0, ni 0
 #else
     constexpr int kColBytes = 32;
     const int bbyte = (wn * (32 * NI) + j) * 32 + h * 16;
@@ -255,7 +277,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : C
     for (int it = 0; it < niter; ++it) {
         const int c = grp + it * KS;
         const unsigned char *cur = xs3 + (it & 1) * G::kBufBytes + bbyte;
-        if (it + 1 < niter) stage_load(c + KS);
+        unsigned char *const nxt = xs3 + ((it + 1) & 1) * G::kBufBytes;
+        if constexpr (!kPipe) {
+#if TTSAMD_X3_PIPE == 0
+            if (it + 1 < niter) stage_load(c + KS);
+#else
+            stage_load(c + KS);      // past the last chunk: zeros from the buffer range check, no memory traffic
+#endif
+        }
         if (KS == 1 || c < nchunks) {
 #pragma unroll
             for (int tap = 0; tap < K; ++tap) {
@@ -268,7 +297,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : C
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) a_nxt[mi][q] = wp[mi][g + q * 64];
+                if constexpr (kPipe) {
+#pragma unroll
+                    for (int i = 0; i < G::kNStage; ++i)
+                        if (lt_of(i) == tap) stage_load_item(i, c + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
+                if constexpr (kPipe) {
+#pragma unroll
+                    for (int i = 0; i < G::kNStage; ++i)
+                        if (lt_of(i) + 2 == tap) stage_store_item(i, nxt);
+                }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     u32x4 bq[3];
@@ -292,7 +331,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : C
                     for (int q = 0; q < 3; ++q) a_cur[mi][q] = a_nxt[mi][q];
             }
         }
-        if (it + 1 < niter) stage_store(xs3 + ((it + 1) & 1) * G::kBufBytes);
+        if constexpr (kPipe) {
+#pragma unroll
+            for (int i = 0; i < G::kNStage; ++i)
+                if (lt_of(i) + 2 >= K) stage_store_item(i, nxt);
+        } else {
+#if TTSAMD_X3_PIPE == 0
+            if (it + 1 < niter) stage_store(nxt);
+#else
+            stage_store(nxt);
+#endif
+        }
         __syncthreads();
     }
 

@@ -42,7 +42,8 @@ struct ResGeom {
     static constexpr int kItems = kNCh * 2 * kXW;  // staged (chunk, half, column) items: 8 channels each
     static constexpr int kRounds = (kItems + kThreads - 1) / kThreads;
     static constexpr size_t kLdsBytes = (size_t)3 * kNCh * 2 * kPlaneX;
-    static constexpr int kOcc = (2 * kLdsBytes <= 160 * 1024 && kThreads <= 256) ? 2 : (kThreads >= 512 ? 2 : 1);
+    static constexpr int kOcc = (NI == 1 && kThreads <= 256 && 4 * kLdsBytes <= 160 * 1024) ? 4     // small tiles: 4 blocks / CU
+                                : (2 * kLdsBytes <= 160 * 1024 && kThreads <= 256) ? 2 : (kThreads >= 512 ? 2 : 1);
     static_assert(C % (32 * WM) == 0 && kBN > 0, "bad tile");
 };
 
@@ -144,32 +145,20 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                 const int pl = e / G::kXW;
                 const int col = e - pl * G::kXW;
                 if (e < G::kItems) {
-#if TTSAMD_SPLIT_PAIRS
+                    // two values per conversion instruction, parts stay packed (conv_split3x2: the same round-to-nearest-even
+                    // conversions and exact residuals as conv_split3, bit for bit)
                     unsigned pw[3][4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        conv_split3x2(conv_in_act(st[rr][2 * i] * sm[rr], TTSAMD_ACT_LRELU, a.slope),
-                                      conv_in_act(st[rr][2 * i + 1] * sm[rr], TTSAMD_ACT_LRELU, a.slope), pw[0][i], pw[1][i], pw[2][i]);
-#else
-                    unsigned p[3][8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        conv_split3(conv_in_act(st[rr][i] * sm[rr], TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
-#endif
+                        conv_split3x2(conv_lrelu(st[rr][2 * i] * sm[rr], a.slope), conv_lrelu(st[rr][2 * i + 1] * sm[rr], a.slope),
+                                      pw[0][i], pw[1][i], pw[2][i]);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         u32x4 w;
-#if TTSAMD_SPLIT_PAIRS
                         w.x = pw[q][0];
                         w.y = pw[q][1];
                         w.z = pw[q][2];
                         w.w = pw[q][3];
-#else
-                        w.x = p[q][0] | (p[q][1] << 16);
-                        w.y = p[q][2] | (p[q][3] << 16);
-                        w.z = p[q][4] | (p[q][5] << 16);
-                        w.w = p[q][6] | (p[q][7] << 16);
-#endif
                         *reinterpret_cast<u32x4 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneX + col * 16) = w;
                     }
                 }
@@ -215,14 +204,14 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
         const bool ok = (t >= 0) && (t < T);                      // outside the tensor conv2 sees its zero padding
         mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
     }
+    // biases through buffer resources: an absent bias is a zero-length resource (reads 0) — no branch per element
+    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(a.bias1, a.bias1 ? C * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(a.bias2, a.bias2 ? C * 4 : 0);
     float bia[MI][16];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            bia[mi][r] = a.bias1 ? a.bias1[row] : 0.f;
-        }
+        for (int r = 0; r < 16; ++r) bia[mi][r] = ld_buf(rb1, 16 * h, ((wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2)) * 4);
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -249,35 +238,20 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                 const int col = (wn * NI + ni) * 32 + j;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-#if TTSAMD_SPLIT_PAIRS
                     unsigned pw[3][2];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const float v0 = (acc[mi][ni][rg * 4 + 2 * i] + bia[mi][rg * 4 + 2 * i]) * mk[ni];
                         const float v1 = (acc[mi][ni][rg * 4 + 2 * i + 1] + bia[mi][rg * 4 + 2 * i + 1]) * mk[ni];
-                        conv_split3x2(conv_in_act(v0, TTSAMD_ACT_LRELU, a.slope), conv_in_act(v1, TTSAMD_ACT_LRELU, a.slope), pw[0][i],
-                                      pw[1][i], pw[2][i]);
+                        conv_split3x2(conv_lrelu(v0, a.slope), conv_lrelu(v1, a.slope), pw[0][i], pw[1][i], pw[2][i]);
                     }
-#else
-                    unsigned p[3][4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = (acc[mi][ni][rg * 4 + i] + bia[mi][rg * 4 + i]) * mk[ni];
-                        conv_split3(conv_in_act(v, TTSAMD_ACT_LRELU, a.slope), p[0][i], p[1][i], p[2][i]);
-                    }
-#endif
                     // rows 8*rg + 4*h + i of m-tile (wm*MI + mi): chunk 2*mtile + rg/2, 8-channel half rg%2, channels 4h..4h+3
                     const int pl = (2 * (wm * MI + mi) + (rg >> 1)) * 2 + (rg & 1);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         u32x2 w;
-#if TTSAMD_SPLIT_PAIRS
                         w.x = pw[q][0];
                         w.y = pw[q][1];
-#else
-                        w.x = p[q][0] | (p[q][1] << 16);
-                        w.y = p[q][2] | (p[q][3] << 16);
-#endif
                         *reinterpret_cast<u32x2 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneM + col * 16 + h * 8) = w;
                     }
                 }
@@ -289,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bia2[mi][r] = a.bias2 ? a.bias2[(wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+        for (int r = 0; r < 16; ++r) bia2[mi][r] = ld_buf(rb2, 16 * h, ((wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2)) * 4);
     __syncthreads();                                                   // the mid tile is complete
     res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc2, wp2, a_cur, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
 
@@ -311,21 +285,28 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                 const int o = (wn * NI + ni) * 32 + j;
                 const int t = t0 + o;
                 const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-                float e2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) e2[r] = 0.f;
-                if (has_accum) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-                }
+                // every optional pass behind ONE wave-uniform branch (inside the element loop hipcc evaluates the IEEE division
+                // sequence for every element of every launch and selects afterwards); operations and their order are those of
+                // the unfused conv epilogue
+                float vout[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc2[mi][ni][r] + bia2[mi][r];
-                    v += 0.f;                    // (the unfused epilogue's absent-operand add: keeps -0.0 handling identical)
-                    v = e2[r] + v;
-                    if (out_div != 0.f) v = v / out_div;
-                    st_buf(ry, v, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+                    vout[r] = acc2[mi][ni][r] + bia2[mi][r];
+                    vout[r] += 0.f;              // (the unfused epilogue's absent-operand add: keeps -0.0 handling identical)
                 }
+                if (has_accum) {
+                    float e2[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vout[r] = e2[r] + vout[r];
+                }
+                if (out_div != 0.f) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vout[r] = vout[r] / out_div;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st_buf(ry, vout[r], vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
             }
         }
     }
@@ -353,6 +334,12 @@ int resblock_pair_launch_cfg(const ttsamd_resblock_args &a, hipStream_t st)
 template <int K, int D>
 int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
 {
+    if constexpr (K == 3) {
+        // variant 2 (A/B): half-width tiles — 4 waves x 32 columns at C = 32, 2x2 waves x 32 columns at C = 64: a quarter /
+        // half of the LDS, <= 128 VGPRs, 4 blocks per CU instead of 3 / 2 (more blocks in different phases per SIMD)
+        if (a.variant == 2 && a.c == 32) return resblock_pair_launch_cfg<K, D, 32, 1, 4, 1>(a, st);
+        if (a.variant == 2 && a.c == 64) return resblock_pair_launch_cfg<K, D, 64, 2, 2, 1>(a, st);
+    }
     switch (a.c) {
         case 32: return resblock_pair_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:

@@ -14,17 +14,31 @@ import torch
 
 
 class GraphedSegment:
+    _capture = {}      # device index -> the ONE dedicated stream every segment is warmed up and captured on
+
+    @classmethod
+    def capture_stream(cls, device):
+        """Warm-up and capture run on the same dedicated stream, so everything a segment creates per stream on first use
+        (the HiFiGAN generator's MRF branch streams are keyed by the current stream) exists before capture begins, and is
+        re-used by every later capture instead of piling up per throw-away stream."""
+        from . import _lib
+
+        idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        if idx not in cls._capture:
+            cls._capture[idx] = _lib.OwnedStream(torch.device("cuda", idx))
+        return cls._capture[idx].stream
+
     def __init__(self, fn, example_inputs):
         self.stream = torch.cuda.current_stream()
         self.static_in = [t.clone() for t in example_inputs]
-        side = torch.cuda.Stream()
+        side = self.capture_stream(example_inputs[0].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up outside capture: one-time hipFuncSetAttribute calls, allocator
             for _ in range(2):
                 fn(*self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):
