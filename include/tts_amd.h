@@ -160,8 +160,8 @@ size_t ttsamd_conv1d_packed_floats(int c_out, int c_in, int kernel);
  * dst (host) = [ceil(c_out/32)][k-step groups][64 lanes][4]; zero padded. */
 int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, int kernel);
 /* Split-bf16 weight image (see ttsamd_conv1d_args.w_split): bytes, and the HOST-side repack
- * w [c_out, c_in, kernel] fp32 -> [ceil(c_out/32)][ceil(c_in/16)][kernel][3 parts][64 lanes][8 bf16] (+ one zero
- * group of prefetch slack); part q of a weight = round-to-nearest bf16 of what parts < q left of it. */
+ * w [c_out, c_in, kernel] fp32 -> [ceil(c_out/32)][ceil(c_in/16)][kernel][3 parts][64 lanes][8 bf16] (+ two zero
+ * groups of prefetch slack); part q of a weight = round-to-nearest bf16 of what parts < q left of it. */
 size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kernel);
 int ttsamd_conv1d_pack_weights_split(void *dst, const float *w, int c_out, int c_in, int kernel);
 /* 1 if (kernel, dilation) has a tuned instantiation. */

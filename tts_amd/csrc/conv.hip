@@ -89,7 +89,7 @@ extern "C" size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kern
     if (c_out <= 0 || c_in <= 0 || kernel <= 0) return 0;
     const size_t mtiles = (size_t)(c_out + 31) / 32;
     const size_t nchunks = (size_t)(c_in + kConvCK - 1) / kConvCK;
-    return (mtiles * nchunks * kernel + 1) * 3 * 64 * 16;   // + one zero group of prefetch slack
+    return (mtiles * nchunks * kernel + 2) * 3 * 64 * 16;   // + two zero groups of prefetch slack (the fused ResBlock kernel requests two taps ahead)
 }
 
 extern "C" int ttsamd_conv1d_pack_weights_split(void *dst_, const float *w, int c_out, int c_in, int kernel)

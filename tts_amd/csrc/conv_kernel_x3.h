@@ -230,7 +230,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS > 1 ? (WM * WN * KS) / 4 : C
         for (int i = 0; i < G::kNStage; ++i) stage_store_item(i, buf);
     };
     // pipelined staging (TTSAMD_X3_PIPE == 2): item i is requested at tap kLT(i) and converted at tap kLT(i) + 2 (K = "after the taps")
-    constexpr bool kPipe = (TTSAMD_X3_PIPE == 2) && KS == 1 && K >= 3;
+    // (K < 7: too few taps to spread over — measured same-box, the post-loop form with unconditional requests is as fast or faster)
+    constexpr bool kPipe = (TTSAMD_X3_PIPE == 2) && KS == 1 && K >= 7;
     auto lt_of = [](int i) constexpr { return (i * K) / G::kNStage; };
 
     f32x16 acc[MI][NI];

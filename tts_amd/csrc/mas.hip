@@ -316,6 +316,7 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw_kernel(
 constexpr int kMasBigThreads = 1024;
 constexpr int kMasBigLdsRows = 16384;
 
+template <bool GSTATE>   // column state in the workspace (global memory) instead of LDS
 __global__ __launch_bounds__(kMasBigThreads) void mas_forward_big_kernel(
     const float *in_values, const float *__restrict__ mask, float *dp_values, unsigned long long *__restrict__ dirs,
     float *gcol /* [B][2][Tx] or nullptr (LDS) */, const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty,
@@ -327,7 +328,12 @@ __global__ __launch_bounds__(kMasBigThreads) void mas_forward_big_kernel(
     const int t_x = min(t_xs[b], Tx);
     const int t_y = min(t_ys[b], Ty);
     const long base = (long)b * Tx * Ty;
-    float *col = gcol ? gcol + (long)b * 2 * Tx : smem;        // generic pointer: LDS or global
+    // (two instantiations rather than one generic pointer: flat accesses into the LDS aperture faulted on this stack)
+    auto col_ptr = [&]() {
+        if constexpr (GSTATE) return gcol + (long)b * 2 * Tx;
+        else return smem;
+    };
+    auto *const col = col_ptr();
     const bool need_copy = (dp_values != nullptr);
     const int nrow = R * 64;                                    // rows swept (whole 64-row groups: ballots are per group)
     // When the caller wants the full value*mask matrix back (dp_values_out != values_in), cells outside the band are copied.
@@ -341,8 +347,8 @@ __global__ __launch_bounds__(kMasBigThreads) void mas_forward_big_kernel(
     __syncthreads();
     const int y_stop = copy_all ? Ty : t_y;
     for (int y = 0; y < y_stop; ++y) {
-        const float *cp = col + (y & 1) * Tx;                   // column y-1
-        float *cn = col + ((y + 1) & 1) * Tx;                   // column y
+        const auto *cp = col + (y & 1) * Tx;                    // column y-1
+        auto *cn = col + ((y + 1) & 1) * Tx;                    // column y
         const int x_lo = max(0, t_x + y - t_y);
         const int x_hi = min(t_x, y + 1);
         const bool dp_col = y < t_y;
@@ -560,9 +566,15 @@ extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const fl
         }
         const size_t lds = gstate ? 0 : (size_t)2 * t_x * sizeof(float);
         static std::atomic<unsigned long long> lds_attr_done{0};
-        TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_big_kernel), 2 * kMasBigLdsRows * (int)sizeof(float), lds_attr_done));
-        hipLaunchKernelGGL(mas_forward_big_kernel, dim3(b), dim3(kMasBigThreads), lds, st, values_in, mask, dp_values_out, dirs, gcol,
-                           t_xs, t_ys, t_x, t_y, R, max_neg_val);
+        if (gstate) {
+            hipLaunchKernelGGL(mas_forward_big_kernel<true>, dim3(b), dim3(kMasBigThreads), 0, st, values_in, mask, dp_values_out, dirs,
+                               gcol, t_xs, t_ys, t_x, t_y, R, max_neg_val);
+        } else {
+            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_big_kernel<false>),
+                                          2 * kMasBigLdsRows * (int)sizeof(float), lds_attr_done));
+            hipLaunchKernelGGL(mas_forward_big_kernel<false>, dim3(b), dim3(kMasBigThreads), lds, st, values_in, mask, dp_values_out,
+                               dirs, gcol, t_xs, t_ys, t_x, t_y, R, max_neg_val);
+        }
         rc = (hipGetLastError() == hipSuccess) ? TTSAMD_OK : TTSAMD_ERR_HIP;
         if (rc != TTSAMD_OK) set_error("maximum_path: launch of the any-T_x kernel failed");
     } else if (R <= 8 && !single_wave) {

@@ -51,22 +51,26 @@ struct ResGeom {
 //   wp[mi]  this wave's A stream (m-tile (wm*MI + mi)): [chunk][tap][part][64 lanes] x 16 bytes, read from L2/L1 one tap
 //           ahead; a_cur holds tap 0 of chunk 0 on entry.
 //   bbase   LDS address of this lane's fragment for (part 0, chunk 0, n-tile 0, tap 0): plane `half`, column wn*32*NI + j.
+// Weight fragments are requested TWO taps ahead (a_cur: this tap, a_n1: the next, the third set is requested at the top of
+// the tap): a wave of these kernels issues only 12 MFMAs per tap (MI = 1, NI = 2: 384 cycles), which covered an L1 hit but
+// not the L2 round trip the fragments take whenever the streaming x tiles have pushed them out of L1 — the PMC counters of
+// round 2 show it (matrix pipe busy 0.65-0.70 here against 0.78 in the unfused kernel, whose waves issue 24 MFMAs per tap).
 template <int KK, int DD, int MI, int NI, int NCH, int PLANE>
 __device__ __forceinline__ void res_conv_mainloop(f32x16 (&acc)[MI][NI], const u32x4 *const (&wp)[MI], u32x4 (&a_cur)[MI][3],
-                                                  const unsigned char *bbase)
+                                                  u32x4 (&a_n1)[MI][3], const unsigned char *bbase)
 {
-    u32x4 a_nxt[MI][3];
+    u32x4 a_n2[MI][3];
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
         const unsigned char *cb = bbase + c * (2 * PLANE);
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
-            const long g = ((long)c * KK + tap + 1) * (3 * 64);   // the packed image ends with one group of slack
+            const long g = ((long)c * KK + tap + 2) * (3 * 64);   // the packed image ends with two groups of slack
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a_nxt[mi][q] = wp[mi][g + q * 64];
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
+                for (int q = 0; q < 3; ++q) a_n2[mi][q] = wp[mi][g + q * 64];
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch two whole taps ahead of its use
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 u32x4 bq[3];
@@ -87,7 +91,10 @@ __device__ __forceinline__ void res_conv_mainloop(f32x16 (&acc)[MI][NI], const u
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a_cur[mi][q] = a_nxt[mi][q];
+                for (int q = 0; q < 3; ++q) {
+                    a_cur[mi][q] = a_n1[mi][q];
+                    a_n1[mi][q] = a_n2[mi][q];
+                }
         }
     }
 }
@@ -174,11 +181,14 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
         wp1[mi] = reinterpret_cast<const u32x4 *>(a.w1_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
         wp2[mi] = reinterpret_cast<const u32x4 *>(a.w2_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
     }
-    u32x4 a_cur[MI][3];
+    u32x4 a_cur[MI][3], a_n1[MI][3];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp1[mi][q * 64];
+        for (int q = 0; q < 3; ++q) {
+            a_cur[mi][q] = wp1[mi][q * 64];
+            a_n1[mi][q] = wp1[mi][(3 + q) * 64];
+        }
 
     // conv2's accumulators start from the residual x — the tile's own columns, requested NOW: the lines were fetched for
     // the staging pass microseconds ago (L2 hits; requested after conv1 they had been evicted: PMC fetch 2.1x the tensor)
@@ -220,13 +230,16 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     __syncthreads();
-    res_conv_mainloop<K, D, MI, NI, NCH, G::kPlaneX>(acc, wp1, a_cur, rs3 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
+    res_conv_mainloop<K, D, MI, NI, NCH, G::kPlaneX>(acc, wp1, a_cur, a_n1, rs3 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
 
     // conv2's first weight fragments: requested before the mid epilogue so that their latency hides behind it
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a_cur[mi][q] = wp2[mi][q * 64];
+        for (int q = 0; q < 3; ++q) {
+            a_cur[mi][q] = wp2[mi][q * 64];
+            a_n1[mi][q] = wp2[mi][(3 + q) * 64];
+        }
 
     // ---- mid epilogue: (acc + bias1) * mask -> leaky ReLU -> 3-way split -> LDS (same bytes as the x tile) ------------
     {
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
 #pragma unroll
         for (int r = 0; r < 16; ++r) bia2[mi][r] = ld_buf(rb2, 16 * h, ((wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2)) * 4);
     __syncthreads();                                                   // the mid tile is complete
-    res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc2, wp2, a_cur, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
+    res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc2, wp2, a_cur, a_n1, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
 
     // ---- output epilogue: + bias2 (+ accum) (/ div) -------------------------------------------------------------------
     {
