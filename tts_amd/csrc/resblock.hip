@@ -35,3 +35,4 @@ extern "C" int ttsamd_resblock_pair(const ttsamd_resblock_args *args, void *stre
     }
     return TTSAMD_ERR_UNSUPPORTED;
 }
+

@@ -99,9 +99,26 @@ __device__ __forceinline__ void res_conv_mainloop(f32x16 (&acc)[MI][NI], const u
     }
 }
 
+#ifdef TTSAMD_PHASE_CLOCKS
+// debug build only (scripts/res_phase.py): shader-clock stamps of one mid-grid block's wave 0 at the phase boundaries
+static __device__ long long g_res_clk[16];     // one per translation unit (no relocatable device code): getters in resblock_k*.hip
+#define TTSAMD_RES_CLOCK_GETTER(name)                                                                                    \
+    extern "C" int name(long long *host_out16)                                                                           \
+    {                                                                                                                    \
+        return hipMemcpyFromSymbol(host_out16, HIP_SYMBOL(ttsamd::g_res_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : -1; \
+    }
+#define RES_STAMP(i) do { if (stamp) { if ((i) == 0) g_res_clk[15] = wall_clock64(); g_res_clk[i] = clock64(); if ((i) == 8) g_res_clk[14] = wall_clock64(); } } while (0)
+#else
+#define RES_STAMP(i) do { } while (0)
+#endif
+
 template <int K, int D, int C, int WM, int WN, int NI>
 __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_x3_kernel(const ttsamd_resblock_args a)
 {
+#ifdef TTSAMD_PHASE_CLOCKS
+    const bool stamp = threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.z == gridDim.z / 2;
+#endif
+    RES_STAMP(0);
     using G = ResGeom<K, D, C, WM, WN, NI>;
     constexpr int MI = G::kMI;
     constexpr int NCH = G::kNCh;
@@ -173,6 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
         }
     }
 
+    RES_STAMP(1);
     // ---- conv1 ------------------------------------------------------------------------------------------------------
     const u32x4 *wp1[MI], *wp2[MI];
 #pragma unroll
@@ -230,7 +248,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     __syncthreads();
+    RES_STAMP(2);
     res_conv_mainloop<K, D, MI, NI, NCH, G::kPlaneX>(acc, wp1, a_cur, a_n1, rs3 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
+    RES_STAMP(3);
 
     // conv2's first weight fragments: requested before the mid epilogue so that their latency hides behind it
 #pragma unroll
@@ -277,8 +297,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) bia2[mi][r] = ld_buf(rb2, 16 * h, ((wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2)) * 4);
+    RES_STAMP(4);
     __syncthreads();                                                   // the mid tile is complete
+    RES_STAMP(5);
     res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc2, wp2, a_cur, a_n1, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
+    RES_STAMP(6);
 
     // ---- output epilogue: + bias2 (+ accum) (/ div) -------------------------------------------------------------------
     {
@@ -323,6 +346,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
             }
         }
     }
+    RES_STAMP(7);
+#ifdef TTSAMD_PHASE_CLOCKS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    RES_STAMP(8);
 }
 
 template <int K, int D, int C, int WM, int WN, int NI>

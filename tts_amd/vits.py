@@ -9,7 +9,7 @@ the reference's names and argument meaning.  Training, ONNX export, voice conver
 """
 import torch
 
-from . import _lib, graphs, layers, ops
+from . import _lib, graphs, helpers, layers, ops
 from .hifigan import HifiganGenerator
 
 VITS_ARGS_DEFAULTS = dict(  # VitsArgs, vits.py:544-600
