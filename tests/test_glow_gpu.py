@@ -221,3 +221,37 @@ def test_glow_decoder_forward_and_inference_with_mas(gpu):
     rt = m.decoder_inference(y.to(gpu), yl.to(gpu))["model_outputs"]                   # forward then reverse
     ym = y[:, :44] * mask[:, :, None]
     assert _rel(rt, ym) < 1e-4
+
+
+def test_glow_single_sentence_graphs_equal_eager(gpu):
+    """GlowTTS.inference on one sentence replays the encoder + duration predictor as one hipGraph and everything after the
+    host sync as a second one at the frame count padded to 32: same outputs as the eager launches at the true length, for
+    several sentences sharing captures, with the model's own durations and with an odd frame count (squeeze drops it)."""
+    args = dict(num_flow_blocks_dec=3, inference_noise_scale=0.3)
+    args["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    sd = W.make_glow_state(args, seed=77)
+    m = _model(args, sd, gpu)
+    g = torch.Generator().manual_seed(5)
+    T = 21
+    for rep in range(4):
+        x = torch.randint(0, 130, (1, T), generator=g).to(gpu)
+        dur = (1 + torch.randint(0, 3, (1, T), generator=g)).float()
+        if rep == 1 and int(dur.sum()) % 2 == 0:            # an odd frame count once (the squeeze drops its last frame)
+            dur[0, 0] += 1
+        t_dec = int(dur.sum())
+        aux = {"x_lengths": torch.tensor([T], device=gpu), "durations": dur.to(gpu),
+               "noise": torch.randn(1, 80, t_dec, generator=g).to(gpu)}
+        want = m.inference(x, dict(aux, no_graph=True))
+        for _ in range(3):                               # eager, capture, replay
+            got = m.inference(x, aux)
+            for k in ("model_outputs", "y_mean", "alignments", "durations", "durations_log", "total_durations_log"):
+                assert got[k].shape == want[k].shape, (rep, k)
+                assert _rel(got[k], want[k]) < 2e-6, (rep, k)
+    assert m._tail.stats["captures"] >= 1 and m._tail.stats["replays"] >= 3 and m._front.stats["replays"] >= 4
+    # the model's own durations (no injection): graphs on / off agree
+    x = torch.randint(0, 130, (1, T), generator=g).to(gpu)
+    aux = {"x_lengths": torch.tensor([T], device=gpu)}
+    m.inference_noise_scale = 0.0
+    a = m.inference(x, dict(aux, no_graph=True))
+    b = m.inference(x, aux)
+    assert torch.equal(a["durations"], b["durations"]) and _rel(b["model_outputs"], a["model_outputs"]) < 2e-6

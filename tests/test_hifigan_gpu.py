@@ -144,3 +144,30 @@ def test_inference_slabbed_equals_inference_bitwise(gpu):
     m.inference_slabbed(mel, out=host, max_live_bytes=3 * per_item)              # host mels -> host waveforms
     torch.cuda.synchronize()
     assert torch.equal(host, want.cpu())
+
+
+def test_single_item_inference_graph_equals_eager(gpu):
+    """`inference` on one item replays as a hipGraph per 32-frame length bucket (the item runs ragged-exact inside the padded
+    tensor): same waveform as the eager launches at the true length — for several lengths sharing a bucket, across capture
+    (3rd call) and replay, and after a weight re-pack (captured graphs are dropped with the weights they point to)."""
+    cfg = dict(W.HIFIGAN_V2)
+    sd = W.make_hifigan_state(cfg, 80, seed=3)
+    m = _make(cfg, 80, gpu, sd)
+    g = torch.Generator().manual_seed(4)
+    for T in (41, 64, 50, 41, 41):
+        c = torch.randn(1, 80, T, generator=g).to(gpu)
+        m.use_graphs = False
+        want = m.inference(c)
+        m.use_graphs = True
+        for _ in range(3):
+            got = m.inference(c)
+            assert got.shape == want.shape == (1, 1, (T + 10) * 256)
+            assert _errs(got, want)[1] < 2e-6
+    assert m._graph.stats["captures"] >= 1 and m._graph.stats["replays"] >= 6 and len(m._graph.entries) <= 2
+    m.load_state_dict(W.make_hifigan_state(cfg, 80, seed=5))          # re-pack: graphs of the old weights must not replay
+    c = torch.randn(1, 80, 41, generator=g).to(gpu)
+    m.use_graphs = False
+    want = m.inference(c)
+    m.use_graphs = True
+    for _ in range(3):
+        assert _errs(m.inference(c), want)[1] < 2e-6

@@ -379,7 +379,7 @@ def test_vits_request_lanes_equal_single_stream(gpu):
     lanes = parallel.Lanes(2, device=gpu)
     for _ in range(2):          # second round replays the per-lane captured graphs
         outs = [lanes.run(m.inference, x, aux) for x, aux in reqs]
-        lanes.sync()
+        lanes.sync(timeout_s=120.0)      # bounded wait: a stalled lane raises instead of blocking for ever
         got = [o["model_outputs"] for o in outs]
         for a, b in zip(got, want):
             assert torch.equal(a, b)

@@ -41,11 +41,12 @@ extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tile
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
 #endif
-// Build-time experiment (TTSAMD_EXTRA_FLAGS=-DTTSAMD_X3S_ALL=1): the conv_kernel_x3s.h kernels for EVERY kernel size / dilation
-// on small grids (the waveform decoder's 512/256-channel stages of a single utterance, conv_pre), not only k <= 5 at
-// dilation 1.  Builds; not yet measured on a GPU.
+// The conv_kernel_x3s.h kernels for EVERY kernel size / dilation on small grids (the waveform decoder's 512/256-channel stages of
+// a single utterance, conv_pre, HiFiGAN-v2's k = 7 / 11 ResBlocks), not only k <= 5 at dilation 1.  Measured round 3, same box:
+// Glow-TTS + HiFiGAN-v2 sentence 3.49 -> 3.28 ms, VITS B = 1 request +-0 (4.74 / 4.79 ms).  TTSAMD_X3S_ALL=0 builds the
+// round-2 selection.
 #ifndef TTSAMD_X3S_ALL
-#define TTSAMD_X3S_ALL 0
+#define TTSAMD_X3S_ALL 1
 #endif
 
 // Staging pipeline of the large-grid kernel (build-time, A/B through TTSAMD_LIB_PATH):

@@ -6,7 +6,7 @@ training is out of scope.
 """
 import torch
 
-from . import _lib, helpers, layers, ops
+from . import _lib, graphs, helpers, layers, ops
 from .vits import _Args, _get
 
 GLOW_DEFAULTS = dict(  # glow_tts_config.py:101-152
@@ -55,6 +55,16 @@ class GlowTTS:
         self.device = torch.device("cpu")
         self._sd = None
         self.encoder = self.decoder = None
+        # A sentence is ~230 launches of a few microseconds (encoder ~60, 12 flow blocks ~170): issued one by one the HOST is
+        # the bottleneck (~10 us per launch through the C ABI).  As in tts_amd.Vits the encoder + duration predictor replay
+        # as one hipGraph per input shape and, for single sentences / ragged-exact batches, everything after the one host
+        # sync (prior expansion, alignment path, decoder flows) as a second one at the frame count padded to 32 (masks make
+        # the padded run equal the unpadded one).  `use_graphs = False` restores eager launches.
+        self.use_graphs = True
+        self._front = graphs.GraphCache(self._front_eager)
+        self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
+        self._tail_cfg = None
+        self.graph_tail_max_frames = 4096      # B * padded frames up to which the tail is captured
 
     @staticmethod
     def init_from_config(config, samples=None, verbose=True):
@@ -92,6 +102,8 @@ class GlowTTS:
         if self.device.type != "cuda":
             raise _lib.TtsAmdError("tts_amd.GlowTTS runs only on a GPU (no CPU fallback)")
         a, sd, dev = self.args, self._sd, self.device
+        self._front.clear()          # captured graphs hold raw pointers to the weight tensors replaced below
+        self._tail.clear()
         self.encoder = layers.GlowEncoder(sd, "encoder.", dev, a.hidden_channels_enc, a.out_channels, a.encoder_params,
                                           a.mean_only, a.use_encoder_prenet)
         self.decoder = layers.GlowDecoder(sd, "decoder.", dev, a.out_channels, a.hidden_channels_dec, a.kernel_size_dec,
@@ -123,6 +135,21 @@ class GlowTTS:
             v = dvec.to(dev, torch.float32).reshape(-1, dvec.shape[-1])
         return ops.l2_normalize(v.contiguous()).unsqueeze(-1)
 
+    def _front_eager(self, x, x_mask, g):
+        """encoder + duration predictor: tokens -> (o_mean, o_logs or empty, logw).  g [B,C,1] or an empty tensor."""
+        o_mean, o_logs, logw = self.encoder(x, x_mask, g=g if g.numel() else None)
+        return o_mean, (o_logs if o_logs is not None else torch.empty(0, device=x.device)), logw.contiguous()
+
+    def _tail_eager(self, o_mean, o_logs, cum, x_mask, y_lengths, noise, g):
+        """everything after the output extent is known, at the padded length self._tail_cfg[0] (glow_tts.py:361-366)."""
+        t_pad, noise_scale = self._tail_cfg
+        pri = ops.expand_prior(o_mean, o_logs if o_logs.numel() else None, noise if noise.numel() else None, cum, x_mask,
+                               y_lengths, t_pad, noise_scale, mask_out=True)
+        attn = ops.generate_path(cum, x_mask, y_lengths, t_pad)
+        y = self.decoder(pri["z_p"], pri["y_mask"], g=g if g.numel() else None)
+        logs_p = pri["logs_p"] if pri["logs_p"] is not None else torch.empty(0, device=o_mean.device)
+        return y, attn, pri["m_p"], logs_p
+
     @torch.no_grad()
     def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None}):  # noqa: B006
         """glow_tts.py:341-374.  Optional aux keys: "noise" [B,C,T_dec] pins the randn_like(y_mean) draw;
@@ -141,7 +168,11 @@ class GlowTTS:
             x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
         g = self._speaker_embedding(aux_input, dev)
-        o_mean, o_logs, logw = self.encoder(x, x_mask, g=g)
+        no_graph = bool((aux_input or {}).get("no_graph", False))
+        empty = torch.empty(0, device=dev)
+        self._front.enabled = bool(self.use_graphs) and not no_graph
+        o_mean, o_logs, logw = self._front(x, x_mask, g if g is not None else empty)
+        o_logs = o_logs if o_logs.numel() else None
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
         d_in = aux_input.get("durations") if aux_input else None
         if d_in is not None:   # not a reference feature: lets a parity harness pin the integer durations (ceil cliff)
@@ -155,6 +186,28 @@ class GlowTTS:
             noise = torch.randn(B, C, t_dec, device=dev, dtype=torch.float32)
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()
+        t_pad = -(-t_dec // 32) * 32
+        if self.use_graphs and not no_graph and (B == 1 or ragged) and B * t_pad <= self.graph_tail_max_frames:
+            nz = empty
+            if noise is not None:                       # drawn / pinned at the true extent, zero-extended (masked there)
+                nz = torch.zeros(B, C, t_pad, device=dev, dtype=torch.float32)
+                nz[:, :, :t_dec] = noise
+            self._tail.enabled = True
+            self._tail_cfg = (t_pad, float(self.inference_noise_scale))
+            y, attn, m_p, logs_p = self._tail(o_mean, o_logs if o_logs is not None else empty, cum, x_mask, y_lengths, nz,
+                                              g if g is not None else empty, key=self._tail_cfg)
+            # static buffers of the graph (overwritten by its next replay): hand out copies cut to the true extent
+            return {
+                "model_outputs": y[:, :, :t_dec].transpose(1, 2).clone(),
+                "logdet": None,
+                "y_mean": m_p[:, :, :t_dec].transpose(1, 2).clone(),
+                "y_log_scale": logs_p[:, :, :t_dec].transpose(1, 2).clone() if logs_p.numel() else None,
+                "alignments": attn[:, :, :t_dec].permute(0, 2, 1).clone(),
+                "durations_log": logw.clone().unsqueeze(1).transpose(1, 2),
+                "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
+                "y_lengths": y_lengths.clone(),
+                "durations": w_ceil.unsqueeze(1).clone(),
+            }
         pri = ops.expand_prior(o_mean, o_logs, noise, cum, x_mask, y_lengths, t_dec, float(self.inference_noise_scale),
                                mask_out=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)
@@ -166,7 +219,7 @@ class GlowTTS:
             "y_mean": pri["m_p"].transpose(1, 2),
             "y_log_scale": y_log_scale.transpose(1, 2),
             "alignments": attn.permute(0, 2, 1),
-            "durations_log": logw.unsqueeze(1).transpose(1, 2),
+            "durations_log": logw.clone().unsqueeze(1).transpose(1, 2),      # (may alias the front graph's static buffer)
             "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
             "y_lengths": y_lengths,
             "durations": w_ceil.unsqueeze(1),

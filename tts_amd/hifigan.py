@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import _lib, ops
+from . import _lib, graphs, ops
 from .ops import ACT_LRELU, ACT_TANH, CONV_SHUFFLE, PackedConv
 
 LRELU_SLOPE = 0.1  # hifigan_generator.py:11
@@ -64,6 +64,12 @@ class HifiganGenerator:
         self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "32,64,128").split(",") if c)
         self.fuse_max_kernel = {128: 3}     # channel count -> largest kernel size fused (absent = all)
         self._side_streams = {}     # current stream handle -> its MRF branch streams
+        # A single utterance through the vocoder is ~110 launches of a few microseconds each on up to four streams: issued
+        # one by one the host is the bottleneck.  `inference` on one item of up to `graph_max_frames` frames replays as ONE
+        # hipGraph per 32-frame length bucket (the item runs ragged-exact inside the padded tensor: same samples).
+        self.use_graphs = True
+        self.graph_max_frames = 2048
+        self._graph = graphs.GraphCache(self._inference_ragged, max_entries=12)
 
     def hop_length(self):
         return _cumprod(self.upsample_factors)[-1]
@@ -138,6 +144,7 @@ class HifiganGenerator:
                         P[rp + "convs.%d" % m] = PackedConv(ops.fold_weight_norm(sd, rp + "convs.%d" % m),
                                                             sd.get(rp + "convs.%d.bias" % m), dev, dilation=d)
         P["conv_post"] = PackedConv(ops.fold_weight_norm(sd, "conv_post"), sd.get("conv_post.bias"), dev)
+        self._graph.clear()          # captured graphs hold raw pointers to the previous weight tensors
         self._packed = P
 
     def weight_bytes(self):
@@ -289,7 +296,7 @@ class HifiganGenerator:
             out = torch.empty((B, self.out_channels, t_out), dtype=torch.float32, device=c.device)
         for lo in range(0, B, slab):
             hi = min(B, lo + slab)
-            w = self.inference(c[lo:hi].to(self.device, non_blocking=True))
+            w = self._inference_ragged(c[lo:hi].to(self.device, non_blocking=True).contiguous().float())   # throughput path: no graphs
             out[lo:hi].copy_(w, non_blocking=True)
         return out
 
@@ -299,6 +306,17 @@ class HifiganGenerator:
         `lengths` [B] (frames, optional) = ragged-exact batching (see forward): row b's first
         (lengths[b] + 2*pad)*hop samples equal `inference(c[b:b+1, :, :lengths[b]])`."""
         c = c.to(self.device).contiguous().float()
+        if (self.use_graphs and lengths is None and c.shape[0] == 1 and 0 < c.shape[2] <= self.graph_max_frames):
+            T = c.shape[2]
+            t_pad = -(-T // 32) * 32
+            cp = torch.zeros((1, c.shape[1], t_pad), dtype=torch.float32, device=c.device)
+            cp[:, :, :T] = c
+            wav = self._graph(cp, torch.full((1,), T, dtype=torch.int64, device=c.device))
+            hop = wav.shape[-1] // (t_pad + 2 * self.inference_padding)
+            return wav[:, :, : (T + 2 * self.inference_padding) * hop].clone()     # the graph's buffer is static: hand out a copy
+        return self._inference_ragged(c, lengths)
+
+    def _inference_ragged(self, c, lengths=None):
         if lengths is not None:
             lengths = torch.as_tensor(lengths).to(self.device, torch.int64)     # the pad kernel reads them on the device
         p = self.inference_padding

@@ -106,6 +106,21 @@ class Lanes:
         self._outs[i] = out
         return out
 
-    def sync(self):
-        for st in self.streams:
-            st.synchronize()
+    def sync(self, timeout_s=None):
+        """Wait for every lane.  With `timeout_s` the wait polls the lanes' streams and raises TtsAmdError when the deadline
+        passes instead of blocking for ever on a stalled stream — a serving loop can then drop the request and rebuild
+        its lanes (a blocking hipStreamSynchronize cannot be interrupted)."""
+        if timeout_s is None:
+            for st in self.streams:
+                st.synchronize()
+            return
+        import time
+
+        from . import _lib
+
+        deadline = time.monotonic() + float(timeout_s)
+        for i, st in enumerate(self.streams):
+            while not st.query():
+                if time.monotonic() > deadline:
+                    raise _lib.TtsAmdError("request lane %d did not finish within %.1f s (stalled stream?)" % (i, timeout_s))
+                time.sleep(0.0002)
