@@ -196,9 +196,11 @@ class GlowTTS:
             self._tail_cfg = (t_pad, float(self.inference_noise_scale))
             y, attn, m_p, logs_p = self._tail(o_mean, o_logs if o_logs is not None else empty, cum, x_mask, y_lengths, nz,
                                               g if g is not None else empty, key=self._tail_cfg)
-            # static buffers of the graph (overwritten by its next replay): hand out copies cut to the true extent
+            # static buffers of the graph (overwritten by its next replay): hand out copies cut to the true extent (the decoder's
+            # squeeze drops the frames that do not fill a group: its output is (t_dec // num_squeeze) * num_squeeze long)
+            t_y = (t_dec // self.num_squeeze) * self.num_squeeze
             return {
-                "model_outputs": y[:, :, :t_dec].transpose(1, 2).clone(),
+                "model_outputs": y[:, :, :t_y].transpose(1, 2).clone(),
                 "logdet": None,
                 "y_mean": m_p[:, :, :t_dec].transpose(1, 2).clone(),
                 "y_log_scale": logs_p[:, :, :t_dec].transpose(1, 2).clone() if logs_p.numel() else None,
