@@ -16,6 +16,7 @@ timeout 300 python bench.py --workload xtts_stream --steps 5 2>/dev/null | tail 
 timeout 300 python scripts/b1_latency.py 1 2>&1 | grep -v amdgpu.ids > $OUT/b1_latency.txt; cat $OUT/b1_latency.txt; stamp $OUT/b1_latency.txt
 [ -f tts_amd/libtts_amd_dbg.so ] && { TTSAMD_LIB_PATH=tts_amd/libtts_amd_dbg.so timeout 200 python scripts/res_phase.py 32,32,3,1,197120 32,32,3,5,197120 32,64,3,1,98560 32,32,11,1,197120 32,64,11,1,98560 32,128,3,1,49280 2>&1 | grep -v amdgpu.ids > $OUT/resblock_phase_clocks.txt; stamp $OUT/resblock_phase_clocks.txt; }
 timeout 600 python scripts/resblock_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/resblock_fused_vs_unfused.txt; stamp $OUT/resblock_fused_vs_unfused.txt; tail -4 $OUT/resblock_fused_vs_unfused.txt
+timeout 600 python scripts/power_probe.py 4 2>&1 | grep -v amdgpu.ids > $OUT/power_probe.txt; stamp $OUT/power_probe.txt; cat $OUT/power_probe.txt
 # power / clock while the headline workload runs (rocm-smi sampled once a second)
 ( timeout 200 python bench.py --steps 400 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_long.jsonl 2>/dev/null ) &
 BP=$!
