@@ -385,6 +385,39 @@ def test_vits_request_lanes_equal_single_stream(gpu):
             assert torch.equal(a, b)
 
 
+def test_vits_text_length_buckets_share_one_capture(gpu):
+    """With graphs on, the token axis is padded to a multiple of 16 (pad ids masked out): requests of 17..32 tokens replay ONE
+    captured front end, and every output equals the eager run at the true length — token-indexed outputs cut back to T."""
+    args = dict(upsample_initial_channel_decoder=64)
+    sd = W.make_vits_state(args, seed=14)
+    m = _model(args, sd, gpu)
+    g = torch.Generator().manual_seed(10)
+    for T in (29, 17, 32, 23, 29, 31):
+        x = torch.randint(0, 100, (1, T), generator=g).to(gpu)
+        aux = {"x_lengths": torch.tensor([T], device=gpu), "noise_dp": torch.randn(1, 2, T, generator=g).to(gpu),
+               "return_extras": True}
+        want = m.inference(x, dict(aux, no_graph=True, noise_z=None))
+        t_dec = want["model_outputs"].shape[-1] // 256
+        nz = torch.randn(1, 192, t_dec, generator=g).to(gpu)
+        want = m.inference(x, dict(aux, no_graph=True, noise_z=nz))
+        got = m.inference(x, dict(aux, noise_z=nz))
+        assert torch.equal(got["durations"], want["durations"]) and got["durations"].shape == (1, 1, T)
+        assert got["alignments"].shape == want["alignments"].shape and torch.equal(got["alignments"], want["alignments"])
+        assert got["x"].shape == want["x"].shape == (1, 192, T)
+        for k in ("model_outputs", "z", "m_p", "logs_p", "x", "logw"):
+            assert _errs(got[k], want[k])[1] < 2e-6, (T, k)
+    assert len(m._front.entries) == 1 and m._front.stats["replays"] >= 4, m._front.stats
+    # a ragged batch: rows keep their own lengths inside the bucket
+    x = torch.randint(0, 100, (3, 27), generator=g).to(gpu)
+    aux = {"x_lengths": torch.tensor([27, 20, 9], device=gpu), "noise_dp": torch.randn(3, 2, 27, generator=g).to(gpu)}
+    a = m.inference(x, dict(aux, no_graph=True))
+    nz = torch.randn(3, 192, a["model_outputs"].shape[-1] // 256, generator=g).to(gpu)
+    a = m.inference(x, dict(aux, no_graph=True, noise_z=nz))
+    for _ in range(3):
+        b = m.inference(x, dict(aux, noise_z=nz))
+        assert torch.equal(a["durations"], b["durations"]) and _errs(b["model_outputs"], a["model_outputs"])[1] < 2e-6
+
+
 def test_vits_bench_batch32_rows_match_oracle(gpu):
     """The benchmark's exact step (VitsArgs defaults, B=32 x 257 ids, 770 frames, both noise draws pinned) — 8 sampled
     rows of the batch against B=1 oracle runs on the same row: waveform <= 1e-4 RMS and <= 1e-5 relative per row, and the

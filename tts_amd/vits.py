@@ -104,6 +104,7 @@ class Vits:
         self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
         self._tail_cfg = None
         self.graph_tail_max_frames = 2048      # B * padded frames up to which the tail is captured
+        self.text_bucket = 16                  # token-axis padding of graphed requests (1 = off): 16 lengths share a capture
 
     # ---- plug-in surface ---------------------------------------------------------------------------
     @staticmethod
@@ -330,21 +331,36 @@ class Vits:
         x_lengths = aux_input.get("x_lengths") if aux_input else None
         if x_lengths is None:
             x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)       # vits.py:1082-1086
+        durations = aux_input.get("durations") if aux_input else None
+        no_graph = bool((aux_input or {}).get("no_graph", False))
+        # Text-length buckets: real traffic brings a new token count with almost every request, and a captured front end is
+        # keyed by its shape.  With graphs on, the token axis is padded to a multiple of 16 (pad ids masked out by x_mask —
+        # exactly the situation of a shorter sentence inside a batch: masked convs / attention / flows give the valid
+        # positions the values of the unpadded run), so 16 lengths share one capture; outputs are cut back at the end.
+        T0 = T
+        need_dp = durations is None or bool((aux_input or {}).get("run_duration_predictor"))
+        if self.use_graphs and not no_graph and need_dp and self.text_bucket > 1 and T % self.text_bucket:
+            T = -(-T // self.text_bucket) * self.text_bucket
+            xp = torch.zeros((B, T), dtype=torch.int64, device=dev)
+            xp[:, :T0] = x
+            x = xp
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
         g = self._speaker_g(aux_input, B, dev)
         g_dp = g if a.condition_dp_on_speaker else None
         lang = self._language_emb(aux_input, B, dev)
         H = a.hidden_channels
-        durations = aux_input.get("durations") if aux_input else None
         # the reference skips the duration predictor when durations are injected (vits.py:1124-1143);
         # "run_duration_predictor" keeps it in the pass anyway (bench.py: fixed output length, no work skipped)
-        need_dp = durations is None or bool(aux_input.get("run_duration_predictor"))
         logw = None
         if need_dp:
             noise_dp = aux_input.get("noise_dp") if aux_input else None
-            if noise_dp is None:
-                noise_dp = torch.randn(B, 2, T, device=dev, dtype=torch.float32) if a.use_sdp else torch.empty(0, device=dev)
+            if noise_dp is None:     # drawn at the reference's shape [B, 2, T0] (a fixed seed gives the same draw, bucketed or not)
+                noise_dp = torch.randn(B, 2, T0, device=dev, dtype=torch.float32) if a.use_sdp else torch.empty(0, device=dev)
             noise_dp = noise_dp.to(dev, torch.float32).contiguous()
+            if T != T0 and noise_dp.numel():
+                nd = torch.zeros((B, 2, T), dtype=torch.float32, device=dev)
+                nd[:, :, :T0] = noise_dp
+                noise_dp = nd
             gd = g_dp if g_dp is not None else torch.empty(0, device=dev)
             self._front.enabled = bool(self.use_graphs) and not (aux_input or {}).get("no_graph", False)
             ld = lang if lang is not None else torch.empty(0, device=dev)
@@ -354,12 +370,15 @@ class Vits:
         if durations is None:
             w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale))
         else:
-            d = durations.to(dev, torch.float32).reshape(B, T).contiguous()       # vits.py:1141-1143 (+ batches)
+            d = durations.to(dev, torch.float32).reshape(B, T0).contiguous()      # vits.py:1141-1143 (+ batches)
+            if T != T0:
+                dp = torch.zeros((B, T), dtype=torch.float32, device=dev)
+                dp[:, :T0] = d
+                d = dp
             w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d)
         t_dec = int(y_lengths.max().item())                                       # one D2H sync: output extent
         noise_z = aux_input.get("noise_z") if aux_input else None
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
-        no_graph = bool((aux_input or {}).get("no_graph", False))
         t_pad = -(-t_dec // 32) * 32
         if (self.use_graphs and not no_graph and (B == 1 or ragged) and self.interpolate_factor is None
                 and self.max_inference_len is None and B * t_pad <= self.graph_tail_max_frames):
@@ -392,7 +411,7 @@ class Vits:
                 outputs["y_lengths"] = y_lengths.clone()
             if aux_input and aux_input.get("return_extras"):
                 outputs.update(x=h.clone(), logw=None if logw is None else logw.clone().unsqueeze(1), y_lengths=y_lengths.clone())
-            return outputs
+            return self._cut_text(outputs, T0, T)
         if noise_z is None:
             noise_z = torch.randn(B, H, t_dec, device=dev, dtype=torch.float32)
         noise_z = noise_z.to(dev, torch.float32).contiguous()
@@ -430,6 +449,17 @@ class Vits:
         if aux_input and aux_input.get("return_extras"):
             # (h / logw may alias the captured front end's static buffers: hand out copies)
             outputs.update(x=h.clone(), logw=None if logw is None else logw.clone().unsqueeze(1), y_lengths=y_lengths)
+        return self._cut_text(outputs, T0, T)
+
+    @staticmethod
+    def _cut_text(outputs, T0, T):
+        """Undo the text-length bucket: token-indexed outputs back to the caller's T0 tokens."""
+        if T != T0:
+            outputs["alignments"] = outputs["alignments"][:, :T0].contiguous()
+            outputs["durations"] = outputs["durations"][:, :, :T0].contiguous()
+            for k in ("x", "logw"):
+                if outputs.get(k) is not None:
+                    outputs[k] = outputs[k][:, :, :T0].contiguous()
         return outputs
 
     __call__ = inference
