@@ -248,6 +248,7 @@ def test_glow_single_sentence_graphs_equal_eager(gpu):
                 assert got[k].shape == want[k].shape, (rep, k)
                 assert _rel(got[k], want[k]) < 2e-6, (rep, k)
     assert m._tail.stats["captures"] >= 1 and m._tail.stats["replays"] >= 3 and m._front.stats["replays"] >= 4
+    assert len(m._front.entries) == 1                 # T = 21 runs in the 32-token bucket: one captured front end
     # the model's own durations (no injection): graphs on / off agree
     x = torch.randint(0, 130, (1, T), generator=g).to(gpu)
     aux = {"x_lengths": torch.tensor([T], device=gpu)}

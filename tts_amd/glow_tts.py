@@ -65,6 +65,7 @@ class GlowTTS:
         self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
         self._tail_cfg = None
         self.graph_tail_max_frames = 4096      # B * padded frames up to which the tail is captured
+        self.text_bucket = 16                  # token-axis padding of graphed requests (1 = off)
 
     @staticmethod
     def init_from_config(config, samples=None, verbose=True):
@@ -166,9 +167,18 @@ class GlowTTS:
         x_lengths = aux_input.get("x_lengths") if aux_input else None
         if x_lengths is None:
             x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+        no_graph = bool((aux_input or {}).get("no_graph", False))
+        # text-length buckets (see tts_amd.Vits.inference): the token axis of a graphed request is padded to a multiple of 16,
+        # pad ids masked out and — unlike the reference's batches, where clamp_min gives every PADDED token one frame —
+        # owning no frames ("ragged_exact" durations), so the valid positions see the unpadded run
+        T0 = T
+        if self.use_graphs and not no_graph and self.text_bucket > 1 and T % self.text_bucket:
+            T = -(-T // self.text_bucket) * self.text_bucket
+            xp = torch.zeros((B, T), dtype=torch.int64, device=dev)
+            xp[:, :T0] = x
+            x = xp
         x_mask = ops.sequence_mask(x_lengths.to(dev), T)
         g = self._speaker_embedding(aux_input, dev)
-        no_graph = bool((aux_input or {}).get("no_graph", False))
         empty = torch.empty(0, device=dev)
         self._front.enabled = bool(self.use_graphs) and not no_graph
         o_mean, o_logs, logw = self._front(x, x_mask, g if g is not None else empty)
@@ -176,9 +186,15 @@ class GlowTTS:
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
         d_in = aux_input.get("durations") if aux_input else None
         if d_in is not None:   # not a reference feature: lets a parity harness pin the integer durations (ceil cliff)
-            w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d_in.to(dev, torch.float32).reshape(B, T).contiguous())
+            d = d_in.to(dev, torch.float32).reshape(B, T0).contiguous()
+            if T != T0:
+                dp = torch.zeros((B, T), dtype=torch.float32, device=dev)
+                dp[:, :T0] = d
+                d = dp
+            w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d)
         else:
-            w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), glow=2 if ragged else 1)
+            w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale),
+                                                   glow=2 if (ragged or T != T0) else 1)
         t_dec = int(y_lengths.max().item())
         noise = aux_input.get("noise") if aux_input else None
         C = a.out_channels
@@ -199,7 +215,7 @@ class GlowTTS:
             # static buffers of the graph (overwritten by its next replay): hand out copies cut to the true extent (the decoder's
             # squeeze drops the frames that do not fill a group: its output is (t_dec // num_squeeze) * num_squeeze long)
             t_y = (t_dec // self.num_squeeze) * self.num_squeeze
-            return {
+            return self._cut_text({
                 "model_outputs": y[:, :, :t_y].transpose(1, 2).clone(),
                 "logdet": None,
                 "y_mean": m_p[:, :, :t_dec].transpose(1, 2).clone(),
@@ -209,13 +225,13 @@ class GlowTTS:
                 "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
                 "y_lengths": y_lengths.clone(),
                 "durations": w_ceil.unsqueeze(1).clone(),
-            }
+            }, T0, T)
         pri = ops.expand_prior(o_mean, o_logs, noise, cum, x_mask, y_lengths, t_dec, float(self.inference_noise_scale),
                                mask_out=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)
         y = self.decoder(pri["z_p"], pri["y_mask"], g=g)
         y_log_scale = pri["logs_p"]
-        return {
+        return self._cut_text({
             "model_outputs": y.transpose(1, 2),
             "logdet": None,
             "y_mean": pri["m_p"].transpose(1, 2),
@@ -225,7 +241,17 @@ class GlowTTS:
             "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
             "y_lengths": y_lengths,
             "durations": w_ceil.unsqueeze(1),
-        }
+        }, T0, T)
+
+    @staticmethod
+    def _cut_text(out, T0, T):
+        """Undo the text-length bucket: token-indexed outputs back to the caller's T0 tokens."""
+        if T != T0:
+            out["alignments"] = out["alignments"][:, :, :T0].contiguous()              # [B, T_dec, T_x]
+            out["durations"] = out["durations"][:, :, :T0].contiguous()                # [B, 1, T_x]
+            for k in ("durations_log", "total_durations_log"):                         # [B, T_x, 1]
+                out[k] = out[k][:, :T0].contiguous()
+        return out
 
     __call__ = inference
 
