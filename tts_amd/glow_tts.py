@@ -171,8 +171,11 @@ class GlowTTS:
         # text-length buckets (see tts_amd.Vits.inference): the token axis of a graphed request is padded to a multiple of 16,
         # pad ids masked out and — unlike the reference's batches, where clamp_min gives every PADDED token one frame —
         # owning no frames ("ragged_exact" durations), so the valid positions see the unpadded run
+        # (single sentences and ragged-exact batches only: in a plain batch the reference's one-frame-per-padded-token rule
+        # applies to the batch's own padding and is kept as it is)
         T0 = T
-        if self.use_graphs and not no_graph and self.text_bucket > 1 and T % self.text_bucket:
+        ragged_in = bool((aux_input or {}).get("ragged_exact"))
+        if self.use_graphs and not no_graph and (B == 1 or ragged_in) and self.text_bucket > 1 and T % self.text_bucket:
             T = -(-T // self.text_bucket) * self.text_bucket
             xp = torch.zeros((B, T), dtype=torch.int64, device=dev)
             xp[:, :T0] = x
