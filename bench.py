@@ -23,8 +23,8 @@ Output contract: the LAST line rank 0 prints is the headline JSON line of the se
 metric/value/unit/... + "roofline" + "cpu_baseline", no tables).  Everything else comes BEFORE it, one JSON object per
 line: {"detail": ...} lines carry the per-kernel tables of the roofline pass, and at N=1 the default invocation also
 measures BASELINE configs[0] (Glow-TTS + HiFiGAN-v2, one 64-char sentence) and configs[2] (HiFiGAN-v1 vocoder only,
-256 x 8192-frame mels) after the headline's timed region and prints each as its OWN line ({"extra_workload": ...};
-`--no-extras` skips them).  Every line carries its CPU baseline: the oracle on the host cores at the best of a
+256 x 8192-frame mels), each in its own fresh process after the headline's timed region, and prints each as its OWN line
+({"extra_workload": ...}; `--no-extras` skips them).  Every line carries its CPU baseline: the oracle on the host cores at the best of a
 thread-count sweep (thread count and core count stated).
 """
 import argparse
@@ -813,21 +813,30 @@ def main():
     line = WORKLOADS[args.workload](args, ctx)
     emit_details(ctx)
     if args.workload == "vits_e2e" and ctx.world == 1 and not args.no_extras:
+        # The other single-GPU BASELINE configs, each measured in its OWN fresh process after the headline's timed region
+        # and printed as its own line before the headline line.  Not in this process: a HIP event recorded with timing
+        # (the roofline passes bracket every conv launch with them) switches its hardware queue to profiling mode for the
+        # rest of the process, and every later dispatch on that queue then pays a few microseconds of completion-signal
+        # handling — invisible in a 76 ms step, +75 % on the 330-launch single-sentence line (measured round 3: 3.2 ms in a
+        # fresh process, 5.7 ms after the headline's roofline pass; round 2's 3.0 vs 3.86 ms discrepancy was this).
         import gc
 
-        # the other single-GPU BASELINE configs, measured AFTER the headline's timed region, each printed as its own line
-        for name, fn, over in (("configs[0] glow_hifigan_v2", wl_glow_hifigan_v2, dict(steps=50, warmup=5)),
-                               ("configs[2] hifigan_v1", wl_hifigan_v1,
-                                dict(hifigan_steps=args.hifigan_steps or 1,
-                                     hifigan_warmup=1 if args.hifigan_warmup is None else args.hifigan_warmup))):
-            gc.collect()
-            torch.cuda.empty_cache()
-            sub = argparse.Namespace(**dict(vars(args), **over))
+        gc.collect()
+        torch.cuda.empty_cache()
+        common = ["--precision", args.precision] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        for name, extra_args in (("configs[0] glow_hifigan_v2", ["--workload", "glow_hifigan_v2", "--steps", "50", "--warmup", "5"]),
+                                 ("configs[2] hifigan_v1", ["--workload", "hifigan_v1", "--steps", str(args.hifigan_steps or 1),
+                                                            "--warmup", str(1 if args.hifigan_warmup is None else args.hifigan_warmup),
+                                                            "--items", str(args.items), "--frames", str(args.frames)])):
             try:
-                extra = fn(sub, ctx)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra_args + common, capture_output=True, text=True,
+                                   timeout=600, cwd=ROOT)
+                rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                for ln in rows[:-1]:
+                    print(ln, flush=True)                                  # the child's detail tables
+                extra = json.loads(rows[-1]) if (r.returncode == 0 and rows) else {"error": "rc=%d %s" % (r.returncode, r.stderr[-400:])}
             except Exception as e:          # an extra must never cost the headline line
                 extra = {"error": "%s: %s" % (type(e).__name__, e)}
-            emit_details(ctx)
             print(json.dumps({"extra_workload": name, "line": extra}), flush=True)
     if ctx.rank == 0:
         print(headline_json(line), flush=True)
