@@ -40,7 +40,7 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_W
   PYTHONPATH=$R timeout 600 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc$i -o p -- python $BENCH > $OUT/pmc$i.log 2>&1; echo "pmc$i rc=$?"
   cp $(find $OUT/pmc$i -name '*counter_collection.csv' | head -1) $OUT/pmc$i.csv 2>/dev/null; rm -rf $OUT/pmc$i
 done
-(cd $R && python scripts/pmc_round.py $OUT/pmc_dominant_x3.json "conv1d_x3_kernel<11,1,1,4,4,1,0>" $OUT/pmc1.csv $OUT/pmc2.csv $OUT/pmc3.csv > $OUT/pmc_table.txt); stamp $OUT/pmc_table.txt; head -24 $OUT/pmc_table.txt
+(cd $R && python scripts/pmc_round.py $OUT/pmc_dominant_x3.json "conv1d_x3_kernel<11,1,1,4,4,1,0," $OUT/pmc1.csv $OUT/pmc2.csv $OUT/pmc3.csv > $OUT/pmc_table.txt); stamp $OUT/pmc_table.txt; head -24 $OUT/pmc_table.txt
 V1="$R/bench.py --workload hifigan_v1 --items 16 --steps 1 --warmup 1 --no-cpu-baseline"
 for P in "FETCH_SIZE" "WRITE_SIZE"; do
   PYTHONPATH=$R timeout 600 rocprofv3 --pmc $P --output-format csv -d $OUT/v1$P -o p -- python $V1 > $OUT/v1$P.log 2>&1; echo "v1 $P rc=$?"
