@@ -354,7 +354,7 @@ def wl_vits_e2e(args, ctx):
         utterances_per_gpu=args.batch, chars=args.chars,
         weights="random-init VitsArgs defaults (29.1 M params)", weight_broadcast_s=bcast_s, weight_broadcast_bytes=bcast_bytes,
         weight_broadcast_backend=ctx.backend if ctx.world > 1 else "none (1 rank)",
-        mrf_branch_streams=1 if args.serial_branches else 3, request_lanes=args.lanes,
+        mrf_branch_streams=1 if (args.serial_branches or args.lanes > 1) else 3, request_lanes=args.lanes,
         fused_resblocks=bool(getattr(model.waveform_decoder, "fuse_resblocks", False)))
     line["rtf_x"] = value / SAMPLE_RATE
     line["rtf_x_per_gpu"] = value / SAMPLE_RATE / ctx.world
@@ -777,7 +777,8 @@ def main():
                     help="headline run only: skip the configs[0] / configs[2] lines carried under extra_workloads at N=1")
     ap.add_argument("--serial-branches", action="store_true",
                     help="run the MRF resblock branches on one stream (for rocprof: per-kernel durations are then not "
-                         "inflated by co-running kernels; the roofline pass always runs this way)")
+                         "inflated by co-running kernels; the roofline pass always runs this way; with two or more lanes the "
+                         "generator does so by itself)")
     ap.add_argument("--precision", default=None, choices=["x3", "f32"],
                     help="conv arithmetic: x3 = split-bf16 kernels (default, fp32-class accuracy on the bf16 MFMA), "
                          "f32 = fp32-input MFMA kernels (bitwise fmaf chain)")

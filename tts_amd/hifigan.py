@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import _lib, graphs, ops
+from . import _lib, graphs, ops, parallel
 from .ops import ACT_LRELU, ACT_TANH, CONV_SHUFFLE, PackedConv
 
 LRELU_SLOPE = 0.1  # hifigan_generator.py:11
@@ -54,7 +54,9 @@ class HifiganGenerator:
         self.device = torch.device("cpu")
         self._sd = None
         self._packed = None
-        self.concurrent_branches = True     # MRF resblocks on separate HIP streams (see forward)
+        # MRF resblocks on separate HIP streams (see forward): True / False, or "auto" = three branch streams for a lone
+        # request, one stream when the request runs inside parallel.Lanes with two or more lanes (parallel.active_lanes)
+        self.concurrent_branches = "auto"
         # ResBlock1 iterations (lrelu -> conv(k,d) -> lrelu -> conv(k,1) -> +x) run as ONE fused launch where the kernel
         # covers the shape (C in {32,64,128} per `fuse_channels`, split-bf16 arithmetic): the intermediate tensor stays in
         # LDS, 5 HBM tensor passes -> 2.  Bitwise equal to the unfused pair.
@@ -198,6 +200,7 @@ class HifiganGenerator:
         else:
             ops.conv1d(P["conv_pre"], x, o, in_mask=in_mask)
         nk = self.num_kernels
+        concurrent = (parallel.active_lanes() <= 1) if self.concurrent_branches == "auto" else bool(self.concurrent_branches)
         for i, u in enumerate(self.upsample_factors):
             ch //= 2
             T_up = T * u
@@ -213,7 +216,7 @@ class HifiganGenerator:
             # the reference's order): each branch runs on its own HIP stream so that one branch's launch tail / ramp
             # overlaps another branch's compute; events order only the accumulating convs.
             main = torch.cuda.current_stream()
-            side = self._streams(nk) if self.concurrent_branches and nk > 1 else None
+            side = self._streams(nk) if concurrent and nk > 1 else None
             ev_up = torch.cuda.Event() if side else None
             if side:
                 ev_up.record(main)

@@ -72,6 +72,17 @@ def shard_by_length(lengths, world_size):
     return [order[r::world_size] for r in range(world_size)]
 
 
+_ACTIVE_LANES = 0      # lanes of the Lanes object whose run() is issuing the current request (0: not inside a lane)
+
+
+def active_lanes():
+    """How many request lanes the request being issued shares the GPU with (0 outside `Lanes.run`).  The HiFiGAN generator
+    reads it: with two or more requests in flight the lanes already supply the concurrency and its MRF branches run on ONE
+    stream (measured round 3, two lanes, per request: B=1 3.47 vs 4.41 ms, B=4 10.2 vs 11.6, B=16 38.2 vs 41.2, B=32 75.4 vs
+    77.3 — serial vs three branch streams); a lone request keeps its three branch streams (B=1 4.50 vs 4.72 ms)."""
+    return _ACTIVE_LANES
+
+
 class Lanes:
     """Request lanes inside one GPU process: N HIP streams used round-robin, one request (batch) per lane at a time.
     A request's text front end is a few milliseconds of tiny, latency-bound launches with a host sync in the middle
@@ -86,6 +97,10 @@ class Lanes:
     """
 
     def __init__(self, n=2, device=None, priority=-1):
+        # priority -1 (high), measured round 3 with two lanes: B=32 76.5 vs 77.9 ms/step, B=1 3.52 vs 4.05 ms/request against
+        # priority 0.  (Only while a lane's request stays on its own stream, as it does inside a lane — see active_lanes():
+        # with normal-priority MRF branch streams next to a high-priority lane every stage pays cross-priority event waits,
+        # B=1 5.1 ms/request.)
         # High-priority lane streams: a request's own launches (text front end, flows, up-sampling convs) then win free CU
         # slots over the other lane's resblock convs, which run on the generator's normal-priority branch streams —
         # otherwise every one of the front end's ~170 dependent launches queues behind a chip-filling decoder kernel.
@@ -101,8 +116,13 @@ class Lanes:
         self._next = (i + 1) % len(self.streams)
         st = self.streams[i]
         st.wait_stream(torch.cuda.current_stream())        # inputs produced on the caller's stream
-        with torch.cuda.stream(st):
-            out = fn(*args, **kwargs)
+        global _ACTIVE_LANES
+        was, _ACTIVE_LANES = _ACTIVE_LANES, len(self.streams)
+        try:
+            with torch.cuda.stream(st):
+                out = fn(*args, **kwargs)
+        finally:
+            _ACTIVE_LANES = was
         self._outs[i] = out
         return out
 
