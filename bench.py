@@ -768,8 +768,8 @@ WORKLOADS = {"vits_e2e": wl_vits_e2e, "glow_hifigan_v2": wl_glow_hifigan_v2, "hi
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--chars", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
