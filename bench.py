@@ -768,8 +768,8 @@ WORKLOADS = {"vits_e2e": wl_vits_e2e, "glow_hifigan_v2": wl_glow_hifigan_v2, "hi
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 2 for hifigan_v1: a step is 6 s)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 5; 1 for hifigan_v1)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--chars", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -798,6 +798,10 @@ def main():
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="process-group backend (default: nccl = RCCL on GPUs; gloo only for launch_check on CPU)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 2 if args.workload == "hifigan_v1" else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == "hifigan_v1" else 5
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
