@@ -5,6 +5,8 @@ gloo in the CPU tests): the whole reference-layout state_dict travels as ONE fla
 VITS) instead of hundreds of small broadcasts — a single large transfer is what a point-to-point xGMI
 ring/tree wants.  SURVEY.md §8(e).
 """
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -72,7 +74,7 @@ def shard_by_length(lengths, world_size):
     return [order[r::world_size] for r in range(world_size)]
 
 
-_ACTIVE_LANES = 0      # lanes of the Lanes object whose run() is issuing the current request (0: not inside a lane)
+_TLS = threading.local()      # .lanes: lanes of the Lanes object whose run() is issuing this THREAD's current request
 
 
 def active_lanes():
@@ -80,7 +82,7 @@ def active_lanes():
     reads it: with two or more requests in flight the lanes already supply the concurrency and its MRF branches run on ONE
     stream (measured round 3, two lanes, per request: B=1 3.47 vs 4.41 ms, B=4 10.2 vs 11.6, B=16 38.2 vs 41.2, B=32 75.4 vs
     77.3 — serial vs three branch streams); a lone request keeps its three branch streams (B=1 4.50 vs 4.72 ms)."""
-    return _ACTIVE_LANES
+    return getattr(_TLS, "lanes", 0)
 
 
 class Lanes:
@@ -116,13 +118,12 @@ class Lanes:
         self._next = (i + 1) % len(self.streams)
         st = self.streams[i]
         st.wait_stream(torch.cuda.current_stream())        # inputs produced on the caller's stream
-        global _ACTIVE_LANES
-        was, _ACTIVE_LANES = _ACTIVE_LANES, len(self.streams)
+        was, _TLS.lanes = getattr(_TLS, "lanes", 0), len(self.streams)
         try:
             with torch.cuda.stream(st):
                 out = fn(*args, **kwargs)
         finally:
-            _ACTIVE_LANES = was
+            _TLS.lanes = was
         self._outs[i] = out
         return out
 
