@@ -157,6 +157,9 @@ class HifiganGenerator:
         own set, so that two requests in flight never queue work on a common stream (round 2 shared one set between the
         lanes: one lane's branch launches then sat behind the other lane's event waits)."""
         key = torch.cuda.current_stream().cuda_stream
+        if key not in self._side_streams and len(self._side_streams) >= 16:
+            # lanes come and go in a long-lived server: keep the sets of the 16 most recently created owner streams
+            self._side_streams.pop(next(iter(self._side_streams)))
         pool = self._side_streams.setdefault(key, [])
         while len(pool) < n:
             pool.append(_lib.OwnedStream(self.device))
