@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace ttsamd {
 
@@ -204,8 +205,10 @@ __global__ __launch_bounds__(kMasThreads) void mas_forward_kernel(
 // the skew below the ring size (a slot is reused 64 columns later).  Same single fp32 add per cell as the reference
 // => bit-exact, like the one-wave kernel.
 // 12 waves per item: R DP waves + (12 - R) tile movers.  Measured on [32,257,770] (R = 5), forward kernel alone: one DP wave
-// 520 us -> this kernel 250 us; with the DP switched off the movers need 70 us, with the movers off the DP needs the same
-// 250 us: the DP waves are instruction-issue bound (~75 instructions per column and wave; waves 0 and 4 share a SIMD).
+// 520 us -> this kernel 250 us (round 2; with the DP switched off the movers need 70 us, with the movers off the DP needs the
+// same 250 us: the DP waves are instruction-issue bound, ~75 instructions and a dozen branches per column and wave) -> 150 us
+// with the straight-line column step of round 3 (~40 instructions; whole maximum_path 0.282 -> 0.207 ms, [256,257,770] 0.313 ->
+// 0.245 ms = 1.1e11 cells/s; raising the DP waves' issue priority with s_setprio changed nothing).
 constexpr int kMasMwWaves = 12;
 constexpr int kMasRing = 64;
 
@@ -238,6 +241,10 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw_kernel(
     const int nmov = kMasMwWaves - R;
 
     for (int i = threadIdx.x; i < R * kMasRing; i += blockDim.x) MAS_RING_ST(i, ~0ull);     // tag -1: nothing published
+    for (int i = threadIdx.x; i < 2 * YT * XP; i += blockDim.x) {   // padding rows x >= Tx (no mover writes them) read as 0
+        const int xx = i % XP;
+        if (xx >= Tx) smem[i] = 0.f;
+    }
     if (!dp_wave && nt_work > 0)
         mas_stage_tile<YT, 16>(buf0, in_values, mask, base, Tx, Ty, XP, 0, mover, lane, nmov);
     __syncthreads();
@@ -245,51 +252,71 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw_kernel(
     const int r = wave;
     const int x = r * 64 + lane;
     float prev = 0.f;      // this row's value in the previous column
+    // Round 3: the column step as straight-line code.  The round-2 loop spent ~75 instructions and a dozen branches per
+    // column (y == 0 / r > 0 / lane == 0 / in-band cases re-derived every column); here column 0 is peeled (it is just
+    // prev = value), the first row group is its own instantiation (no ring, row 0's "no upper neighbour"), band membership is
+    // two compares on d = y - x against the constant t_y - t_x (x_lo <= x < x_hi  <=>  0 <= y - x <= t_y - t_x for x < t_x),
+    // the next column's value and ring slot are requested unconditionally (one row past the tile stays inside the LDS
+    // allocation), in-place values are written for every lane (outside the band keep == value), and max() is the bare
+    // instruction (fmaxf first canonicalises both operands).  Same fp32 add per cell => still bit-exact.
+    const int band = t_y - t_x;
+    const int xe = (x < t_x) ? x : 0x3fffffff;                 // rows beyond t_x never enter the band
+    const bool publish = (r + 1 < R);
+    auto vmax = [](float a_, float b_) {
+        float o;
+        asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a_), "v"(b_));
+        return o;
+    };
+    auto dp_tile = [&](auto first_tag, float *cur, int t) {
+        constexpr bool kFirst = decltype(first_tag)::value;
+        int y = t * YT;
+        const int y_end = min(t_y, min(Ty, (t + 1) * YT));
+        if (y >= y_end) return;
+        float *cp = cur + x;                                    // this lane's row in the tile, one column = XP floats
+        float cnext = cp[0];
+        if (t == 0) {                                           // column 0: value[x,0] = value (x = 0: max(neg, 0) + value)
+            prev = cnext;
+            cnext = cp[XP];
+            if (publish && lane == 63) MAS_RING_ST(r * kMasRing, (unsigned long long)__builtin_bit_cast(unsigned, prev));
+            cp += XP;
+            y = 1;
+            if (y >= y_end) return;
+        }
+        unsigned long long wq = ~0ull;                          // ring slot of column y - 1 (requested a column ahead)
+        if (!kFirst) wq = MAS_RING_LD((r - 1) * kMasRing + ((y - 1) & (kMasRing - 1)));
+        unsigned long long *dp = dirs + ((long)b * Ty + (y - 1)) * R + r;     // bit-plane word of column y - 1
+        int d = y - xe;
+        for (; y < y_end; ++y, ++d, cp += XP, dp += R) {
+            const float c = cnext;
+            cnext = cp[XP];
+            // x-1 neighbour of the previous column: DPP wave shift inside the group, the ring across groups
+            float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, prev), 0x138, 0xf, 0xf, false));
+            if constexpr (!kFirst) {
+                while ((int)(wq >> 32) != y - 1) wq = MAS_RING_LD((r - 1) * kMasRing + ((y - 1) & (kMasRing - 1)));
+                const float carry = __builtin_bit_cast(float, (unsigned)(wq & 0xffffffffull));
+                wq = MAS_RING_LD((r - 1) * kMasRing + (y & (kMasRing - 1)));      // the slot the NEXT column needs
+                up = (lane == 0) ? carry : up;
+            }
+            // direction bit-plane of column y-1: value[x,y-1] < value[x-1,y-1] (row 0 has no upper neighbour)
+            const unsigned long long bits = __ballot((kFirst ? (lane != 0) : true) && prev < up);
+            if (lane == 0) *dp = bits;
+            const float v_cur = (d == 0) ? neg : prev;                           // x == y
+            const float v_prev = (kFirst && lane == 0) ? neg : up;               // x == 0
+            const float nv = vmax(v_cur, v_prev) + c;
+            const bool inb = (d >= 0) && (d <= band);
+            prev = inb ? nv : c;
+            if (need_copy) cp[0] = prev;
+            if (publish && lane == 63)
+                MAS_RING_ST(r * kMasRing + (y & (kMasRing - 1)), ((unsigned long long)(unsigned)y << 32) | __builtin_bit_cast(unsigned, prev));
+        }
+    };
     for (int t = 0; t < nt_work; ++t) {
         float *cur = (t & 1) ? buf1 : buf0;
         float *oth = (t & 1) ? buf0 : buf1;
         if (dp_wave) {
-            const int y_end = min(t_y, min(Ty, (t + 1) * YT));
             if (t_x > 0) {
-                float cnext = (x < Tx && t * YT < y_end) ? cur[x] : 0.f;
-                unsigned long long wq = ~0ull;     // ring slot of the column before the one being processed
-                if (r > 0 && t > 0) wq = MAS_RING_LD((r - 1) * kMasRing + ((t * YT - 1) & (kMasRing - 1)));
-                const float *cp = cur + x;         // this lane's row in the tile, one column = XP floats
-                unsigned long long *dp = dirs + ((long)b * Ty + (t * YT - 1)) * R + r;   // bit-plane word of column y-1
-                for (int y = t * YT; y < y_end; ++y, cp += XP, dp += R) {
-                    const int x_lo = max(0, t_x + y - t_y);
-                    const int x_hi = min(t_x, y + 1);
-                    const float c = cnext;
-                    if (y + 1 < y_end) cnext = (x < Tx) ? cp[XP] : 0.f;
-                    // x-1 neighbour of the previous column: DPP wave shift inside the group, the ring across groups
-                    float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, prev), 0x138, 0xf,
-                                                                                     0xf, false));
-                    if (r > 0) {
-                        float carry = 0.f;
-                        if (y > 0) {
-                            while ((int)(wq >> 32) != y - 1) wq = MAS_RING_LD((r - 1) * kMasRing + ((y - 1) & (kMasRing - 1)));
-                            carry = __builtin_bit_cast(float, (unsigned)(wq & 0xffffffffull));
-                        }
-                        // the slot the NEXT column needs, requested a whole column ahead of its use (a miss — the wave below
-                        // has not published it yet — is re-read above; the lag then grows until these reads hit)
-                        if (y + 1 < y_end) wq = MAS_RING_LD((r - 1) * kMasRing + (y & (kMasRing - 1)));
-                        if (lane == 0) up = carry;
-                    }
-                    if (y > 0) {   // direction bit-plane of column y-1: value[x,y-1] < value[x-1,y-1]
-                        const unsigned long long bits = __ballot(x >= 1 && prev < up);
-                        if (lane == 0) *dp = bits;
-                    }
-                    const float v_cur = (x == y) ? neg : prev;
-                    const float v_prev = (x == 0) ? (y == 0 ? 0.f : neg) : up;
-                    const float nv = fmaxf(v_cur, v_prev) + c;
-                    const bool inb = (x >= x_lo) && (x < x_hi);
-                    const float keep = inb ? nv : c;
-                    prev = keep;
-                    if (need_copy && inb) const_cast<float *>(cp)[0] = keep;
-                    if (r + 1 < R && lane == 63)
-                        MAS_RING_ST(r * kMasRing + (y & (kMasRing - 1)),
-                                    ((unsigned long long)(unsigned)y << 32) | __builtin_bit_cast(unsigned, keep));
-                }
+                if (r == 0) dp_tile(std::true_type{}, cur, t);
+                else dp_tile(std::false_type{}, cur, t);
             }
         } else {
             if (need_copy && t > 0)
