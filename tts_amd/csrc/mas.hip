@@ -465,16 +465,22 @@ __global__ __launch_bounds__(kMasBtThreads) void mas_backtrack_kernel(
                 const int wlo = (int)(unsigned)(window & 0xffffffffull);
                 const int whi = (int)(unsigned)(window >> 32);
                 const int jmax = min(63, t_y - 1 - y_lo);
-                for (int j = jmax; j >= 0; --j) {          // core.pyx:34-37
+                // the index chain is serial (core.pyx:34-37): kept in a SCALAR register (readfirstlane pins it: left to itself
+                // hipcc ran the chain on the vector ALU — a 64-bit vector shift and three selects per column, ~140 cycles;
+                // the scalar chain is a handful of one-cycle ops), the per-lane bookkeeping (myidx) stays off the chain
+                int sidx = __builtin_amdgcn_readfirstlane(idx);
+                const int sidx0 = sidx;
+                for (int j = jmax; j >= 0; --j) {
                     const int yy = y_lo + j;
-                    if (lane == j) myidx = idx;
+                    if (lane == j) myidx = sidx;
                     const unsigned ulo = (unsigned)__builtin_amdgcn_readlane(wlo, j);
                     const unsigned uhi = (unsigned)__builtin_amdgcn_readlane(whi, j);
                     const unsigned long long w = ((unsigned long long)uhi << 32) | ulo;
-                    const int k = idx - idx0 + 63;
-                    const bool dec = (idx != 0) && (yy > 0) && ((idx == yy) || ((w >> k) & 1ull));
-                    idx -= dec ? 1 : 0;
+                    const int k = sidx - sidx0 + 63;
+                    const bool dec = (sidx != 0) && (yy > 0) && ((sidx == yy) || ((w >> k) & 1ull));
+                    sidx = __builtin_amdgcn_readfirstlane(sidx - (dec ? 1 : 0));
                 }
+                idx = sidx;
             }
             s_idx[c & 1][lane] = myidx;
             if (prezeroed && myidx >= 0) paths[base + (long)myidx * Ty + y_lo + lane] = (PathT)1;
