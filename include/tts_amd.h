@@ -185,7 +185,9 @@ int ttsamd_conv1d_set_small_grid(int mode);
  * in_mask).  Weights are the split-bf16 images of ttsamd_conv1d_pack_weights_split ([c, c, k] each); the intermediate
  * tensor stays in LDS (5 HBM tensor passes -> 2) and the arithmetic is product-for-product that of two ttsamd_conv1d
  * launches with w_split set: results are bitwise identical to the unfused pair.
- * Limits: c in {32, 64, 128}, kernel in {3, 7, 11}, dilation in {1, 3, 5} (ttsamd_resblock_pair_supported). */
+ * Limits: c in {8, 16, 32, 64, 128}, kernel in {3, 7, 11}, dilation in {1, 3, 5} (ttsamd_resblock_pair_supported).
+ * c = 8 / 16 (HiFiGAN-v2's late stages) run on the 32-channel tile: pass the split images of the weights ZERO-PADDED to
+ * [32, 32, k] (tensors and biases keep their real channel count; equal to the unfused pair up to the sign of zeros). */
 typedef struct ttsamd_resblock_args {
     const float *x;
     float *y;

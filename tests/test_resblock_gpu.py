@@ -58,7 +58,8 @@ def _rel(a, b):
     return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
 
 
-ALL = [(C, K, D) for C in (32, 64, 128) for K in (3, 7, 11) for D in (1, 3, 5)]
+ALL = [(C, K, D) for C in (32, 64, 128) for K in (3, 7, 11) for D in (1, 3, 5)] + \
+      [(16, 3, 1), (16, 7, 3), (16, 11, 5), (8, 3, 5), (8, 7, 1), (8, 11, 3)]      # HiFiGAN-v2's late stages: zero-padded tile
 
 
 @pytest.mark.parametrize("ckd", ALL, ids=lambda c: "c%d_k%d_d%d" % c)
@@ -79,7 +80,8 @@ def test_fused_pair_bitwise_equals_two_convs(gpu, ckd):
                                   (64, 7, 3, 3, 517, True, True, 3.0), (64, 11, 1, 1, 247, False, True, 0.0),
                                   (128, 3, 5, 2, 300, True, True, 3.0), (32, 7, 1, 4, 5, True, True, 3.0),
                                   (64, 3, 1, 1, 1, False, False, 0.0), (32, 11, 3, 1, 246, False, False, 0.0),
-                                  (32, 11, 3, 1, 247, False, True, 3.0)])
+                                  (32, 11, 3, 1, 247, False, True, 3.0), (16, 7, 5, 3, 700, True, True, 3.0),
+                                  (8, 11, 1, 2, 1000, True, True, 3.0)])
 def test_fused_pair_mask_accum_div_and_edges(gpu, case):
     """Ragged length masks (both convs see x*mask / mid*mask), the MRF accumulate + true division of the block's last
     iteration, tensors shorter than the halo, and lengths that end exactly on / one past a tile edge (kBN = 256-(K-1))."""
@@ -126,9 +128,11 @@ def test_fused_pair_alternative_tile_and_limits(gpu):
     with pytest.raises(_lib.TtsAmdError):
         ops.resblock_pair(pc1, pc2, x, x, slope=SLOPE)                 # in place is refused (tiles read x's halo)
     _, p1, p2, _ = _pair(16, 3, 1, 1, gpu)
-    assert not ops.resblock_pair_supported(p1, p2)                     # C = 16 (HiFiGAN-v2 tail stages): unfused path
+    assert ops.resblock_pair_supported(p1, p2)                         # C = 16 / 8 (HiFiGAN-v2 tail stages): padded 32-row tile
+    _, p1, p2, _ = _pair(48, 3, 1, 1, gpu)
+    assert not ops.resblock_pair_supported(p1, p2)                     # no instantiation: the unfused path
     with pytest.raises(_lib.TtsAmdError):
-        ops.resblock_pair(p1, p2, x[:, :16].contiguous(), ya[:, :16].contiguous(), slope=SLOPE)
+        ops.resblock_pair(p1, p2, x[:, :48].contiguous(), ya[:, :48].contiguous(), slope=SLOPE)
     was = ops.conv_precision()
     ops.set_conv_precision("f32")
     try:
@@ -150,7 +154,7 @@ def test_hifigan_fused_equals_unfused(gpu, ragged):
     m.to(gpu)
     mel = torch.randn(3, 80, 23, generator=torch.Generator().manual_seed(6))
     lengths = torch.tensor([23, 17, 9]) if ragged else None
-    m.fuse_resblocks, m.fuse_channels, m.fuse_max_kernel = True, (32, 64, 128), {}
+    m.fuse_resblocks, m.fuse_channels, m.fuse_max_kernel = True, (16, 32, 64, 128), {}
     fused = m.inference(mel.to(gpu), lengths=lengths)
     m.fuse_resblocks = False
     plain = m.inference(mel.to(gpu), lengths=lengths)

@@ -420,9 +420,12 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     // summation order than the large-grid tiles — the usual fp32 reassociation, within every parity tolerance).  Only
     // instantiated where such launches occur: every NORMAL-mode conv (text side, flows, and the waveform decoder's 512/256-
     // channel stages of a single utterance) and the dilation-1 gate / res-skip / coupling convs of the flows.
-    if constexpr (MODE == TTSAMD_CONV_NORMAL ||
+    // (round 3: + the 1x1 affine-coupling convs of the Glow decoder — a single sentence launched THREE 64x256 blocks per flow
+    // block there, 30 us each: 11 % of the Glow-TTS + HiFiGAN-v2 sentence)
+    constexpr bool affine = (MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD);
+    if constexpr (MODE == TTSAMD_CONV_NORMAL || (affine && K == 1) ||
                   (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE))) {
-        constexpr bool paired = (MODE == TTSAMD_CONV_GATE);
+        constexpr bool paired = (MODE == TTSAMD_CONV_GATE) || affine;
         const long tiles_n = (a.t_out + 127) / 128;
         const long blocks_default = tiles_n * ((mtiles + 3) / 4) * a.batch;      // 128x128-class blocks
         if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks) {

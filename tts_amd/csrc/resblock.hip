@@ -5,7 +5,7 @@ using namespace ttsamd;
 
 extern "C" int ttsamd_resblock_pair_supported(int c, int kernel, int dilation)
 {
-    return (c == 32 || c == 64 || c == 128) && (kernel == 3 || kernel == 7 || kernel == 11) &&
+    return (c == 8 || c == 16 || c == 32 || c == 64 || c == 128) && (kernel == 3 || kernel == 7 || kernel == 11) &&
            (dilation == 1 || dilation == 3 || dilation == 5);
 }
 

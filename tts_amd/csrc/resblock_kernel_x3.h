@@ -137,8 +137,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
     const int T = a.t;
     constexpr int kOob = kConvOob;
 
-    const long slab = (long)C * T * 4;    // one item's [C, T] tensor (contiguous rows)
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * C * T, slab);
+    // a.c may be smaller than the instantiation's C (HiFiGAN-v2's 16- and 8-channel stages run on the C = 32 kernel with
+    // zero-padded weight images): every tensor is addressed with the REAL channel count, rows beyond it read as zeros
+    // through the buffer range check and their stores are dropped by it
+    const int creal = a.c;
+    const long slab = (long)creal * T * 4;    // one item's [c, T] tensor (contiguous rows)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * creal * T, slab);
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc(a.mask ? a.mask + (long)b * T : nullptr, a.mask ? (long)T * 4 : 0);
     const bool has_mask = a.mask != nullptr;
 
@@ -233,8 +237,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
         mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
     }
     // biases through buffer resources: an absent bias is a zero-length resource (reads 0) — no branch per element
-    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(a.bias1, a.bias1 ? C * 4 : 0);
-    const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(a.bias2, a.bias2 ? C * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(a.bias1, a.bias1 ? creal * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(a.bias2, a.bias2 ? creal * 4 : 0);
     float bia[MI][16];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -310,8 +314,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
         asm volatile("" : "+s"(ep) : : "memory");
         const float out_div = ep->out_div;
         const bool has_accum = ep->accum != nullptr;
-        const __amdgpu_buffer_rsrc_t ry = make_rsrc(ep->y + (long)b * C * T, slab);
-        const __amdgpu_buffer_rsrc_t racc = make_rsrc(has_accum ? ep->accum + (long)b * C * T : nullptr, has_accum ? slab : 0);
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(ep->y + (long)b * creal * T, slab);
+        const __amdgpu_buffer_rsrc_t racc = make_rsrc(has_accum ? ep->accum + (long)b * creal * T : nullptr, has_accum ? slab : 0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int row0 = (wm * MI + mi) * 32;
@@ -382,6 +386,8 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
         if (a.variant == 2 && a.c == 64) return resblock_pair_launch_cfg<K, D, 64, 2, 2, 1>(a, st);
     }
     switch (a.c) {
+        case 8:
+        case 16:   // zero-padded to the 32-channel tile (the caller passes the weight images of the padded conv)
         case 32: return resblock_pair_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:
             // k = 11: the 8-wave / 256-column tile (4 % halo work instead of 8 %) wins by 3 %; k = 3, 7: the 4-wave tile
@@ -389,7 +395,7 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
             return resblock_pair_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
         case 128: return resblock_pair_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
     }
-    set_error("resblock_pair: c = %d has no instantiation (32, 64, 128)", a.c);
+    set_error("resblock_pair: c = %d has no instantiation (8, 16, 32, 64, 128)", a.c);
     return TTSAMD_ERR_UNSUPPORTED;
 }
 

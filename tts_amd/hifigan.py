@@ -58,12 +58,12 @@ class HifiganGenerator:
         # request, one stream when the request runs inside parallel.Lanes with two or more lanes (parallel.active_lanes)
         self.concurrent_branches = "auto"
         # ResBlock1 iterations (lrelu -> conv(k,d) -> lrelu -> conv(k,1) -> +x) run as ONE fused launch where the kernel
-        # covers the shape (C in {32,64,128} per `fuse_channels`, split-bf16 arithmetic): the intermediate tensor stays in
+        # covers the shape (C in {8,16,32,64,128} per `fuse_channels`, split-bf16 arithmetic): the intermediate tensor stays in
         # LDS, 5 HBM tensor passes -> 2.  Bitwise equal to the unfused pair.
         # Measured at the benchmark's stage shapes (scripts/resblock_ab.py, fused / unfused time): C=32 0.59-0.83,
         # C=64 0.66-0.92, C=128 0.88 (k=3), 1.00 (k=7), 1.07 (k=11) -> the 128-channel stage fuses its k=3 blocks only.
         self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
-        self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "32,64,128").split(",") if c)
+        self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "8,16,32,64,128").split(",") if c)
         self.fuse_max_kernel = {128: 3}     # channel count -> largest kernel size fused (absent = all)
         self._side_streams = {}     # current stream handle -> its MRF branch streams
         # A single utterance through the vocoder is ~110 launches of a few microseconds each on up to four streams: issued

@@ -117,6 +117,17 @@ class PackedConv:
                                                  self.c_out, self.c_in, self.kernel), "conv1d_pack_weights_split")
         self.w_split = split.to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+        # square convs of fewer than 32 channels also keep the split image of the weight zero-padded to [32, 32, k]: what the
+        # fused ResBlock kernel's 32-channel tile reads (ttsamd_resblock_pair, c = 8 / 16)
+        self.w_split_pad32 = None
+        if self.c_out == self.c_in and self.c_out in (8, 16):
+            wp = torch.zeros(32, 32, self.kernel, dtype=torch.float32)
+            wp[: self.c_out, : self.c_in] = w
+            nbp = L.ttsamd_conv1d_packed_split_bytes(32, 32, self.kernel)
+            sp = torch.empty(nbp, dtype=torch.uint8)
+            check(L.ttsamd_conv1d_pack_weights_split(ctypes.c_void_p(sp.data_ptr()), ctypes.c_void_p(wp.data_ptr()), 32, 32,
+                                                     self.kernel), "conv1d_pack_weights_split")
+            self.w_split_pad32 = sp.to(device)
 
     def nbytes(self):
         return self.w.numel() * 4 + (0 if self.bias is None else self.bias.numel() * 4)
@@ -193,13 +204,15 @@ def resblock_pair_supported(pc1: PackedConv, pc2: PackedConv):
 
 def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, accum=None, out_div=0.0, variant=0):
     """y = conv2(lrelu(conv1(lrelu(x*mask)) * mask)) + x [+ accum] [/ out_div] as ONE launch (ttsamd_resblock_pair):
-    one ResBlock1 iteration, hifigan_generator.py:90-98.  Bitwise equal to the two conv1d launches it replaces."""
+    one ResBlock1 iteration, hifigan_generator.py:90-98.  Bitwise equal to the two conv1d launches it replaces (C = 8 / 16 run
+    zero-padded on the 32-channel tile: equal up to the sign of zeros)."""
     B, C, T = x.shape
     assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and x.dtype == y.dtype == torch.float32
     assert accum is None or (accum.is_contiguous() and accum.shape == x.shape)
     a = ResblockArgs()
     a.x, a.y, a.accum, a.mask = x.data_ptr(), y.data_ptr(), _dp(accum), _dp(mask)
-    a.w1_split, a.bias1, a.w2_split, a.bias2 = pc1.w_split.data_ptr(), _dp(pc1.bias), pc2.w_split.data_ptr(), _dp(pc2.bias)
+    ws1, ws2 = (pc1.w_split, pc2.w_split) if C >= 32 else (pc1.w_split_pad32, pc2.w_split_pad32)
+    a.w1_split, a.bias1, a.w2_split, a.bias2 = ws1.data_ptr(), _dp(pc1.bias), ws2.data_ptr(), _dp(pc2.bias)
     a.c, a.t, a.batch, a.kernel, a.dilation = C, T, B, pc1.kernel, pc1.dilation
     a.slope, a.out_div, a.variant = slope, out_div, variant
     if _TIMER is not None and not torch.cuda.is_current_stream_capturing():
