@@ -219,7 +219,8 @@ int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
  *   v       = act(v)   (NONE | RELU | GELU(erf))
  *   v       = post_res[c,t] + v                              (if post_res)
  *   y[c,t]  = v * out_mask[t]                                (if out_mask)
- * Limit: C <= 512. */
+ * Any channel count (up to 512 a thread keeps its channels in registers between the passes; beyond, the passes re-read x:
+ * y must then not alias x). */
 typedef struct ttsamd_norm_args {
     const float *x;
     int64_t x_bstride, x_rstride;
