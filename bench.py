@@ -159,14 +159,20 @@ def base_line(args, ctx, metric, value, unit, elapsed_max, workload, dtype, high
 
 
 def code_stamp():
-    """sha256 over the kernel sources (tts_amd/csrc/*, include/*.h), first 16 hex digits: what a PMC file must have been
-    recorded with for its figures to describe the code that is running (the GPU box has no .git)."""
+    """sha256 over the kernel sources (tts_amd/csrc/*, include/*.h) with comments and whitespace stripped, first 16 hex
+    digits: what a PMC file must have been recorded with for its figures to describe the code that is running (the GPU box
+    has no .git; an edit to a comment does not make a measurement stale)."""
+    import re
+
     h = hashlib.sha256()
     for d in ("tts_amd/csrc", "include"):
         for f in sorted(os.listdir(os.path.join(ROOT, d))):
             if f.endswith((".hip", ".h")):
+                src = open(os.path.join(ROOT, d, f), "r", encoding="utf-8", errors="replace").read()
+                src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+                src = re.sub(r"//[^\n]*", "", src)
                 h.update(f.encode())
-                h.update(open(os.path.join(ROOT, d, f), "rb").read())
+                h.update("".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
