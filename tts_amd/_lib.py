@@ -83,6 +83,10 @@ class OwnedStream:
 
     def __del__(self):
         try:
+            import sys
+
+            if sys.is_finalizing():          # the HIP runtime may already be gone at interpreter exit: leave the stream to it
+                return
             if getattr(self, "handle", None):
                 _lib.ttsamd_stream_destroy(ctypes.c_void_p(self.handle))
                 self.handle = None
