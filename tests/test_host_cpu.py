@@ -247,3 +247,27 @@ def test_speaker_and_language_managers(tmp_path):
                                            "datasets": [{"name": "a", "language": "fr"}, {"name": "b", "language": "de"}]})
     assert lm.name_to_id == {"de": 0, "fr": 1}
     assert LanguageManager.init_from_config({"model_args": {"use_language_embedding": False}}) is None
+
+
+def test_text_bucket_outputs_are_cut_back_to_the_callers_token_count():
+    """Vits / GlowTTS run graphed requests with the token axis padded to a multiple of 16; `_cut_text` returns every
+    token-indexed output at the caller's length (frame-indexed outputs are untouched)."""
+    import torch
+
+    from tts_amd.glow_tts import GlowTTS
+    from tts_amd.vits import Vits
+
+    T0, T, F = 21, 32, 57
+    v = {"alignments": torch.arange(2 * T * F).float().view(2, T, F), "durations": torch.ones(2, 1, T), "x": torch.zeros(2, 4, T),
+         "logw": torch.zeros(2, 1, T), "z": torch.zeros(2, 4, F)}
+    out = Vits._cut_text(dict(v), T0, T)
+    assert out["alignments"].shape == (2, T0, F) and out["durations"].shape == (2, 1, T0)
+    assert out["x"].shape == (2, 4, T0) and out["logw"].shape == (2, 1, T0) and out["z"].shape == (2, 4, F)
+    assert torch.equal(out["alignments"], v["alignments"][:, :T0]) and out["alignments"].is_contiguous()
+    assert Vits._cut_text(dict(v), T, T)["alignments"].shape == (2, T, F)              # no bucket: untouched
+    g = {"alignments": torch.zeros(2, F, T), "durations": torch.ones(2, 1, T), "durations_log": torch.zeros(2, T, 1),
+         "total_durations_log": torch.zeros(2, T, 1), "model_outputs": torch.zeros(2, F, 80)}
+    out = GlowTTS._cut_text(dict(g), T0, T)
+    assert out["alignments"].shape == (2, F, T0) and out["durations"].shape == (2, 1, T0)
+    assert out["durations_log"].shape == (2, T0, 1) and out["total_durations_log"].shape == (2, T0, 1)
+    assert out["model_outputs"].shape == (2, F, 80)
