@@ -53,3 +53,23 @@ for mode, extra in (("eager tail (front end graphed)", {"no_graph_tail": True}),
           "sync => host issue %.2f ms, rtf_x=%.0f"
           % (B, mode, dt * 1e3, t_issue / n * 1e3, _blocked[0] / n * 1e3, (t_issue - _blocked[0]) / n * 1e3,
              B * 197120 / 22050 / dt), flush=True)
+
+# request THROUGHPUT with several requests in flight (tts_amd.parallel.Lanes; inside a lane the generator runs its MRF branches
+# on the lane's own stream): ms per request over 40 back-to-back requests
+from tts_amd import parallel  # noqa: E402
+
+aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True, "ragged_exact": B > 1}
+m.graph_tail_max_frames = 1 << 20
+for nl, pr in ((1, -1), (2, -1), (2, 0), (3, -1)):
+    lanes = parallel.Lanes(nl, device=dev, priority=pr)
+    for _ in range(6):
+        lanes.run(m.inference, x, aux)
+    lanes.sync()
+    n = 40
+    t0 = time.perf_counter()
+    for _ in range(n):
+        lanes.run(m.inference, x, aux)
+    lanes.sync(timeout_s=60.0)
+    dt = (time.perf_counter() - t0) / n
+    print("B=%d %d lane(s), priority %2d: %.2f ms per request (%.0f requests/s, rtf_x=%.0f)"
+          % (B, nl, pr, dt * 1e3, 1.0 / dt, B * 197120 / 22050 / dt), flush=True)

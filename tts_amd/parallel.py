@@ -108,6 +108,8 @@ class Lanes:
         # otherwise every one of the front end's ~170 dependent launches queues behind a chip-filling decoder kernel.
         from . import _lib
 
+        if int(n) <= 1:
+            priority = 0       # a lone lane keeps its MRF branch streams (normal priority): same priority, no cross-priority waits
         self._owned = [_lib.OwnedStream(device, priority) for _ in range(max(1, int(n)))]    # dedicated, never pool-aliased
         self.streams = [o.stream for o in self._owned]
         self._next = 0
