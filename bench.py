@@ -106,20 +106,24 @@ class Ctx:
             self.dev = torch.device("cuda", self.local_rank)
         else:
             self.dev = torch.device("cpu")
-        if self.world > 1:
+        # --force-pg: the process group (RCCL communicator, barrier, all-reduce, weight broadcast) also at world size 1 —
+        # the multi-GPU code path on the one GPU a test box has
+        self.pg = self.world > 1 or bool(getattr(args, "force_pg", False))
+        if self.pg:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
             kw = {"device_id": self.dev} if self.backend == "nccl" else {}
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
 
     def fence(self):
-        if self.world > 1:
+        if self.pg:
             self.dist.barrier()
         if self.gpu:
             torch.cuda.synchronize()
 
     def _reduce(self, v, op):
         t = torch.tensor([float(v)], dtype=torch.float64, device=self.dev)
-        if self.world > 1:
+        if self.pg:
             self.dist.all_reduce(t, op=op)
         return float(t.item())
 
@@ -137,13 +141,18 @@ class Ctx:
         sd = make_sd() if self.rank == 0 else None
         self.fence()
         t0 = time.perf_counter()
-        sd = parallel.broadcast_state_dict(sd, src=0, device=self.dev)
+        src = sd
+        sd = parallel.broadcast_state_dict(sd, src=0, device=self.dev, force=self.pg)
         self.fence()
         dt = time.perf_counter() - t0
+        if self.pg and self.rank == 0:      # the blob came back through the collective: every tensor must be bit-identical
+            bad = [k for k in src if not torch.equal(src[k].cpu(), sd[k])]
+            if bad:
+                raise SystemExit("bench.py: weight broadcast changed %d tensors (first: %s)" % (len(bad), bad[0]))
         return sd, self.max(dt), 4 * sum(v.numel() for v in sd.values())
 
     def close(self):
-        if self.world > 1:
+        if self.pg:
             self.dist.barrier()
             self.dist.destroy_process_group()
 
@@ -226,12 +235,14 @@ def cpu_thread_candidates():
     return c, cores
 
 
-def cpu_sweep(run, warm=None, reps_best=2):
+def cpu_sweep(run, warm=None, reps=3):
     """The CPU's best, not an over-subscribed number: `run()` (returns the units it processed) is timed once per thread
-    count after one `warm()` (default: `run`) at that count; the fastest count then gets `reps_best` more repetitions.
-    -> (units/s at the best count, best thread count, host cores, {threads: units/s}, seconds per run at the best count)."""
+    count after one `warm()` (default: `run`) at that count; the fastest count is then timed `reps` (>= 3) more times and
+    the MEDIAN of those repetitions is the reported rate (1 warm-up + >= 3 timed reps), min / max beside it.
+    -> dict(rate, threads, host_cores, table {threads: units/s}, sec (median seconds per run), reps, rate_min, rate_max)."""
     cands, cores = cpu_thread_candidates()
     table = {}
+    reps = max(int(reps), 3)
     with torch.no_grad():
         for t in cands:
             torch.set_num_threads(t)
@@ -241,11 +252,24 @@ def cpu_sweep(run, warm=None, reps_best=2):
             table[t] = units / (time.perf_counter() - t0)
         best = max(table, key=table.get)
         torch.set_num_threads(best)
-        t0 = time.perf_counter()
-        units = sum(run() for _ in range(reps_best))
-        dt = time.perf_counter() - t0
-    rate = max(units / dt, table[best])
-    return rate, best, cores, {str(k): float("%.4g" % v) for k, v in table.items()}, dt / reps_best
+        run()                                              # warm again at the winning count (the sweep left another count's pool)
+        secs, units = [], 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            units = run()
+            secs.append(time.perf_counter() - t0)
+    secs.sort()
+    med = secs[len(secs) // 2] if len(secs) % 2 else 0.5 * (secs[len(secs) // 2 - 1] + secs[len(secs) // 2])
+    return {"rate": units / med, "threads": best, "host_cores": cores,
+            "table": {str(k): float("%.4g" % v) for k, v in table.items()}, "sec": med, "reps": reps,
+            "rate_min": units / secs[-1], "rate_max": units / secs[0]}
+
+
+def cpu_entry(sw, unit, sample):
+    """The `cpu_baseline` object of a bench line from a cpu_sweep result: value = median of the timed repetitions."""
+    return {"value": sw["rate"], "unit": unit, "cores": sw["threads"], "kind": "port", "host_cores": sw["host_cores"],
+            "reps": sw["reps"], "value_min": sw["rate_min"], "value_max": sw["rate_max"],
+            "threads_sweep_" + unit.replace("/", "_per_"): sw["table"], "sample": sample}
 
 
 def cpu_baseline_vits(sd, n_chars):
@@ -266,12 +290,36 @@ def cpu_baseline_vits(sd, n_chars):
         out = O.vits_inference(sd, x, xl, {}, noise_dp=noise_dp, durations=dur.view(1, 1, -1))
         return out["model_outputs"].shape[-1]
 
-    rate, best, cores, table, sec = cpu_sweep(run, warm, reps_best=1)
-    return {"value": rate, "unit": "samples/s", "cores": best, "kind": "port", "host_cores": cores,
-            "threads_sweep_samples_per_s": table,
-            "sample": "1 utterance of %d chars (197120 samples) per run, B=1 as the reference's sentence loop; oracle "
-                      "(torch fp32 CPU ops) at the best of the thread sweep: %d threads of %d cores, %.2f s/utterance, "
-                      "rtf_x=%.1f" % (n_chars, best, cores, sec, rate / SAMPLE_RATE)}
+    sw = cpu_sweep(run, warm, reps=3)
+    out = cpu_entry(sw, "samples/s",
+                    "1 utterance of %d chars (197120 samples) per run, B=1 as the reference's sentence loop; oracle (torch fp32 "
+                    "CPU ops), median of %d timed reps at the best of the thread sweep: %d threads of %d cores, %.2f "
+                    "s/utterance, rtf_x=%.1f" % (n_chars, sw["reps"], sw["threads"], sw["host_cores"], sw["sec"],
+                                                 sw["rate"] / SAMPLE_RATE))
+    # SURVEY §8d also asks for the batched `x_lengths` mode: 4 ragged utterances in one oracle call at the same thread count
+    nb = 4
+    xb, xlb, durb = synthetic_batch(nb, n_chars, 1, "cpu")
+    xlb = torch.tensor([x.shape[1], x.shape[1] - 20, x.shape[1] - 40, x.shape[1] - 57])
+    durb = durb * (torch.arange(x.shape[1])[None, :] < xlb[:, None]).float()
+    nzb = torch.randn(nb, 2, x.shape[1])
+
+    def run_b():
+        O.vits_inference(sd, xb, xlb, {}, noise_dp=nzb, stop_after="prior")
+        o = O.vits_inference(sd, xb, xlb, {}, noise_dp=nzb, durations=durb.view(nb, 1, -1))
+        return int(o["y_mask"].sum().item()) * 256
+
+    with torch.no_grad():
+        torch.set_num_threads(sw["threads"])
+        run_b()
+        secs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            units = run_b()
+            secs.append(time.perf_counter() - t0)
+    secs.sort()
+    out["batched_x_lengths_mode"] = {"value": units / secs[1], "unit": "samples/s", "batch": nb, "reps": 3,
+                                     "value_min": units / secs[2], "value_max": units / secs[0], "threads": sw["threads"]}
+    return out
 
 
 def wl_vits_e2e(args, ctx):
@@ -370,7 +418,12 @@ def wl_vits_e2e(args, ctx):
         "kernel": conv_kernel_name(args.precision, "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0")
                   + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
         "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
-        "frac": ach / conv_peak(args.precision), "traffic": load_pmc(pmc), "traffic_source": pmc_state(pmc),
+        "frac": ach / conv_peak(args.precision),
+        # SURVEY §8(d) asks for both of its own rooflines per kernel: algorithmic bytes against 8 TB/s and algorithmic FLOP
+        # against the 157.3 TF fp32 vector/fp32-MFMA peak (the split-bf16 kernels run on the bf16 pipe, so this one can exceed 1)
+        "frac_of_8TBps": (dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS) if dom["launches"] else 0.0,
+        "frac_of_157TF": ach / PEAK_FP32_MFMA_TFLOPS,
+        "traffic": load_pmc(pmc), "traffic_source": pmc_state(pmc),
         # from the same PMC passes: fraction of kernel cycles the matrix pipe is busy and the kernel's cycle count
         "pmc_mfma_busy_frac": load_pmc(pmc, "mfma_busy_frac"), "pmc_kernel_cycles": load_pmc(pmc, "kernel_cycles"),
         "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B) / HIP-event launch time; peak = bf16 dense MFMA "
@@ -471,11 +524,11 @@ def wl_glow_hifigan_v2(args, ctx):
             voc_in = ap_v.normalize(ap_t.denormalize(mel.T))                      # synthesizer.py:414-416 (numpy seam)
             return O.hifigan_inference(hsd, "", torch.from_numpy(voc_in).unsqueeze(0), hcfg).shape[-1]
 
-        rate, best, cores, table, sec = cpu_sweep(cpu_step, reps_best=5)
-        line["cpu_baseline"] = {"value": rate, "unit": "samples/s", "cores": best, "kind": "port", "host_cores": cores,
-                                "threads_sweep_samples_per_s": table,
-                                "sample": "the same sentence (%d samples) through the oracle + numpy seam, best of the "
-                                          "thread sweep: %d threads of %d cores, %.1f ms per sentence" % (samples, best, cores, sec * 1e3)}
+        sw = cpu_sweep(cpu_step, reps=5)
+        line["cpu_baseline"] = cpu_entry(sw, "samples/s",
+                                         "the same sentence (%d samples) through the oracle + numpy seam, median of %d timed reps "
+                                         "at the best of the thread sweep: %d threads of %d cores, %.1f ms per sentence"
+                                         % (samples, sw["reps"], sw["threads"], sw["host_cores"], sw["sec"] * 1e3))
     del glow, voc
     return line
 
@@ -585,12 +638,11 @@ def wl_hifigan_v1(args, ctx):
         def cpu_run():
             return O.hifigan_inference(csd, "", cmel, cfg).shape[-1]
 
-        rate, best, cores, table, sec = cpu_sweep(cpu_run, warm=lambda: O.hifigan_inference(csd, "", cmel[:, :, :64], cfg),
-                                                  reps_best=1)
-        line["cpu_baseline"] = {"value": rate, "unit": "samples/s", "cores": best, "kind": "port", "host_cores": cores,
-                                "threads_sweep_samples_per_s": table,
-                                "sample": "1 item x 1024 frames (264 704 samples) of the same generator through the oracle, "
-                                          "best of the thread sweep: %d threads of %d cores, %.2f s per run" % (best, cores, sec)}
+        sw = cpu_sweep(cpu_run, warm=lambda: O.hifigan_inference(csd, "", cmel[:, :, :64], cfg), reps=3)
+        line["cpu_baseline"] = cpu_entry(sw, "samples/s",
+                                         "1 item x 1024 frames (264 704 samples) of the same generator through the oracle, median "
+                                         "of %d timed reps at the best of the thread sweep: %d threads of %d cores, %.2f s per run"
+                                         % (sw["reps"], sw["threads"], sw["host_cores"], sw["sec"]))
     del m
     return line
 
@@ -739,7 +791,9 @@ def wl_launch_check(args, ctx):
     body — runs without a GPU on gloo (tests/test_parallel.py drives `bench.py --gpus 2 --workload launch_check`)."""
     from tts_amd import synthetic as W
 
-    sd, bcast_s, bcast_bytes = ctx.broadcast_weights(lambda: W.make_hifigan_state(dict(W.HIFIGAN_V2), 80, seed=7))
+    big = ctx.gpu            # on GPUs the blob is the real one: the 116 MB VITS state_dict of the headline workload
+    sd, bcast_s, bcast_bytes = ctx.broadcast_weights(
+        (lambda: W.make_vits_state({}, seed=1234)) if big else (lambda: W.make_hifigan_state(dict(W.HIFIGAN_V2), 80, seed=7)))
     digest = float(sum(float(v.double().sum()) for v in sd.values()))
     same = ctx.max(digest) == -ctx.max(-digest)                    # identical weights on every rank
     units = 1000 + ctx.rank
@@ -753,7 +807,7 @@ def wl_launch_check(args, ctx):
     if ctx.rank != 0:
         return None
     line = base_line(args, ctx, "launch check (no kernels)", total * args.steps / elapsed_max, "units/s", elapsed_max,
-                     "launcher skeleton", "none", backend=ctx.backend, weights_identical=bool(same),
+                     "launcher skeleton", "none", backend=ctx.backend, process_group=bool(ctx.pg), weights_identical=bool(same),
                      weight_broadcast_s=bcast_s, weight_broadcast_bytes=bcast_bytes, units_per_step_all_ranks=total,
                      slowest_rank_floor_s=0.01 * ctx.world * args.steps)
     # the same printer as the GPU workloads (tests/test_parallel.py checks the output contract on it): a bulky detail
@@ -801,6 +855,9 @@ def main():
     ap.add_argument("--hifigan-steps", type=int, default=None, help="hifigan_v1: timed steps (default --steps; 1 as an extra)")
     ap.add_argument("--hifigan-warmup", type=int, default=None)
     ap.add_argument("--mas-batch", type=int, default=32, help="mas: items per GPU")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="initialise the process group and run the weight broadcast / barriers / reductions through it even "
+                         "with ONE rank (exercises the RCCL path on a single GPU)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="process-group backend (default: nccl = RCCL on GPUs; gloo only for launch_check on CPU)")
     args = ap.parse_args()
@@ -813,6 +870,20 @@ def main():
         raise SystemExit(self_launch(args, sys.argv[1:]))
     if args.workload != "launch_check" and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    try:
+        _run(args)
+    except BaseException as e:          # every rank says which one it is before it goes down (torchrun interleaves stderr)
+        if not isinstance(e, SystemExit) or e.code not in (0, None):
+            import traceback
+
+            sys.stderr.write("[bench.py rank %s/%s host %s] %s: %s\n%s" % (
+                os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"), socket.gethostname(), type(e).__name__, e,
+                "" if isinstance(e, SystemExit) else traceback.format_exc()))
+            sys.stderr.flush()
+        raise
+
+
+def _run(args):
     ctx = Ctx(args)
     if args.workload != "launch_check":
         from tts_amd import ops
@@ -823,9 +894,10 @@ def main():
 
     line = WORKLOADS[args.workload](args, ctx)
     emit_details(ctx)
+    extras = []
     if args.workload == "vits_e2e" and ctx.world == 1 and not args.no_extras:
-        # The other single-GPU BASELINE configs, each measured in its OWN fresh process after the headline's timed region
-        # and printed as its own line before the headline line.  Not in this process: a HIP event recorded with timing
+        # The other single-GPU BASELINE configs, each measured in its OWN fresh process after the headline's timed region.
+        # Not in this process: a HIP event recorded with timing
         # (the roofline passes bracket every conv launch with them) switches its hardware queue to profiling mode for the
         # rest of the process, and every later dispatch on that queue then pays a few microseconds of completion-signal
         # handling — invisible in a 76 ms step, +75 % on the 330-launch single-sentence line (measured round 3: 3.2 ms in a
@@ -844,13 +916,26 @@ def main():
                                    timeout=600, cwd=ROOT)
                 rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 for ln in rows[:-1]:
-                    print(ln, flush=True)                                  # the child's detail tables
+                    print(ln, flush=True)                                  # the child's detail tables (incl. its full line)
                 extra = json.loads(rows[-1]) if (r.returncode == 0 and rows) else {"error": "rc=%d %s" % (r.returncode, r.stderr[-400:])}
             except Exception as e:          # an extra must never cost the headline line
                 extra = {"error": "%s: %s" % (type(e).__name__, e)}
-            print(json.dumps({"extra_workload": name, "line": extra}), flush=True)
+            extras.append((name, extra))
     if ctx.rank == 0:
-        print(headline_json(line), flush=True)
+        # Output contract (round 4): every bulky object first — tables, then each line IN FULL as a {"detail": ...} object —
+        # and the compact lines LAST: configs[0], configs[2], headline (< 4 KB together), so that all three sit in whatever
+        # tail of stdout the driver keeps.  The headline also carries a two-number summary of the other two configs.
+        print(json.dumps({"detail": "full line of %s (every field; the compact line below drops explanatory strings only)"
+                                    % line.get("config", {}).get("workload", args.workload)[:40], "line": line}), flush=True)
+        for name, extra in extras:
+            print(json.dumps({"extra_workload": name, "line": compact_line(extra)}), flush=True)
+        if extras:
+            line["other_configs"] = {name.split()[0]: {k: (float("%.5g" % v) if isinstance(v, float) else v) for k, v in (
+                ("ms_per_step", e.get("ms_per_step")), ("value", e.get("value")), ("unit", e.get("unit")),
+                ("roofline_frac", (e.get("roofline") or {}).get("frac")),
+                ("cpu_baseline_value", (e.get("cpu_baseline") or {}).get("value")), ("error", e.get("error"))) if v is not None}
+                for name, e in extras}
+        print(headline_json(compact_line(line, limit=None)), flush=True)
     ctx.close()
 
 
@@ -861,15 +946,61 @@ def emit_details(ctx):
     del DETAILS[:]
 
 
-HEADLINE_MAX_BYTES = 4000
+HEADLINE_MAX_BYTES = 2300
+EXTRA_MAX_BYTES = 800
+_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_8TBps", "frac_of_157TF", "traffic",
+              "pmc_mfma_busy_frac", "pmc_kernel_cycles", "launches_timed", "avg_launch_us", "algorithmic_bytes_per_launch",
+              "all_conv_launches", "hbm_subset_best_frac_of_8TBps", "traffic_source", "launches_per_request")
+_CPU_KEEP = ("value", "unit", "cores", "kind", "host_cores", "reps", "value_min", "value_max", "batched_x_lengths_mode", "sample")
+
+
+def _round(v):
+    if isinstance(v, float):
+        return float("%.6g" % v)
+    if isinstance(v, dict):
+        return {k: _round(x) for k, x in v.items()}
+    return v
+
+
+def compact_line(line, limit=EXTRA_MAX_BYTES):
+    """A bench line without its prose: every number stays (rounded to 6 significant digits), explanatory strings are cut or
+    dropped.  With a byte `limit` (the extra-workload lines) optional fields go until it fits."""
+    if "error" in line and "metric" not in line:
+        return line
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data", "rtf_x", "rtf_x_per_gpu", "other_configs") if k in line}
+    cfg = dict(line.get("config", {}))
+    cfg.pop("weights", None)
+    out["config"] = cfg
+    if "roofline" in line:
+        out["roofline"] = {k: line["roofline"][k] for k in _ROOF_KEEP if k in line["roofline"]}
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = {k: line["cpu_baseline"][k] for k in _CPU_KEEP if k in line["cpu_baseline"]}
+    out = _round(out)
+    if limit is None:
+        return out
+    out["dtype"] = str(out.get("dtype", ""))[:4].strip()
+    out["metric"] = str(out["metric"])[:80]
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:60]}
+    for path in (("cpu_baseline", "sample"), ("roofline", "traffic_source"), ("roofline", "kernel"), ("roofline", "all_conv_launches"),
+                 ("cpu_baseline", "batched_x_lengths_mode"), ("roofline", "algorithmic_bytes_per_launch"), ("cpu_baseline", "host_cores"),
+                 ("data",), ("scaling",), ("vs_baseline",), ("higher_is_better",)):
+        if len(json.dumps(out)) <= limit:
+            break
+        d = out
+        for k in path[:-1]:
+            d = d.get(k, {})
+        d.pop(path[-1], None)
+    return out
 
 
 def headline_json(line):
-    """The last line of the run: compact by contract.  If a future field pushes it over the limit, explanatory strings
-    are dropped first (never a number)."""
+    """The last line of the run: compact by contract.  If a field pushes it over the limit, explanatory strings
+    are dropped first (never a number that the contract names)."""
     out = json.dumps(line)
     for path in (("roofline", "peak_note"), ("roofline", "measured"), ("roofline", "traffic_source"), ("cpu_baseline", "sample"),
-                 ("cpu_baseline", "threads_sweep_samples_per_s"), ("config", "weights"), ("roofline", "all_conv_launches")):
+                 ("cpu_baseline", "threads_sweep_samples_per_s"), ("config", "weights"), ("roofline", "all_conv_launches"),
+                 ("cpu_baseline", "batched_x_lengths_mode"), ("roofline", "kernel")):
         if len(out) <= HEADLINE_MAX_BYTES:
             break
         d = line

@@ -202,7 +202,12 @@ typedef struct ttsamd_resblock_args {
     float slope;            /* leaky-ReLU slope of both activations */
     float out_div;
     int32_t variant;        /* 0 = default tile; other values select alternative tiles (measurement only) */
+    int64_t w1_bytes, w2_bytes; /* ABI v2: size of each split image; must equal ttsamd_resblock_weight_bytes(c, kernel) — the
+                                   kernel walks whole 32-channel tiles (c = 8 / 16: the image of the [32, 32, k] padded weight) */
 } ttsamd_resblock_args;
+/* bytes of the split-bf16 weight image ttsamd_resblock_pair reads for a c-channel pair (= ttsamd_conv1d_packed_split_bytes of
+ * the [max(c,32), max(c,32), kernel] weight) */
+size_t ttsamd_resblock_weight_bytes(int c, int kernel);
 int ttsamd_resblock_pair(const ttsamd_resblock_args *args /* host */, void *stream);
 int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
 
@@ -303,6 +308,15 @@ int ttsamd_sdp_affine_reverse(float *z_out, const float *z_in, const float *m, c
 int ttsamd_durations(float *durations, int32_t *cum, int64_t *y_lengths, const float *logw,
                      const float *durations_in, const float *mask, float length_scale, int glow, int batch,
                      int t, void *stream);
+/* The same with two extras (ABI v2):
+ *   t_valid: columns t >= t_valid own no frames whatever the rule (a request padded to a text-length bucket: the reference's
+ *     clamp_min(.,1) still gives every column of the CALLER's tensor a frame, masked or not — glow_tts.py:350-351 — and the
+ *     bucket's own padding none); pass t for "all columns are the caller's".
+ *   y_lengths_host (or NULL): host-mapped (pinned) mirror of y_lengths, written with a system-scope release store — the host
+ *     sets it to -1 before the call and polls it instead of a stream synchronise + device-to-host copy. */
+int ttsamd_durations_ex(float *durations, int32_t *cum, int64_t *y_lengths, int64_t *y_lengths_host, const float *logw,
+                        const float *durations_in, const float *mask, float length_scale, int glow, int t_valid,
+                        int batch, int t, void *stream);
 
 /* generate_path (helpers.py:154-169): attn[b,x,y] = (cum[b,x-1] <= y < cum[b,x]) * x_mask[b,x] * (y < y_lengths[b]). */
 int ttsamd_generate_path(float *attn, const int32_t *cum, const float *x_mask, const int64_t *y_lengths,

@@ -553,6 +553,15 @@ def vits_language_emb(sd, language_ids):
     return None if language_ids is None else F.embedding(language_ids, sd["emb_l.weight"]).unsqueeze(-1)
 
 
+def interpolate_vocoder_input(scale_factor, spec):
+    """TTS/vocoder/utils/generic_utils.py:11-29 (called at synthesizer.py:418-424 when the TTS and vocoder sample rates
+    differ): spec numpy [C, T] -> tensor [1, C, T'] by bilinear interpolation with scale_factor = [1, sr_vocoder / sr_tts],
+    recompute_scale_factor=True, align_corners=False."""
+    spec = torch.tensor(spec).unsqueeze(0).unsqueeze(0)
+    return F.interpolate(spec, scale_factor=scale_factor, recompute_scale_factor=True, mode="bilinear",
+                         align_corners=False).squeeze(0)
+
+
 def vits_inference(sd, tokens, x_lengths=None, args=None, noise_dp=None, noise_z=None, durations=None,
                    stop_after=None, g=None, lang_emb=None):
     """Vits.inference, vits.py:1088-1173 (g: speaker conditioning [B,C,1]; lang_emb: language embedding [B,L,1]).

@@ -146,6 +146,29 @@ def test_inference_slabbed_equals_inference_bitwise(gpu):
     assert torch.equal(host, want.cpu())
 
 
+def test_inference_slabbed_full_width_against_oracle(gpu):
+    """A parity point on the configs[2] path at the generator's real width (HiFiGAN-v1, 512 channels): five 700-frame mels
+    (190 K samples each — every stage runs many time tiles of the large-grid kernels) through `inference_slabbed` cut into
+    slabs of 2, 2, 1 items; the first item of the first slab, the item at a slab boundary and the lone item of the last slab
+    against oracle runs on those items alone, and the whole call against the unslabbed one."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = dict(W.HIFIGAN_V1)
+    sd = O.make_hifigan_state(cfg, 80, seed=23)
+    m = _make(cfg, 80, gpu, sd)
+    B, T = 5, 700
+    mel = torch.randn(B, 80, T, generator=torch.Generator().manual_seed(6))
+    widest = max((512 >> (i + 1)) * h for i, h in enumerate((8, 64, 128, 256)))
+    per_item = 6 * 4 * widest * (T + 10)
+    got = m.inference_slabbed(mel.to(gpu), max_live_bytes=2 * per_item + 1)
+    assert got.shape == (B, 1, (T + 10) * 256)
+    whole = m.inference(mel.to(gpu))
+    assert _errs(got, whole)[1] < 2e-6          # tile family may differ with the batch (fp32 reassociation), nothing more
+    for b in (0, 2, 4):
+        want = O.hifigan_inference(sd, "", mel[b:b + 1], cfg)
+        rms, rel = _errs(got[b:b + 1], want)
+        assert rms < 1e-4 and rel < 1e-5, (b, rms, rel)
+
+
 def test_single_item_inference_graph_equals_eager(gpu):
     """`inference` on one item replays as a hipGraph per 32-frame length bucket (the item runs ragged-exact inside the padded
     tensor): same waveform as the eager launches at the true length — for several lengths sharing a bucket, across capture

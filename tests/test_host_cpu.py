@@ -152,6 +152,15 @@ def test_split_into_sentences_reference_golden_strings():
     assert Synthesizer.split_into_sentences("The U.S. Army is big.") == ["The U.S. Army is big."]
     assert Synthesizer.split_into_sentences("See fig. 2 for details. It is clear.") == ["See fig. 2 for details.", "It is clear."]
     assert Synthesizer.split_into_sentences("He lives in the U.S. The next day he left.") == ["He lives in the U.S.", "The next day he left."]
+    # ordinary words that double as abbreviations end a sentence before any capitalised word (round-3 advisor finding: the
+    # sentence-starter rule had been applied to them and merged these)
+    for text, want in (("I said no. Then he left.", ["I said no.", "Then he left."]),
+                       ("The cat sat. Dogs barked.", ["The cat sat.", "Dogs barked."]),
+                       ("We bought apples, pears, etc. Then we left.", ["We bought apples, pears, etc.", "Then we left."]),
+                       ("It was 5 p.m. Nobody came.", ["It was 5 p.m.", "Nobody came."]),
+                       ("Take no. 5 please. Thanks.", ["Take no. 5 please.", "Thanks."]),
+                       ("Fruit, e.g. Apples, is good. Yes.", ["Fruit, e.g. Apples, is good.", "Yes."])):
+        assert Synthesizer.split_into_sentences(text) == want, text
 
 
 def test_audio_processor_norm_denorm_known_answers():

@@ -118,3 +118,26 @@ def test_oracle_forward_mas_matches_reference_method():
     out = O.vits_forward_mas(z_p, m_p, logs_p, x_mask, y_mask, cpu_mas)
     assert torch.equal(out["attn"], attn)
     assert torch.equal(out["attn_durations"], attn.sum(3))
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree absent (GPU box)")
+def test_oracle_interpolate_vocoder_input_matches_reference():
+    """oracle.interpolate_vocoder_input against the reference function compiled straight from
+    TTS/vocoder/utils/generic_utils.py:11-29 (the module itself imports librosa-dependent code)."""
+    import ast
+    import contextlib
+    import io
+
+    from oracle import tts_oracle as O
+
+    src = open(os.path.join(ref_shim.REF_ROOT, "TTS/vocoder/utils/generic_utils.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "interpolate_vocoder_input")
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "generic_utils.interpolate_vocoder_input", "exec"), ns)  # noqa: S102
+    rng = np.random.default_rng(0)
+    for t, ratio in ((37, 24000 / 22050), (120, 16000 / 22050), (5, 44100 / 22050)):
+        spec = rng.standard_normal((80, t)).astype(np.float32)
+        with contextlib.redirect_stdout(io.StringIO()):
+            want = ns["interpolate_vocoder_input"]([1, ratio], spec)
+        got = O.interpolate_vocoder_input([1, ratio], spec)
+        assert got.shape == want.shape and torch.equal(got, want)

@@ -95,3 +95,38 @@ def test_bench_headline_stays_compact():
     assert r["roofline"]["frac"] == 0.5 and r["cpu_baseline"]["value"] == 1.0 and r["value"] == 1.0
     # the stamp that ties a committed PMC file to the running kernel sources is stable and 16 hex digits
     assert bench.code_stamp() == bench.code_stamp() and len(bench.code_stamp()) == 16
+
+
+def test_bench_forced_process_group_world1_gloo():
+    """`--force-pg`: the process group, the weight broadcast (with the bit-identity check) and the reductions also run with
+    ONE rank — the switch tests/test_rccl_gpu.py uses to exercise RCCL on a single GPU, here on gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "launch_check", "--backend",
+                        "gloo", "--force-pg", "--steps", "2"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["config"]["process_group"] is True and r["config"]["weights_identical"] and r["n_gpus"] == 1
+
+
+def test_bench_compact_lines_fit_the_tail():
+    """bench.compact_line: an extra-workload line keeps every number the contract names and fits its byte budget; the three
+    closing lines of a default run (configs[0], configs[2], headline) stay under 4 KB together."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = {"metric": "audio samples/sec (" + "x" * 200 + ")", "value": 123456.789, "unit": "samples/s", "n_gpus": 1, "steps": 50,
+            "warmup": 5, "ms_per_step": 2.6745123, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (" + "d" * 90 + ")", "data": "synthetic", "rtf_x": 1423.85,
+            "config": {"workload": "configs[0]: " + "w" * 300, "weights": "r" * 200, "frames": 318},
+            "roofline": {"bound": "mfma", "kernel": "k" * 300, "achieved": 7.6, "peak": 416.667, "unit": "TFLOP/s", "frac": 0.0183,
+                         "traffic": None, "peak_note": "n" * 500, "launches_per_request": 140},
+            "cpu_baseline": {"value": 1.2e6, "unit": "samples/s", "cores": 16, "kind": "port", "host_cores": 256, "reps": 5,
+                             "value_min": 1.1e6, "value_max": 1.3e6, "threads_sweep_samples_per_s": {"8": 1.0, "16": 2.0},
+                             "sample": "s" * 400}}
+    c = bench.compact_line(json.loads(json.dumps(full)))
+    assert len(json.dumps(c)) <= bench.EXTRA_MAX_BYTES
+    assert c["value"] == float("%.6g" % full["value"]) and c["ms_per_step"] == float("%.6g" % full["ms_per_step"])
+    assert c["roofline"]["frac"] == 0.0183 and c["roofline"]["launches_per_request"] == 140
+    assert c["cpu_baseline"]["value"] == 1.2e6 and c["cpu_baseline"]["reps"] == 5 and c["cpu_baseline"]["cores"] == 16
+    head = bench.headline_json(bench.compact_line(json.loads(json.dumps(full)), limit=None))
+    assert len(head) <= bench.HEADLINE_MAX_BYTES and 2 * (bench.EXTRA_MAX_BYTES + 60) + bench.HEADLINE_MAX_BYTES <= 4096

@@ -7,6 +7,7 @@ HIP library is missing or a call fails this raises.
 import ctypes
 import os
 import re
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTSAMD_LIB_PATH") or os.path.join(_HERE, "libtts_amd.so")
@@ -65,6 +66,15 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_OWNERS = weakref.WeakValueDictionary()      # HIP stream handle -> the OwnedStream that will destroy it
+
+
+def stream_owner(handle):
+    """The live OwnedStream behind a raw stream handle (None for torch's own streams): whoever keeps work or graphs bound
+    to the stream holds this reference so the stream outlives them."""
+    return _OWNERS.get(int(handle)) if handle else None
+
+
 class OwnedStream:
     """A dedicated HIP stream created through the C ABI (ttsamd_stream_create) and wrapped for torch
     (`torch.cuda.ExternalStream`): unlike `torch.cuda.Stream()`, whose objects are handed out round-robin from a pool of
@@ -80,6 +90,7 @@ class OwnedStream:
             check(lib().ttsamd_stream_create(int(priority), ctypes.byref(h)), "stream_create")
         self.handle = h.value
         self.stream = torch.cuda.ExternalStream(self.handle, device=self.device)
+        _OWNERS[int(self.handle)] = self
 
     def __del__(self):
         try:

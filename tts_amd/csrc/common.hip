@@ -15,7 +15,7 @@ void set_error(const char *fmt, ...)
 }  // namespace ttsamd
 
 extern "C" const char *ttsamd_last_error(void) { return ttsamd::g_err; }
-extern "C" int ttsamd_abi_version(void) { return 1; }
+extern "C" int ttsamd_abi_version(void) { return 2; }   // 2: ttsamd_resblock_args carries the weight image sizes
 extern "C" const char *ttsamd_arch(void) { return "gfx950"; }
 
 extern "C" int ttsamd_stream_create(int priority, void **stream_out)

@@ -153,10 +153,11 @@ __global__ void sdp_affine_reverse_kernel(float *__restrict__ z_out, const float
 // ---- durations -> cumulative frame offsets -----------------------------------------------------
 __global__ __launch_bounds__(kTxtThreads) void durations_kernel(float *__restrict__ dur, int *__restrict__ cum,
                                                                 long *__restrict__ y_lengths,
+                                                                long *__restrict__ y_lengths_host,
                                                                 const float *__restrict__ logw,
                                                                 const float *__restrict__ dur_in,
                                                                 const float *__restrict__ mask, float length_scale,
-                                                                int glow, int T)
+                                                                int glow, int t_valid, int T)
 {
     __shared__ int part[kTxtThreads];
     const int b = blockIdx.x;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(kTxtThreads) void durations_kernel(float *__restric
             if (glow) wc = fmaxf(wc, 1.f);
             if (glow == 2) wc *= m;   // ragged-exact batching: padded tokens own no frame
         }
+        if (t >= t_valid) wc = 0.f;   // columns of a text-length bucket beyond the caller's tensor: no frames, whatever the rule
         dur[o] = wc;
         const float cl = fminf(fmaxf(wc, 0.f), 1048576.f);  // keep the int offsets finite for inf/NaN inputs
         local += (int)cl;
@@ -201,7 +203,11 @@ __global__ __launch_bounds__(kTxtThreads) void durations_kernel(float *__restric
     }
     if (tid == kTxtThreads - 1) {
         const int tot = part[kTxtThreads - 1];
-        y_lengths[b] = tot < 1 ? 1 : tot;
+        const long yl = tot < 1 ? 1 : tot;
+        y_lengths[b] = yl;
+        if (y_lengths_host) {          // mirror in host-mapped (pinned) memory: the host polls it instead of a stream sync + D2H
+            __hip_atomic_store(y_lengths_host + b, yl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -371,7 +377,21 @@ extern "C" int ttsamd_durations(float *durations, int32_t *cum, int64_t *y_lengt
                      "durations: bad args");
     if (batch == 0) return TTSAMD_OK;
     hipLaunchKernelGGL(durations_kernel, dim3(batch), dim3(kTxtThreads), 0, as_stream(stream), durations, cum,
-                       reinterpret_cast<long *>(y_lengths), logw, durations_in, mask, length_scale, glow, t);
+                       reinterpret_cast<long *>(y_lengths), (long *)nullptr, logw, durations_in, mask, length_scale, glow, t, t);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_durations_ex(float *durations, int32_t *cum, int64_t *y_lengths, int64_t *y_lengths_host,
+                                   const float *logw, const float *durations_in, const float *mask, float length_scale,
+                                   int glow, int t_valid, int batch, int t, void *stream)
+{
+    TTSAMD_CHECK_ARG(durations && cum && y_lengths && (logw || durations_in) && batch >= 0 && t > 0 && t_valid >= 0,
+                     "durations_ex: bad args");
+    if (batch == 0) return TTSAMD_OK;
+    hipLaunchKernelGGL(durations_kernel, dim3(batch), dim3(kTxtThreads), 0, as_stream(stream), durations, cum,
+                       reinterpret_cast<long *>(y_lengths), reinterpret_cast<long *>(y_lengths_host), logw, durations_in, mask,
+                       length_scale, glow, t_valid < t ? t_valid : t, t);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

@@ -194,11 +194,13 @@ class GlowTTS:
                 dp = torch.zeros((B, T), dtype=torch.float32, device=dev)
                 dp[:, :T0] = d
                 d = dp
-            w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d)
+            w_ceil, cum, y_lengths, t_dec = ops.durations(None, x_mask, 1.0, durations_in=d, want_max=True)
         else:
-            w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale),
-                                                   glow=2 if (ragged or T != T0) else 1)
-        t_dec = int(y_lengths.max().item())
+            # the bucket's own padding (columns >= T0) owns no frames; inside the caller's tensor the reference's rule holds
+            # — clamp_min gives every token one frame, masked or not (glow_tts.py:350-351) — unless the caller asked for
+            # ragged-exact batching
+            w_ceil, cum, y_lengths, t_dec = ops.durations(logw.contiguous(), x_mask, float(self.length_scale),
+                                                          glow=2 if ragged else 1, t_valid=T0, want_max=True)
         noise = aux_input.get("noise") if aux_input else None
         C = a.out_channels
         if noise is None and self.inference_noise_scale != 0.0:

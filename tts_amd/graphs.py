@@ -29,7 +29,13 @@ class GraphedSegment:
         return cls._capture[idx].stream
 
     def __init__(self, fn, example_inputs):
+        from . import _lib
+
         self.stream = torch.cuda.current_stream()
+        # the torch view does not keep a dedicated (lane) stream alive: hold its owner, so that the stream this graph
+        # replays on — and release() synchronises — exists for as long as the graph does (a dropped `Lanes` object would
+        # otherwise destroy it under the cache entry)
+        self.owner = _lib.stream_owner(self.stream.cuda_stream)
         self.static_in = [t.clone() for t in example_inputs]
         side = self.capture_stream(example_inputs[0].device)
         side.wait_stream(torch.cuda.current_stream())
@@ -50,7 +56,10 @@ class GraphedSegment:
     def release(self):
         """Before the graph, its private pool and its static outputs go away: the stream that replays it may still have
         consumers of those buffers queued (request lanes)."""
-        self.stream.synchronize()
+        try:
+            self.stream.synchronize()
+        except Exception:                 # the stream is gone (torn down behind our back): a device-wide wait covers it
+            torch.cuda.synchronize()
 
 
 class GraphCache:
@@ -73,13 +82,25 @@ class GraphCache:
         self.hits.clear()
         self.failed.clear()
 
+    def purge_stream(self, handle):
+        """Drop the graphs captured for one stream (a request lane that is being torn down)."""
+        for k in [k for k in self.entries if k[1] == handle]:
+            self.entries.pop(k).release()
+        for k in [k for k in self.hits if k[1] == handle]:
+            self.hits.pop(k)
+
     def __call__(self, *inputs, key=None):
         """`key`: extra hashable state the captured launches depend on (scalars baked into the graph)."""
         if not self.enabled:
             return self.fn(*inputs)
         # one capture per (shape, stream): concurrent request lanes (parallel.Lanes) replay on their own streams and must
         # not share the static input / output buffers of a graph
-        key = (key, torch.cuda.current_stream().cuda_stream) + tuple((tuple(t.shape), t.dtype) for t in inputs)
+        # ... and per lane count: the HiFiGAN generator bakes "MRF branches on three streams / on one" (parallel.active_lanes)
+        # into whatever it captures, so a graph captured inside a multi-lane request is not replayed for a lone one
+        from . import parallel
+
+        key = (key, torch.cuda.current_stream().cuda_stream, parallel.active_lanes() > 1) + \
+            tuple((tuple(t.shape), t.dtype) for t in inputs)
         seg = self.entries.get(key)
         if seg is not None:
             self.entries.move_to_end(key)

@@ -11,6 +11,7 @@ polyphase 2-tap conv with a pixel-shuffle epilogue; a whole ResBlock1 iteration
 128-channel stage's k=3 blocks) with its intermediate tensor kept in LDS; conv_post is an HBM-streaming
 kernel.  v1: 78 conv launches unfused, 54 with fusion.  No elementwise passes over HBM remain.
 """
+import collections
 import os
 
 import torch
@@ -65,7 +66,9 @@ class HifiganGenerator:
         self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
         self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "8,16,32,64,128").split(",") if c)
         self.fuse_max_kernel = {128: 3}     # channel count -> largest kernel size fused (absent = all)
-        self._side_streams = {}     # current stream handle -> its MRF branch streams
+        self._side_streams = collections.OrderedDict()     # current stream handle -> its MRF branch streams (LRU first)
+        self._retired = []          # evicted sets: parked, destroyed only by release_streams()
+        self._torch_streams = set()
         # A single utterance through the vocoder is ~110 launches of a few microseconds each on up to four streams: issued
         # one by one the host is the bottleneck.  `inference` on one item of up to `graph_max_frames` frames replays as ONE
         # hipGraph per 32-frame length bucket (the item runs ragged-exact inside the padded tensor: same samples).
@@ -155,15 +158,39 @@ class HifiganGenerator:
     def _streams(self, n):
         """MRF branch streams of the CURRENT stream: every request lane (parallel.Lanes) and every capture stream gets its
         own set, so that two requests in flight never queue work on a common stream (round 2 shared one set between the
-        lanes: one lane's branch launches then sat behind the other lane's event waits)."""
+        lanes: one lane's branch launches then sat behind the other lane's event waits).  Sets are kept least-recently-used
+        first; beyond 16 owner streams the oldest set whose owner stream is GONE is retired — a set whose owner is alive
+        (another thread may be in the middle of forward() on it) is never evicted, and a retired set's streams are only
+        parked (`_retired`), not destroyed, until `release_streams()`: a view handed out earlier stays valid."""
         key = torch.cuda.current_stream().cuda_stream
-        if key not in self._side_streams and len(self._side_streams) >= 16:
-            # lanes come and go in a long-lived server: keep the sets of the 16 most recently created owner streams
-            self._side_streams.pop(next(iter(self._side_streams)))
-        pool = self._side_streams.setdefault(key, [])
+        pool = self._side_streams.get(key)
+        if pool is None:
+            if len(self._side_streams) >= 16:
+                for k in list(self._side_streams):
+                    if k != 0 and _lib.stream_owner(k) is None and k not in self._torch_streams:
+                        self._retired.append(self._side_streams.pop(k))
+                        if len(self._side_streams) < 16:
+                            break
+            pool = self._side_streams[key] = []
+            if _lib.stream_owner(key) is None and key != 0:
+                self._torch_streams.add(key)          # a torch-pool stream: never destroyed, its set is never retired
+        else:
+            self._side_streams.move_to_end(key)
         while len(pool) < n:
             pool.append(_lib.OwnedStream(self.device))
         return [o.stream for o in pool[:n]]
+
+    def release_streams(self, handle=None):
+        """Tear-down hook (a serving loop that rebuilds its lanes): after a device-wide wait, destroy the parked branch-stream
+        sets, the set keyed by `handle` (or every set when None), and the graphs captured for that stream."""
+        torch.cuda.synchronize()
+        del self._retired[:]
+        if handle is None:
+            self._side_streams.clear()
+            self._graph.clear()
+        else:
+            self._side_streams.pop(handle, None)
+            self._graph.purge_stream(handle)
 
     # ---- forward (hifigan_generator.py:236-265) ----------------------------------------------------
     @torch.no_grad()

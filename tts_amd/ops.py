@@ -6,6 +6,8 @@ re-ordering, MFMA fragment packing) runs once at load time.
 """
 import ctypes
 import os
+import threading
+import time
 
 import torch
 
@@ -193,6 +195,7 @@ class ResblockArgs(ctypes.Structure):
         ("c", ctypes.c_int32), ("t", ctypes.c_int32), ("batch", ctypes.c_int32),
         ("kernel", ctypes.c_int32), ("dilation", ctypes.c_int32),
         ("slope", ctypes.c_float), ("out_div", ctypes.c_float), ("variant", ctypes.c_int32),
+        ("w1_bytes", ctypes.c_int64), ("w2_bytes", ctypes.c_int64),
     ]
 
 
@@ -213,6 +216,7 @@ def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, a
     a.x, a.y, a.accum, a.mask = x.data_ptr(), y.data_ptr(), _dp(accum), _dp(mask)
     ws1, ws2 = (pc1.w_split, pc2.w_split) if C >= 32 else (pc1.w_split_pad32, pc2.w_split_pad32)
     a.w1_split, a.bias1, a.w2_split, a.bias2 = ws1.data_ptr(), _dp(pc1.bias), ws2.data_ptr(), _dp(pc2.bias)
+    a.w1_bytes, a.w2_bytes = ws1.numel(), ws2.numel()
     a.c, a.t, a.batch, a.kernel, a.dilation = C, T, B, pc1.kernel, pc1.dilation
     a.slope, a.out_div, a.variant = slope, out_div, variant
     if _TIMER is not None and not torch.cuda.is_current_stream_capturing():
@@ -389,17 +393,60 @@ def sdp_affine_reverse(z_out, z_in, m, logs, mask):
     return z_out
 
 
-def durations(logw, mask, length_scale, glow=False, durations_in=None):
-    """-> (w_ceil float [B,T], cum int32 [B,T], y_lengths int64 [B]) (include/tts_amd.h: ttsamd_durations)."""
+class _HostLengths:
+    """Pool of pinned (host-mapped) int64 mirrors the durations kernel writes y_lengths into: the host polls the mirror
+    instead of `y_lengths.max().item()` (a reduce kernel + device-to-host copy + a blocking stream synchronise)."""
+
+    _tls = threading.local()
+
+    @classmethod
+    def take(cls, n):
+        pool = cls._tls.__dict__.setdefault("pool", {})
+        free = pool.setdefault(n, [])
+        if free:
+            return free.pop()
+        t = torch.empty(n, dtype=torch.int64, pin_memory=True)
+        return t, t.numpy()
+
+    @classmethod
+    def give(cls, n, item):
+        cls._tls.pool[n].append(item)
+
+
+def durations(logw, mask, length_scale, glow=False, durations_in=None, t_valid=None, want_max=False):
+    """-> (w_ceil float [B,T], cum int32 [B,T], y_lengths int64 [B]) (include/tts_amd.h: ttsamd_durations_ex).
+    t_valid: columns >= t_valid own no frames (text-length bucket padding).  want_max=True also returns max(y_lengths) as a
+    Python int, read from a pinned host mirror the kernel writes (the request's ONE host wait) — not under stream capture."""
     src = logw if logw is not None else durations_in
     B, T = src.shape[0], src.shape[-1]
     dev = src.device
     dur = torch.empty((B, T), dtype=torch.float32, device=dev)
     cum = torch.empty((B, T), dtype=torch.int32, device=dev)
     ylen = torch.empty((B,), dtype=torch.int64, device=dev)
-    check(lib().ttsamd_durations(P(dur), P(cum), P(ylen), P(logw), P(durations_in), P(mask),
-                                 ctypes.c_float(length_scale), int(glow), B, T, stream_ptr()), "durations")  # glow: 0 VITS, 1 Glow, 2 Glow ragged-exact
-    return dur, cum, ylen
+    host = None
+    if want_max:
+        host = _HostLengths.take(B)
+        host[1][:] = -1
+    # glow: 0 VITS, 1 Glow, 2 Glow ragged-exact
+    check(lib().ttsamd_durations_ex(P(dur), P(cum), P(ylen), P(host[0]) if host else None, P(logw), P(durations_in), P(mask),
+                                    ctypes.c_float(length_scale), int(glow), T if t_valid is None else int(t_valid), B, T,
+                                    stream_ptr()), "durations")
+    if not want_max:
+        return dur, cum, ylen
+    arr = host[1]
+    deadline = None
+    spins = 0
+    while int(arr.min()) < 0:
+        spins += 1
+        if spins & 0xFFF == 0:              # a stalled stream must not hang the host for ever: ~ every millisecond look at the clock
+            now = time.monotonic()
+            if deadline is None:
+                deadline = now + 30.0
+            elif now > deadline:
+                raise _lib.TtsAmdError("durations: the device did not publish y_lengths within 30 s (stalled stream?)")
+    t_max = int(arr.max())
+    _HostLengths.give(B, host)
+    return dur, cum, ylen, t_max
 
 
 def generate_path(cum, x_mask, y_lengths, t_y):

@@ -32,10 +32,12 @@ def unflatten_state_dict(blob, manifest):
     return sd
 
 
-def broadcast_state_dict(sd, src=0, device=None):
+def broadcast_state_dict(sd, src=0, device=None, force=False):
     """Rank `src` passes its state_dict, the others pass None; every rank returns an identical CPU copy.
-    One object broadcast (the manifest, a few KB) + one tensor broadcast (the blob)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    One object broadcast (the manifest, a few KB) + one tensor broadcast (the blob).
+    force=True runs the collectives even in a group of ONE rank (the RCCL communicator, the broadcast kernel and the
+    blob's round trip through the device are then exercised on a single GPU: tests/test_rccl_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return sd
     rank = dist.get_rank()
     if rank == src:
@@ -129,10 +131,30 @@ class Lanes:
         self._outs[i] = out
         return out
 
+    def close(self, models=()):
+        """Tear the lanes down: wait for them, then drop what `models` (Vits / GlowTTS / HifiganGenerator objects) keep per
+        lane stream — captured graphs and MRF branch-stream sets — so that nothing stays keyed by a stream that is about to
+        be destroyed.  (Graphs hold a reference to their stream's owner, so forgetting this leaks streams, it does not crash.)"""
+        for st in self.streams:
+            st.synchronize()
+        for o in self._owned:
+            for m in models:
+                for holder in (m, getattr(m, "waveform_decoder", None), getattr(m, "model_g", None)):
+                    if holder is None:
+                        continue
+                    for name in ("_front", "_tail", "_graph"):
+                        cache = getattr(holder, name, None)
+                        if cache is not None and hasattr(cache, "purge_stream"):
+                            cache.purge_stream(o.handle)
+                    if hasattr(holder, "release_streams"):
+                        holder.release_streams(o.handle)
+        self._outs = [None] * len(self.streams)
+        self.streams, self._owned = [], []
+
     def sync(self, timeout_s=None):
         """Wait for every lane.  With `timeout_s` the wait polls the lanes' streams and raises TtsAmdError when the deadline
         passes instead of blocking for ever on a stalled stream — a serving loop can then drop the request and rebuild
-        its lanes (a blocking hipStreamSynchronize cannot be interrupted)."""
+        its lanes (`close(models)` first) (a blocking hipStreamSynchronize cannot be interrupted)."""
         if timeout_s is None:
             for st in self.streams:
                 st.synchronize()

@@ -24,14 +24,15 @@ from .text import TTSTokenizer
 from .vits import Vits, _get
 
 _MODELS = {"vits": Vits, "glow_tts": GlowTTS}
-# titles that precede a name: a period after them never ends a sentence (pysbd English PREPOSITIVE_ABBREVIATIONS)
-# pysbd's English tables (restated): abbreviations that are followed by a NUMBER never end a sentence ("fig. 2", "no. 5");
-# any other known abbreviation ends one only when the next word is one of the usual sentence starters ("U.S. Army" stays
-# whole, "... in the U.S. The next day ..." splits).
+# pysbd's English tables (restated).  Titles that precede a name (PREPOSITIVE_ABBREVIATIONS): a period after them never
+# ends a sentence.  Abbreviations that precede a NUMBER ("fig. 2", "no. 5") stay whole only before a digit.  Only the
+# MULTI-PERIOD abbreviations pysbd restores around its sentence starters (U.S, U.K, E.U, U.S.A, I.V, U.N) end a sentence only
+# when one of those starters follows ("U.S. Army" stays whole, "... in the U.S. The next day ..." splits); "e.g." / "i.e."
+# never end one.  Every other word — ordinary words that happen to be abbreviations too ("no", "sat", "mar", "etc", "inc",
+# "p.m") — ends a sentence before any token that does not start with a lowercase letter.
 _NUMBER_ABBREVIATIONS = frozenset("art ext no nos p pp fig figs vol vols ch sec eq para".split())
-_OTHER_ABBREVIATIONS = frozenset(
-    "u.s u.k u.n e.g i.e a.m p.m a.d b.c etc inc ltd co corp jr sr bros approx dept est apt ave blvd rd no fig vs al "
-    "jan feb mar apr jun jul aug sep sept oct nov dec mon tue tues wed thu thurs fri sat sun univ assn mfg ft oz lb".split())
+_STARTER_ABBREVIATIONS = frozenset("u.s u.k e.u u.s.a u.n i.v".split())
+_NEVER_FINAL_ABBREVIATIONS = frozenset("e.g i.e".split())
 _SENTENCE_STARTERS = frozenset("A Being Did For He How However I In It Millions More She That The There They We What When "
                                "Where Who Why".split())
 _PREPOSITIVE_ABBREVIATIONS = frozenset("adm attys brig capt cmdr col cpl det dr gen gov ing lt maj mr mrs ms mt messrs mssrs prof ph rep reps rev sen sens sgt st supt v vs".split())
@@ -111,8 +112,9 @@ class Synthesizer:
           * titles that precede a name (dr., mr., mrs., ...) never end a sentence; other abbreviations (co., jr., U.K.)
             do when a capitalised word follows — pysbd's prepositive / other abbreviation split;
           * runs of list markers `1.) 2.)`, `1) 2)`, `1. 2.`, `a. b. c.` start a new segment each.
-          * abbreviations before a number ("fig. 2", "no. 5") and known abbreviations before a word that is not one of
-            pysbd's sentence starters ("The U.S. Army is big.") do not end a sentence.
+          * abbreviations before a number ("fig. 2", "no. 5") and the multi-period abbreviations U.S / U.K / E.U / U.S.A / U.N /
+            I.V before a word that is not one of pysbd's sentence starters ("The U.S. Army is big.") do not end a sentence;
+            ordinary words that double as abbreviations ("no.", "sat.", "etc.", "p.m.") do, before any capitalised token.
         Known differences from pysbd: no per-language rule sets (`_get_segmenter(lang)`), no ellipsis / parenthetical /
         exclamation-word ("Yahoo!") tables beyond the lowercase-follows rule."""
         text = re.sub(r"\s+", " ", text.strip())
@@ -157,7 +159,9 @@ class Synthesizer:
                         continue
                     if abbr in _NUMBER_ABBREVIATIONS and nxt[0].isdigit():
                         continue
-                    if abbr in _OTHER_ABBREVIATIONS and re.match(r"[A-Za-z]+", nxt) and \
+                    if abbr in _NEVER_FINAL_ABBREVIATIONS:
+                        continue
+                    if abbr in _STARTER_ABBREVIATIONS and re.match(r"[A-Za-z]+", nxt) and \
                             re.match(r"[A-Za-z]+", nxt).group(0) not in _SENTENCE_STARTERS:
                         continue
                 out.append(seg[start:m.end()].strip())
@@ -170,9 +174,11 @@ class Synthesizer:
         AudioProcessor.save_wav(np.asarray(wav), path, self.output_sample_rate, pipe_out)
 
     @torch.no_grad()
-    def tts_batch(self, sentences, trim=True, speaker_id=None, d_vector=None, language_id=None):
+    def tts_batch(self, sentences, trim=True, speaker_id=None, d_vector=None, language_id=None, durations=None):
         """Synthesize a list of sentences as one padded batch -> list of float32 waveforms (numpy).
-        speaker_id / d_vector [D] / language_id apply to every sentence (synthesis.py:166-215 per sentence)."""
+        speaker_id / d_vector [D] / language_id apply to every sentence (synthesis.py:166-215 per sentence).
+        durations (not a reference feature): per-sentence integer frame counts per token, pinning the models' own
+        ceil(exp(logw)) — what a parity harness injects when two fp32 implementations land on different sides of a ceil()."""
         tok = self.tts_model.tokenizer
         ids = [tok.text_to_ids(s) for s in sentences]
         if any(len(i) == 0 for i in ids):
@@ -192,6 +198,11 @@ class Synthesizer:
             aux["d_vectors"] = dv.expand(len(ids), -1).contiguous().to(dev)
         if language_id is not None:
             aux["language_ids"] = torch.full((len(ids),), int(language_id), dtype=torch.int64, device=dev)
+        if durations is not None:
+            d = torch.zeros(len(ids), T, dtype=torch.float32)
+            for r, dr in enumerate(durations):
+                d[r, : len(ids[r])] = torch.as_tensor(dr, dtype=torch.float32).reshape(-1)[: len(ids[r])]
+            aux["durations"] = d.to(dev)
         out = self.tts_model.inference(x.to(dev), aux)
         frames = out["y_lengths"]
         if self.vocoder_model is None:

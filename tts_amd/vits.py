@@ -368,15 +368,15 @@ class Vits:
         else:
             h, stats = self.text_encoder(x, x_mask, lang=None if lang is None else lang[:, :, 0])
         if durations is None:
-            w_ceil, cum, y_lengths = ops.durations(logw.contiguous(), x_mask, float(self.length_scale))
+            w_ceil, cum, y_lengths, t_dec = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), want_max=True)
         else:
             d = durations.to(dev, torch.float32).reshape(B, T0).contiguous()      # vits.py:1141-1143 (+ batches)
             if T != T0:
                 dp = torch.zeros((B, T), dtype=torch.float32, device=dev)
                 dp[:, :T0] = d
                 d = dp
-            w_ceil, cum, y_lengths = ops.durations(None, x_mask, 1.0, durations_in=d)
-        t_dec = int(y_lengths.max().item())                                       # one D2H sync: output extent
+            w_ceil, cum, y_lengths, t_dec = ops.durations(None, x_mask, 1.0, durations_in=d, want_max=True)
+        # t_dec = max(y_lengths): the request's one host wait (the output extent), polled from a pinned mirror
         noise_z = aux_input.get("noise_z") if aux_input else None
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
         t_pad = -(-t_dec // 32) * 32
