@@ -477,12 +477,45 @@ def wl_glow_hifigan_v2(args, ctx):
     dur = (4 + (torch.arange(T) % 3)).float().view(1, T)
     x, xl, d = ids.to(dev), torch.tensor([T], device=dev), dur.to(dev)
 
-    def step():
-        o = glow.inference(x, {"x_lengths": xl, "durations": d})
+    from tts_amd import _lib
+    from tts_amd.synthesizer import SentencePipeline
+
+    # the Synthesizer's request path (tts_amd/synthesizer.py: Synthesizer.tts_batch -> SentencePipeline): acoustic model ->
+    # seam -> vocoder, token ids in, waveform on the device out
+    pipe = SentencePipeline(glow, voc, ap_t, ap_v)
+    aux = {"x_lengths": xl, "durations": d}
+
+    def step_unfused():          # the three calls one after the other (round 3's measured path; `--unfused-sentence`)
+        o = glow.inference(x, aux)
         mel = mel_renorm_device(o["model_outputs"].transpose(1, 2), ap_t, ap_v)
         return voc.inference(mel)
 
-    for _ in range(max(args.warmup, 3)):
+    def step():
+        if args.unfused_sentence:
+            return step_unfused()
+        return pipe(x, aux)[0]
+
+    # kernel launches of ONE request, counted by the library around an eager (graph-free) run of the same launch sequence
+    def eager_step():
+        if args.unfused_sentence:
+            glow.use_graphs = voc.use_graphs = False
+            try:
+                return step_unfused()
+            finally:
+                glow.use_graphs = voc.use_graphs = True
+        return pipe(x, aux, eager=True)[0]
+
+    import ctypes
+
+    _lib.lib().ttsamd_launch_count.restype = ctypes.c_uint64
+    eager_step()
+    torch.cuda.synchronize()
+    n0 = int(_lib.lib().ttsamd_launch_count())
+    eager_step()
+    torch.cuda.synchronize()
+    launches = int(_lib.lib().ttsamd_launch_count()) - n0
+
+    for _ in range(max(args.warmup, 4)):
         wav = step()
     ctx.fence()
     t0 = time.perf_counter()
@@ -512,9 +545,11 @@ def wl_glow_hifigan_v2(args, ctx):
     # 20.4 GFLOP per sentence (FlopCounter on the reference modules); a B=1 sentence is launch/latency-bound
     # on this chip, the fraction is reported for completeness
     ach = 20.4e9 * args.steps * ctx.world / elapsed_max / 1e12
-    line["roofline"] = {"bound": "mfma", "kernel": "whole sentence at B=1 (~330 launches): launch / latency-bound",
+    line["roofline"] = {"bound": "mfma", "kernel": "whole sentence at B=1 (%d kernel launches per request): launch / latency-bound" % launches,
                         "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
-                        "frac": ach / conv_peak(args.precision), "traffic": None}
+                        "frac": ach / conv_peak(args.precision), "traffic": None, "launches_per_request": launches}
+    line["config"]["path"] = "three calls (glow.inference, seam, vocoder.inference)" if args.unfused_sentence else \
+        "Synthesizer SentencePipeline: 2 graph replays + 1 host wait per sentence"
     if ctx.world == 1 and not args.no_cpu_baseline:
         from oracle import tts_oracle as O
 
@@ -855,6 +890,9 @@ def main():
     ap.add_argument("--hifigan-steps", type=int, default=None, help="hifigan_v1: timed steps (default --steps; 1 as an extra)")
     ap.add_argument("--hifigan-warmup", type=int, default=None)
     ap.add_argument("--mas-batch", type=int, default=32, help="mas: items per GPU")
+    ap.add_argument("--unfused-sentence", action="store_true",
+                    help="glow_hifigan_v2: time the three model calls one after the other instead of the Synthesizer's fused "
+                         "sentence pipeline")
     ap.add_argument("--force-pg", action="store_true",
                     help="initialise the process group and run the weight broadcast / barriers / reductions through it even "
                          "with ONE rank (exercises the RCCL path on a single GPU)")

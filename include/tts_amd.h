@@ -29,6 +29,10 @@ extern "C" {
 const char *ttsamd_last_error(void);
 /* ABI version (bumped on any signature change) and the gfx arch the library was compiled for. */
 int ttsamd_abi_version(void);
+/* Kernel launches issued through this library since it was loaded (all threads; launches recorded into a stream capture
+ * count when they are recorded, not when the graph replays): "launches per request" of a chain = the difference around one
+ * eager run of it. */
+uint64_t ttsamd_launch_count(void);
 const char *ttsamd_arch(void);
 
 /* Streams owned by the caller through the library: a dedicated HIP stream on the current device (priority 0 = normal,
@@ -332,6 +336,12 @@ int ttsamd_expand_prior(float *z_p, float *z_p2, float *m_p, float *logs_p, floa
                         const float *logs, int64_t stats_bstride, const float *noise, const int32_t *cum,
                         const float *x_mask, const int64_t *y_lengths, float noise_scale, int mask_out, int batch,
                         int c, int t_x, int t_y, void *stream);
+/* noise_packed != 0: `noise` is a contiguous [batch, c, max_b y_lengths[b]] tensor (the draw at the reference's shape,
+ * randn_like(m_p), sitting at the head of a larger fixed buffer); columns beyond that extent take zero noise. */
+int ttsamd_expand_prior_ex(float *z_p, float *z_p2, float *m_p, float *logs_p, float *y_mask, const float *m,
+                           const float *logs, int64_t stats_bstride, const float *noise, const int32_t *cum,
+                           const float *x_mask, const int64_t *y_lengths, float noise_scale, int mask_out, int noise_packed,
+                           int batch, int c, int t_x, int t_y, void *stream);
 /* m / logs are read as m[b*stats_bstride + c*t_x + x] (they are usually the two halves of one [B,2C,T_x]
  * projection buffer). */
 
@@ -366,6 +376,26 @@ int ttsamd_attn_durations(float *o, const int32_t *cum, const float *x_mask, con
 /* ------------------------------------------------------------------------------------------
  * Small streaming kernels (HBM-bound; coalesced, one pass)
  * ---------------------------------------------------------------------------------------- */
+/* Request glue (round 4): a single sentence is a chain of ~250 dependent launches; the tensor.clone() / slice / transpose
+ * copies a request hands out (one small launch each in a tensor library) travel as ONE launch.
+ * Segment i copies a [d0, d1, d2] box: element (a, b, c) from src + (a*s0 + b*s1 + c*s2) to dst + (a*t0 + b*t1 + c*t2) (elements). */
+#define TTSAMD_COPY_MAX_SEGS 12
+typedef struct ttsamd_copy_seg {
+    const void *src;
+    void *dst;
+    int32_t d0, d1, d2;
+    int64_t s0, s1, s2;     /* source strides in elements */
+    int64_t t0, t1, t2;     /* destination strides in elements */
+    int32_t elem_bytes;     /* 4 or 8 */
+} ttsamd_copy_seg;
+int ttsamd_copy_strided(const ttsamd_copy_seg *segs /* host */, int n, void *stream);
+/* All length masks of a ragged vocoder call in one launch (HifiganGenerator.forward with `lengths`: one [B, T_stage] mask per
+ * up-sampling stage): len_eff[b] = lengths[b] / quantum * quantum + add (Glow's squeeze drops the frames that do not fill a
+ * group, decoder.py:19-20; `add` = 2 * inference_padding), stage s: masks[off_s + b*t_stage[s] + t] = t < len_eff[b]*scales[s],
+ * off_s = batch * sum_{r<s} t_stage[r].  len_out (or NULL) receives len_eff. */
+#define TTSAMD_MASK_MAX_STAGES 8
+int ttsamd_stage_masks(float *masks, int64_t *len_out, const int64_t *lengths, int batch, int quantum, int add,
+                       const int32_t *scales /* host */, const int32_t *t_stage /* host */, int n_stages, void *stream);
 /* y[b,c,:] = F.pad(x[b,c,:], (pad,pad), "replicate")  — HifiganGenerator.inference,
  * TTS/vocoder/models/hifigan_generator.py:281.  x [rows, t], y [rows, t + 2*pad]. */
 int ttsamd_replicate_pad(float *y, const float *x, int64_t rows, int t, int pad, void *stream);
@@ -374,6 +404,9 @@ int ttsamd_replicate_pad(float *y, const float *x, int64_t rows, int t, int pad,
  * reference computes sentence by sentence (synthesizer.py:384). */
 int ttsamd_replicate_pad_ragged(float *y, const float *x, const int64_t *lengths, int batch, int c, int t, int pad,
                                 void *stream);
+/* The same with item b's valid frame count given as lengths[b] + len_bias (the vocoder's padded lengths minus 2*pad). */
+int ttsamd_replicate_pad_ragged_ex(float *y, const float *x, const int64_t *lengths, int64_t len_bias, int batch, int c,
+                                   int t, int pad, void *stream);
 
 /* The Synthesizer's Glow-TTS -> vocoder seam on the device: `vocoder_ap.normalize(tts_ap.denormalize(mel))`
  * (TTS/utils/synthesizer.py:412-416; AudioProcessor.normalize / denormalize, TTS/utils/audio/processor.py:259-336;

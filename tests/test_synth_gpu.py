@@ -206,3 +206,64 @@ def test_vits_multispeaker_multilingual_request(gpu, tmp_path, speakers):
         api.tts(text, language="en")
     with pytest.raises(ValueError, match="multi-lingual but no `language`"):
         api.tts(text, speaker="bob")
+
+
+def test_sentence_pipeline_equals_the_three_calls(gpu):
+    """SentencePipeline (acoustic model -> seam -> vocoder as two graph replays around one host wait) against the three
+    calls one after the other (glow.inference, mel_renorm_device, vocoder.inference) — which the other tests pin to the
+    oracle: a single sentence across eager / capture / replay, token counts sharing a bucket, and a ragged-exact batch."""
+    from tts_amd.glow_tts import GlowTTS
+    from tts_amd.hifigan import HifiganGenerator
+    from tts_amd.synthesizer import SentencePipeline
+
+    gargs = dict(num_flow_blocks_dec=3, num_chars=70, inference_noise_scale=0.3)
+    gargs["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    gsd = W.make_glow_state(gargs, seed=41)
+    hcfg = dict(W.HIFIGAN_V2)
+    hsd = O.make_hifigan_state(hcfg, 80, seed=42)
+    glow = GlowTTS(gargs)
+    glow.load_state_dict(gsd)
+    glow.to(gpu)
+    voc = HifiganGenerator(80, 1, hcfg["resblock_type"], hcfg["resblock_dilation_sizes"], hcfg["resblock_kernel_sizes"],
+                           hcfg["upsample_kernel_sizes"], hcfg["upsample_initial_channel"], hcfg["upsample_factors"],
+                           inference_padding=hcfg["inference_padding"])
+    voc.load_state_dict(hsd)
+    voc.to(gpu)
+    a_t, a_v = AudioProcessor(), AudioProcessor(max_norm=3.0)
+    pipe = SentencePipeline(glow, voc, a_t, a_v)
+    g = torch.Generator().manual_seed(3)
+
+    def three_calls(x, aux):
+        o = glow.inference(x, dict(aux, no_graph=True))
+        mel = mel_renorm_device(o["model_outputs"].transpose(1, 2), a_t, a_v)
+        frames = torch.div(o["y_lengths"], 2, rounding_mode="floor") * 2
+        wav = voc._inference_ragged(mel, frames)
+        return wav, [int(f + 10) * 256 for f in frames]
+
+    for T in (23, 29, 23, 23, 32):
+        x = torch.randint(0, 70, (1, T), generator=g).to(gpu)
+        dur = (1 + torch.randint(0, 4, (1, T), generator=g)).float().to(gpu)
+        noise = torch.randn(1, 80, int(dur.sum()), generator=g).to(gpu)
+        aux = {"x_lengths": torch.tensor([T], device=gpu), "durations": dur, "noise": noise}
+        want, wl = three_calls(x, aux)
+        for mode in ("eager", "graph", "graph", "graph"):
+            got, lens = pipe(x, aux, eager=(mode == "eager"))
+            assert lens == wl and got.shape[-1] == wl[0]
+            a, b = got[0, 0].double().cpu(), want[0, 0, : wl[0]].double().cpu()
+            assert float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()) < 2e-6, (T, mode)
+    assert pipe._graph.stats["captures"] >= 1 and pipe._graph.stats["replays"] >= 6
+    # ragged-exact batch of three sentences: every row equals its own single-sentence run
+    xl = torch.tensor([27, 14, 20])
+    x = torch.randint(0, 70, (3, 27), generator=g)
+    dur = (1 + torch.randint(0, 4, (3, 27), generator=g)).float() * (torch.arange(27)[None] < xl[:, None]).float()
+    aux = {"x_lengths": xl.to(gpu), "durations": dur.to(gpu), "ragged_exact": True}
+    glow.inference_noise_scale = 0.0
+    pipe.clear()
+    for _ in range(3):
+        got, lens = pipe(x.to(gpu), aux)
+    for r in range(3):
+        one, l1 = pipe(x[r:r + 1, : int(xl[r])].to(gpu), {"x_lengths": xl[r:r + 1].to(gpu), "durations": dur[r:r + 1, : int(xl[r])].to(gpu)},
+                       eager=True)
+        assert l1[0] == lens[r]
+        a, b = got[r, 0, : lens[r]].double().cpu(), one[0, 0].double().cpu()
+        assert float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()) < 2e-6, r

@@ -32,7 +32,12 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
         }                                                                                        \
     } while (0)
 
-#define TTSAMD_LAUNCH_CHECK() TTSAMD_HIP(hipGetLastError())
+extern std::atomic<unsigned long long> g_launches;       // kernel launches issued through the ABI (ttsamd_launch_count)
+#define TTSAMD_LAUNCH_CHECK()                                        \
+    do {                                                             \
+        ::ttsamd::g_launches.fetch_add(1, std::memory_order_relaxed); \
+        TTSAMD_HIP(hipGetLastError());                               \
+    } while (0)
 
 constexpr int kWave = 64;  // CDNA wavefront width
 

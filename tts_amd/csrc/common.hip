@@ -4,6 +4,7 @@
 
 namespace ttsamd {
 static thread_local char g_err[512] = "";
+std::atomic<unsigned long long> g_launches{0};
 
 void set_error(const char *fmt, ...)
 {
@@ -17,6 +18,7 @@ void set_error(const char *fmt, ...)
 extern "C" const char *ttsamd_last_error(void) { return ttsamd::g_err; }
 extern "C" int ttsamd_abi_version(void) { return 2; }   // 2: ttsamd_resblock_args carries the weight image sizes
 extern "C" const char *ttsamd_arch(void) { return "gfx950"; }
+extern "C" uint64_t ttsamd_launch_count(void) { return ttsamd::g_launches.load(std::memory_order_relaxed); }
 
 extern "C" int ttsamd_stream_create(int priority, void **stream_out)
 {

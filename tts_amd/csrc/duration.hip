@@ -230,9 +230,14 @@ __global__ __launch_bounds__(256) void expand_prior_kernel(
     float *__restrict__ z_p, float *__restrict__ z_p2, float *__restrict__ m_p, float *__restrict__ logs_p,
     float *__restrict__ y_mask, const float *__restrict__ m, const float *__restrict__ logs, long stats_bstride,
     const float *__restrict__ noise, const int *__restrict__ cum, const float *__restrict__ x_mask,
-    const long *__restrict__ y_lengths, float noise_scale, int mask_out, int C, int Tx, int Ty)
+    const long *__restrict__ y_lengths, float noise_scale, int mask_out, int noise_packed, int C, int Tx, int Ty)
 {
     const int b = blockIdx.y;
+    long tn = Ty;                     // extent (and row stride) of the noise tensor
+    if (noise && noise_packed) {      // a contiguous [B, C, max(y_lengths)] draw: beyond that extent the noise is zero
+        tn = 1;
+        for (int i = 0; i < (int)gridDim.y; ++i) tn = y_lengths[i] > tn ? y_lengths[i] : tn;
+    }
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int grp = threadIdx.y;
     if (y >= Ty) return;
@@ -254,7 +259,10 @@ __global__ __launch_bounds__(256) void expand_prior_kernel(
         const float mv = valid ? m[src] : 0.f;
         const float lv = (valid && logs) ? logs[src] : 0.f;
         float z = mv;
-        if (noise) z = mv + noise[dst] * expf(lv) * noise_scale;
+        if (noise) {
+            const float nv = noise_packed ? (y < tn ? noise[((long)b * C + c) * tn + y] : 0.f) : noise[dst];
+            z = mv + nv * expf(lv) * noise_scale;
+        }
         if (mask_out) z *= ym;
         if (m_p) m_p[dst] = mv;
         if (logs_p) logs_p[dst] = lv;
@@ -413,6 +421,15 @@ extern "C" int ttsamd_expand_prior(float *z_p, float *z_p2, float *m_p, float *l
                                    const float *x_mask, const int64_t *y_lengths, float noise_scale, int mask_out,
                                    int batch, int c, int t_x, int t_y, void *stream)
 {
+    return ttsamd_expand_prior_ex(z_p, z_p2, m_p, logs_p, y_mask, m, logs, stats_bstride, noise, cum, x_mask, y_lengths,
+                                  noise_scale, mask_out, 0, batch, c, t_x, t_y, stream);
+}
+
+extern "C" int ttsamd_expand_prior_ex(float *z_p, float *z_p2, float *m_p, float *logs_p, float *y_mask, const float *m,
+                                      const float *logs, int64_t stats_bstride, const float *noise, const int32_t *cum,
+                                      const float *x_mask, const int64_t *y_lengths, float noise_scale, int mask_out,
+                                      int noise_packed, int batch, int c, int t_x, int t_y, void *stream)
+{
     TTSAMD_CHECK_ARG(z_p && m && cum && y_lengths && batch >= 0 && c > 0 && t_x > 0 && t_y >= 0,
                      "expand_prior: bad args");
     if (batch == 0 || t_y == 0) return TTSAMD_OK;
@@ -420,7 +437,7 @@ extern "C" int ttsamd_expand_prior(float *z_p, float *z_p2, float *m_p, float *l
     hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(t_y, 64), batch), dim3(64, 4), 0, as_stream(stream), z_p, z_p2,
                        m_p, logs_p, y_mask, m, logs, (long)stats_bstride, noise, cum, x_mask,
                        reinterpret_cast<const long *>(y_lengths),
-                       noise_scale, mask_out, c, t_x, t_y);
+                       noise_scale, mask_out, noise_packed, c, t_x, t_y);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

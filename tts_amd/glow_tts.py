@@ -64,6 +64,7 @@ class GlowTTS:
         self._front = graphs.GraphCache(self._front_eager)
         self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
         self._tail_cfg = None
+        self._scratch = graphs.StreamScratch()  # per-stream fixed buffers the graphs read in place (see tts_amd.Vits.inference)
         self.graph_tail_max_frames = 4096      # B * padded frames up to which the tail is captured
         self.text_bucket = 16                  # token-axis padding of graphed requests (1 = off)
 
@@ -142,14 +143,103 @@ class GlowTTS:
         return o_mean, (o_logs if o_logs is not None else torch.empty(0, device=x.device)), logw.contiguous()
 
     def _tail_eager(self, o_mean, o_logs, cum, x_mask, y_lengths, noise, g):
-        """everything after the output extent is known, at the padded length self._tail_cfg[0] (glow_tts.py:361-366)."""
+        """everything after the output extent is known, at the padded length self._tail_cfg[0] (glow_tts.py:361-366).
+        noise: the packed [B, C, max(y_lengths)] draw at the head of a [B, C, t_pad] scratch buffer, or empty."""
         t_pad, noise_scale = self._tail_cfg
         pri = ops.expand_prior(o_mean, o_logs if o_logs.numel() else None, noise if noise.numel() else None, cum, x_mask,
-                               y_lengths, t_pad, noise_scale, mask_out=True)
+                               y_lengths, t_pad, noise_scale, mask_out=True, noise_packed=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_pad)
         y = self.decoder(pri["z_p"], pri["y_mask"], g=g if g.numel() else None)
         logs_p = pri["logs_p"] if pri["logs_p"] is not None else torch.empty(0, device=o_mean.device)
-        return y, attn, pri["m_p"], logs_p
+        return y, attn, pri["m_p"], logs_p, ops.attn_durations(cum, x_mask, y_lengths)
+
+    def request_front(self, x, aux_input=None):
+        """First half of `inference` — encoder + duration predictor (one graph replay), durations, and the request's one
+        host wait (the output extent) — as a context dict the second half (`inference` itself, or a Synthesizer pipeline that
+        continues straight into the vocoder) picks up."""
+        if self.encoder is None:
+            raise _lib.TtsAmdError("tts_amd.GlowTTS: no weights loaded / not moved to the GPU")
+        _lib.require_gpu(x, "x")
+        aux_input = aux_input or {}
+        dev = x.device
+        x = x.to(torch.int64).contiguous()
+        B, T = x.shape
+        x_lengths = aux_input.get("x_lengths")
+        if x_lengths is None:
+            x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+        no_graph = bool(aux_input.get("no_graph", False))
+        graphing = bool(self.use_graphs) and not no_graph
+        # text-length buckets (see tts_amd.Vits.inference): the token axis of a graphed request is padded to a multiple of 16,
+        # pad ids masked out and owning no frames, so the valid positions see the unpadded run
+        # (single sentences and ragged-exact batches only: in a plain batch the reference's one-frame-per-padded-token rule
+        # applies to the batch's own padding and is kept as it is)
+        T0 = T
+        ragged = bool(aux_input.get("ragged_exact"))
+        if graphing and (B == 1 or ragged) and self.text_bucket > 1 and T % self.text_bucket:
+            T = -(-T // self.text_bucket) * self.text_bucket
+        sc = None
+        if graphing:       # per-stream scratch at fixed addresses: the graphs read it in place (tts_amd.Vits.inference)
+            sc = self._scratch.get((B, T), lambda: dict(
+                x=torch.zeros((B, T), dtype=torch.int64, device=dev), x_mask=torch.empty((B, T), dtype=torch.float32, device=dev),
+                dur=torch.empty((B, T), dtype=torch.float32, device=dev), cum=torch.empty((B, T), dtype=torch.int32, device=dev),
+                ylen=torch.empty((B,), dtype=torch.int64, device=dev)))
+            ops.copy_into([sc["x"][:, :T0]], [x])
+            x = sc["x"]
+        elif T != T0:
+            xp = torch.zeros((B, T), dtype=torch.int64, device=dev)
+            xp[:, :T0] = x
+            x = xp
+        x_mask = ops.sequence_mask(x_lengths.to(dev), T, out=None if sc is None else sc["x_mask"])
+        g = self._speaker_embedding(aux_input, dev)
+        empty = torch.empty(0, device=dev)
+        self._front.enabled = graphing
+        o_mean, o_logs, logw = self._front(x, x_mask, g if g is not None else empty, stable=(0, 1) if sc is not None else ())
+        front_static = self._front.last_static
+        o_logs = o_logs if o_logs.numel() else None
+        d_in = aux_input.get("durations")
+        dout = None if sc is None else (sc["dur"], sc["cum"], sc["ylen"])
+        host = {}
+        if d_in is not None:   # not a reference feature: lets a parity harness pin the integer durations (ceil cliff)
+            d = d_in.to(dev, torch.float32).reshape(B, T0).contiguous()
+            if T != T0:
+                dp = torch.zeros((B, T), dtype=torch.float32, device=dev)
+                dp[:, :T0] = d
+                d = dp
+            w_ceil, cum, y_lengths, t_dec = ops.durations(None, x_mask, 1.0, durations_in=d, want_max=True, out=dout, host_out=host)
+        else:
+            # the bucket's own padding (columns >= T0) owns no frames; inside the caller's tensor the reference's rule holds
+            # — clamp_min gives every token one frame, masked or not (glow_tts.py:350-351) — unless the caller asked for
+            # ragged-exact batching
+            w_ceil, cum, y_lengths, t_dec = ops.durations(logw.contiguous(), x_mask, float(self.length_scale),
+                                                          glow=2 if ragged else 1, t_valid=T0, want_max=True, out=dout,
+                                                          host_out=host)
+        return dict(B=B, T=T, T0=T0, dev=dev, sc=sc, graphing=graphing, ragged=ragged, x_mask=x_mask, g=g, o_mean=o_mean,
+                    o_logs=o_logs, logw=logw, w_ceil=w_ceil, cum=cum, y_lengths=y_lengths, t_dec=t_dec,
+                    y_lengths_host=host["y_lengths"], front_static=front_static)
+
+    def tail_inputs(self, ctx, aux_input=None):
+        """The inputs of `_tail_eager` for a request context at its 32-frame bucket -> (t_pad, inputs, stable indices):
+        the noise draw (outside any capture, at the reference's shape [B, C, t_dec]) lands packed at the head of the bucket's
+        fixed noise buffer."""
+        a, dev, B, t_dec = self.args, ctx["dev"], ctx["B"], ctx["t_dec"]
+        C = a.out_channels
+        empty = torch.empty(0, device=dev)
+        noise = (aux_input or {}).get("noise")
+        t_pad = -(-t_dec // 32) * 32
+        nz = empty
+        if noise is not None or self.inference_noise_scale != 0.0:
+            nzb = self._scratch.get(("nz", B, t_pad), lambda: torch.zeros(B * C * t_pad, dtype=torch.float32, device=dev))
+            packed = nzb[: B * C * t_dec].view(B, C, t_dec)
+            if noise is None:
+                torch.randn((B, C, t_dec), device=dev, dtype=torch.float32, out=packed)
+            else:
+                ops.copy_into([packed], [noise.to(dev, torch.float32)])
+            nz = nzb.view(B, C, t_pad)
+        o_logs, g = ctx["o_logs"], ctx["g"]
+        inputs = (ctx["o_mean"], o_logs if o_logs is not None else empty, ctx["cum"], ctx["x_mask"], ctx["y_lengths"], nz,
+                  g if g is not None else empty)
+        stable = ((0, 1) if ctx["front_static"] else ()) + (2, 3, 4) + ((5,) if nz.numel() else ())
+        return t_pad, inputs, stable
 
     @torch.no_grad()
     def inference(self, x, aux_input={"x_lengths": None, "d_vectors": None, "speaker_ids": None}):  # noqa: B006
@@ -157,80 +247,35 @@ class GlowTTS:
         "ragged_exact": padded tokens own no frames (the reference gives each PADDED token one frame via clamp_min,
         which only matters in batches) so that row b equals a B=1 run on sentence b (up to the conv launcher's batch-dependent
         tile choice: fp32 reassociation, ~1e-6 relative)."""
-        if self.encoder is None:
-            raise _lib.TtsAmdError("tts_amd.GlowTTS: no weights loaded / not moved to the GPU")
-        _lib.require_gpu(x, "x")
+        ctx = self.request_front(x, aux_input)
         a = self.args
-        dev = x.device
-        x = x.to(torch.int64).contiguous()
-        B, T = x.shape
-        x_lengths = aux_input.get("x_lengths") if aux_input else None
-        if x_lengths is None:
-            x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
-        no_graph = bool((aux_input or {}).get("no_graph", False))
-        # text-length buckets (see tts_amd.Vits.inference): the token axis of a graphed request is padded to a multiple of 16,
-        # pad ids masked out and — unlike the reference's batches, where clamp_min gives every PADDED token one frame —
-        # owning no frames ("ragged_exact" durations), so the valid positions see the unpadded run
-        # (single sentences and ragged-exact batches only: in a plain batch the reference's one-frame-per-padded-token rule
-        # applies to the batch's own padding and is kept as it is)
-        T0 = T
-        ragged_in = bool((aux_input or {}).get("ragged_exact"))
-        if self.use_graphs and not no_graph and (B == 1 or ragged_in) and self.text_bucket > 1 and T % self.text_bucket:
-            T = -(-T // self.text_bucket) * self.text_bucket
-            xp = torch.zeros((B, T), dtype=torch.int64, device=dev)
-            xp[:, :T0] = x
-            x = xp
-        x_mask = ops.sequence_mask(x_lengths.to(dev), T)
-        g = self._speaker_embedding(aux_input, dev)
-        empty = torch.empty(0, device=dev)
-        self._front.enabled = bool(self.use_graphs) and not no_graph
-        o_mean, o_logs, logw = self._front(x, x_mask, g if g is not None else empty)
-        o_logs = o_logs if o_logs.numel() else None
-        ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
-        d_in = aux_input.get("durations") if aux_input else None
-        if d_in is not None:   # not a reference feature: lets a parity harness pin the integer durations (ceil cliff)
-            d = d_in.to(dev, torch.float32).reshape(B, T0).contiguous()
-            if T != T0:
-                dp = torch.zeros((B, T), dtype=torch.float32, device=dev)
-                dp[:, :T0] = d
-                d = dp
-            w_ceil, cum, y_lengths, t_dec = ops.durations(None, x_mask, 1.0, durations_in=d, want_max=True)
-        else:
-            # the bucket's own padding (columns >= T0) owns no frames; inside the caller's tensor the reference's rule holds
-            # — clamp_min gives every token one frame, masked or not (glow_tts.py:350-351) — unless the caller asked for
-            # ragged-exact batching
-            w_ceil, cum, y_lengths, t_dec = ops.durations(logw.contiguous(), x_mask, float(self.length_scale),
-                                                          glow=2 if ragged else 1, t_valid=T0, want_max=True)
+        B, T, T0, dev, t_dec, ragged = ctx["B"], ctx["T"], ctx["T0"], ctx["dev"], ctx["t_dec"], ctx["ragged"]
+        o_mean, o_logs, logw, w_ceil, cum, y_lengths, x_mask, g = (ctx[k] for k in (
+            "o_mean", "o_logs", "logw", "w_ceil", "cum", "y_lengths", "x_mask", "g"))
+        t_pad = -(-t_dec // 32) * 32
+        if ctx["graphing"] and (B == 1 or ragged) and B * t_pad <= self.graph_tail_max_frames:
+            t_pad, inputs, stable = self.tail_inputs(ctx, aux_input)
+            self._tail.enabled = True
+            self._tail_cfg = (t_pad, float(self.inference_noise_scale))
+            y, attn, m_p, logs_p, tot = self._tail(*inputs, key=self._tail_cfg, stable=stable)
+            # static buffers of the graph (overwritten by its next replay): hand out copies cut to the true extent (the decoder's
+            # squeeze drops the frames that do not fill a group: its output is (t_dec // num_squeeze) * num_squeeze long) and to
+            # the caller's T0 tokens — ONE launch for all of them
+            t_y = (t_dec // self.num_squeeze) * self.num_squeeze
+            c = ops.clone_views([y[:, :, :t_y].transpose(1, 2), m_p[:, :, :t_dec].transpose(1, 2),
+                                 logs_p[:, :, :t_dec].transpose(1, 2) if logs_p.numel() else None,
+                                 attn[:, :T0, :t_dec].permute(0, 2, 1), logw[:, :T0].unsqueeze(2), tot[:, :T0].unsqueeze(2),
+                                 y_lengths, w_ceil[:, :T0].unsqueeze(1)])
+            return {"model_outputs": c[0], "logdet": None, "y_mean": c[1], "y_log_scale": c[2], "alignments": c[3],
+                    "durations_log": c[4], "total_durations_log": c[5], "y_lengths": c[6], "durations": c[7]}
         noise = aux_input.get("noise") if aux_input else None
         C = a.out_channels
         if noise is None and self.inference_noise_scale != 0.0:
             noise = torch.randn(B, C, t_dec, device=dev, dtype=torch.float32)
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()
-        t_pad = -(-t_dec // 32) * 32
-        if self.use_graphs and not no_graph and (B == 1 or ragged) and B * t_pad <= self.graph_tail_max_frames:
-            nz = empty
-            if noise is not None:                       # drawn / pinned at the true extent, zero-extended (masked there)
-                nz = torch.zeros(B, C, t_pad, device=dev, dtype=torch.float32)
-                nz[:, :, :t_dec] = noise
-            self._tail.enabled = True
-            self._tail_cfg = (t_pad, float(self.inference_noise_scale))
-            y, attn, m_p, logs_p = self._tail(o_mean, o_logs if o_logs is not None else empty, cum, x_mask, y_lengths, nz,
-                                              g if g is not None else empty, key=self._tail_cfg)
-            # static buffers of the graph (overwritten by its next replay): hand out copies cut to the true extent (the decoder's
-            # squeeze drops the frames that do not fill a group: its output is (t_dec // num_squeeze) * num_squeeze long)
-            t_y = (t_dec // self.num_squeeze) * self.num_squeeze
-            return self._cut_text({
-                "model_outputs": y[:, :, :t_y].transpose(1, 2).clone(),
-                "logdet": None,
-                "y_mean": m_p[:, :, :t_dec].transpose(1, 2).clone(),
-                "y_log_scale": logs_p[:, :, :t_dec].transpose(1, 2).clone() if logs_p.numel() else None,
-                "alignments": attn[:, :, :t_dec].permute(0, 2, 1).clone(),
-                "durations_log": logw.clone().unsqueeze(1).transpose(1, 2),
-                "total_durations_log": ops.attn_durations(cum, x_mask, y_lengths).unsqueeze(1).transpose(1, 2),
-                "y_lengths": y_lengths.clone(),
-                "durations": w_ceil.unsqueeze(1).clone(),
-            }, T0, T)
+        if ctx["sc"] is not None:      # the eager tail hands its tensors out: they must not alias the per-stream scratch
+            w_ceil, cum, y_lengths, x_mask = ops.clone_views([w_ceil, cum, y_lengths, x_mask])
         pri = ops.expand_prior(o_mean, o_logs, noise, cum, x_mask, y_lengths, t_dec, float(self.inference_noise_scale),
                                mask_out=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_dec)

@@ -28,7 +28,7 @@ class GraphedSegment:
             cls._capture[idx] = _lib.OwnedStream(torch.device("cuda", idx))
         return cls._capture[idx].stream
 
-    def __init__(self, fn, example_inputs):
+    def __init__(self, fn, example_inputs, stable=()):
         from . import _lib
 
         self.stream = torch.cuda.current_stream()
@@ -36,7 +36,11 @@ class GraphedSegment:
         # replays on — and release() synchronises — exists for as long as the graph does (a dropped `Lanes` object would
         # otherwise destroy it under the cache entry)
         self.owner = _lib.stream_owner(self.stream.cuda_stream)
-        self.static_in = [t.clone() for t in example_inputs]
+        # `stable` inputs live at the same address on every call (another graph's static outputs, a model's per-stream
+        # scratch): the capture reads them in place — no staging copy per replay (the cache keys on their addresses)
+        self.stable = frozenset(stable)
+        self.static_in = [t if i in self.stable else t.clone() for i, t in enumerate(example_inputs)]
+        self.copied = [i for i, t in enumerate(self.static_in) if i not in self.stable and t.numel()]
         side = self.capture_stream(example_inputs[0].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up outside capture: one-time hipFuncSetAttribute calls, allocator
@@ -48,8 +52,13 @@ class GraphedSegment:
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):
-        for s, t in zip(self.static_in, inputs):
-            s.copy_(t)
+        if len(self.copied) == 1:
+            i = self.copied[0]
+            self.static_in[i].copy_(inputs[i])
+        elif self.copied:                      # all staging copies of the replay as ONE launch
+            from . import ops
+
+            ops.copy_into([self.static_in[i] for i in self.copied], [inputs[i] for i in self.copied])
         self.graph.replay()
         return self.static_out
 
@@ -71,6 +80,7 @@ class GraphCache:
         self.hits = collections.OrderedDict()       # key -> times seen (not captured yet)
         self.failed = set()                         # keys whose capture raised: eager from then on
         self.enabled = True
+        self.last_static = False                    # the last call returned a captured graph's static buffers (fixed addresses)
         self.stats = {"replays": 0, "eager": 0, "captures": 0, "capture_failures": 0, "evictions": 0}
 
     def clear(self):
@@ -89,8 +99,10 @@ class GraphCache:
         for k in [k for k in self.hits if k[1] == handle]:
             self.hits.pop(k)
 
-    def __call__(self, *inputs, key=None):
-        """`key`: extra hashable state the captured launches depend on (scalars baked into the graph)."""
+    def __call__(self, *inputs, key=None, stable=()):
+        """`key`: extra hashable state the captured launches depend on (scalars baked into the graph).
+        `stable`: indices of inputs that live at a fixed address (read in place by the capture, no per-replay copy)."""
+        self.last_static = False
         if not self.enabled:
             return self.fn(*inputs)
         # one capture per (shape, stream): concurrent request lanes (parallel.Lanes) replay on their own streams and must
@@ -99,37 +111,63 @@ class GraphCache:
         # into whatever it captures, so a graph captured inside a multi-lane request is not replayed for a lone one
         from . import parallel
 
-        key = (key, torch.cuda.current_stream().cuda_stream, parallel.active_lanes() > 1) + \
+        base = (key, torch.cuda.current_stream().cuda_stream, parallel.active_lanes() > 1) + \
             tuple((tuple(t.shape), t.dtype) for t in inputs)
+        key = base + tuple(inputs[i].data_ptr() for i in stable)       # a capture is tied to its in-place inputs' addresses
         seg = self.entries.get(key)
         if seg is not None:
             self.entries.move_to_end(key)
             self.stats["replays"] += 1
+            self.last_static = True
             return seg(*inputs)
-        if key in self.failed:
+        if base in self.failed:
             self.stats["eager"] += 1
             return self.fn(*inputs)
-        n = self.hits.get(key, 0) + 1
+        n = self.hits.get(base, 0) + 1                                  # "hot" is a property of the shape, not of the addresses
         if n < self.capture_after:
-            self.hits[key] = n
-            self.hits.move_to_end(key)
+            self.hits[base] = n
+            self.hits.move_to_end(base)
             while len(self.hits) > 8 * self.max_entries:
                 self.hits.popitem(last=False)
             self.stats["eager"] += 1
             return self.fn(*inputs)
-        self.hits.pop(key, None)
         while len(self.entries) >= self.max_entries:
             _, old = self.entries.popitem(last=False)
             old.release()
             self.stats["evictions"] += 1
         try:
-            seg = GraphedSegment(self.fn, inputs)
+            seg = GraphedSegment(self.fn, inputs, stable)
         except Exception:                            # capture is an optimisation: never fail the request over it
-            self.failed.add(key)
+            self.failed.add(base)
             self.stats["capture_failures"] += 1
             torch.cuda.synchronize()
             self.stats["eager"] += 1
             return self.fn(*inputs)
         self.entries[key] = seg
         self.stats["captures"] += 1
+        self.last_static = True
         return seg(*inputs)
+
+
+class StreamScratch:
+    """Fixed device buffers of a model, one set per (current stream, key): what a request writes BEFORE replaying a graph
+    (masks, durations, noise) lands at the same address every time, so the graph reads it in place (`stable` inputs of
+    GraphCache) instead of through a staging copy.  Per stream because request lanes run concurrently.  LRU-bounded."""
+
+    def __init__(self, max_entries=24):
+        self.max_entries = max_entries
+        self.sets = collections.OrderedDict()
+
+    def get(self, key, make):
+        k = (torch.cuda.current_stream().cuda_stream,) + tuple(key)
+        s = self.sets.get(k)
+        if s is None:
+            while len(self.sets) >= self.max_entries:
+                self.sets.popitem(last=False)      # (graphs captured on an evicted set keep their own references to it)
+            s = self.sets[k] = make()
+        else:
+            self.sets.move_to_end(k)
+        return s
+
+    def clear(self):
+        self.sets.clear()

@@ -194,7 +194,7 @@ class HifiganGenerator:
 
     # ---- forward (hifigan_generator.py:236-265) ----------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, g=None, in_mask=None, lengths=None):
+    def forward(self, x, g=None, in_mask=None, lengths=None, _masks=None):
         """`in_mask` [B,T] (optional) multiplies x inside conv_pre's load: VITS feeds `z * y_mask` (vits.py:1161).
         `lengths` [B] (optional, frames): ragged-exact batching — every conv of every stage reads item b as if its
         tensor ended at lengths[b] (positions beyond are zero, exactly the zero padding a stand-alone run of that item
@@ -213,14 +213,15 @@ class HifiganGenerator:
         ch = self.upsample_initial_channel
         o = new(ch, T)
         sm = [None] * (self.num_upsamples + 1)        # per-stage length masks [B, T_stage]
-        if lengths is not None:
-            lengths = lengths.to(dev, torch.int64)
-            scale = 1
-            sm[0] = ops.sequence_mask(lengths, T)
+        if _masks is not None:
+            sm = list(_masks)
             in_mask = sm[0] if in_mask is None else in_mask * sm[0]
-            for i, u in enumerate(self.upsample_factors):
-                scale *= u
-                sm[i + 1] = ops.sequence_mask(lengths * scale, T * scale)
+        elif lengths is not None:
+            # every stage's mask in ONE launch (a sequence_mask + a lengths*scale per stage before: 9 tiny launches at the head
+            # of every ragged call)
+            scales = [1] + _cumprod(self.upsample_factors)
+            sm, _ = ops.stage_masks(lengths.to(dev), scales, [T * sc for sc in scales])
+            in_mask = sm[0] if in_mask is None else in_mask * sm[0]
         if g is not None and "cond_layer" in P:
             # o = conv_pre(x) + cond_layer(g): g is [B, C, 1]; its 1x1 conv is a per-(b, channel) offset that
             # rides in conv_pre's epilogue (hifigan_generator.py:250-251)
@@ -349,13 +350,23 @@ class HifiganGenerator:
             return wav[:, :, : (T + 2 * self.inference_padding) * hop].clone()     # the graph's buffer is static: hand out a copy
         return self._inference_ragged(c, lengths)
 
-    def _inference_ragged(self, c, lengths=None):
-        if lengths is not None:
-            lengths = torch.as_tensor(lengths).to(self.device, torch.int64)     # the pad kernel reads them on the device
+    def _inference_ragged(self, c, lengths=None, quantum=1):
+        """`quantum` > 1: item b's frame count is lengths[b] // quantum * quantum (a Glow-TTS mel whose squeeze dropped the
+        frames that did not fill a group: the count comes straight from the model's y_lengths, on the device)."""
         p = self.inference_padding
+        if lengths is None:
+            if p > 0:
+                B, C, T = c.shape
+                cp = torch.empty((B, C, T + 2 * p), dtype=torch.float32, device=c.device)
+                ops.replicate_pad(c, cp, p)
+                c = cp
+            return self.forward(c)
+        lengths = torch.as_tensor(lengths).to(self.device, torch.int64)     # masks and pad read them on the device
+        B, C, T = c.shape
+        scales = [1] + _cumprod(self.upsample_factors)
+        masks, len_eff = ops.stage_masks(lengths, scales, [(T + 2 * p) * sc for sc in scales], quantum=quantum, add=2 * p)
         if p > 0:
-            B, C, T = c.shape
             cp = torch.empty((B, C, T + 2 * p), dtype=torch.float32, device=c.device)
-            ops.replicate_pad(c, cp, p, lengths)
+            ops.replicate_pad(c, cp, p, len_eff, len_bias=-2 * p)
             c = cp
-        return self.forward(c, lengths=None if lengths is None else lengths + 2 * p)
+        return self.forward(c, _masks=masks)

@@ -274,13 +274,88 @@ def gate_permute(w, bias, hidden):
     return w[idx].contiguous(), (None if bias is None else bias[idx].contiguous())
 
 
-def replicate_pad(x, y, pad, lengths=None):
+class CopySeg(ctypes.Structure):
+    """Mirror of `ttsamd_copy_seg` (include/tts_amd.h)."""
+
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("d0", ctypes.c_int32), ("d1", ctypes.c_int32),
+                ("d2", ctypes.c_int32), ("s0", ctypes.c_int64), ("s1", ctypes.c_int64), ("s2", ctypes.c_int64),
+                ("t0", ctypes.c_int64), ("t1", ctypes.c_int64), ("t2", ctypes.c_int64), ("elem_bytes", ctypes.c_int32)]
+
+
+COPY_MAX_SEGS = 12
+
+
+def _copy_seg(d, v):
+    shp = [1] * (3 - v.dim()) + list(v.shape)
+    g = CopySeg()
+    g.src, g.dst = v.data_ptr(), d.data_ptr()
+    g.d0, g.d1, g.d2 = shp
+    g.s0, g.s1, g.s2 = [0] * (3 - v.dim()) + list(v.stride())
+    g.t0, g.t1, g.t2 = [0] * (3 - d.dim()) + list(d.stride())
+    g.elem_bytes = d.element_size()
+    return g
+
+
+def _copy_launch(segs):
+    for i in range(0, len(segs), COPY_MAX_SEGS):
+        part = segs[i:i + COPY_MAX_SEGS]
+        arr = (CopySeg * len(part))(*part)
+        check(lib().ttsamd_copy_strided(arr, len(part), stream_ptr()), "copy_strided")
+
+
+def clone_views(views):
+    """[v.clone(memory_format=contiguous) for v in views] as ONE launch per 12 views (ttsamd_copy_strided): the slices /
+    transposes of a graph's static buffers a request hands out.  Views of up to 3 dims, 4- or 8-byte elements; None passes
+    through."""
+    outs, segs = [], []
+    for v in views:
+        if v is None:
+            outs.append(None)
+            continue
+        assert v.dim() <= 3 and v.element_size() in (4, 8), "clone_views: <= 3-D views of 4- / 8-byte elements"
+        o = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+        outs.append(o)
+        if o.numel():
+            segs.append(_copy_seg(o, v))
+    _copy_launch(segs)
+    return outs
+
+
+def copy_into(dsts, srcs):
+    """dst.copy_(src) for every pair as ONE launch per 12 pairs (same shape and dtype, up to 3 dims, any strides)."""
+    segs = []
+    for d, v in zip(dsts, srcs):
+        assert d.shape == v.shape and d.dtype == v.dtype and v.dim() <= 3 and d.element_size() in (4, 8)
+        if d.numel():
+            segs.append(_copy_seg(d, v))
+    _copy_launch(segs)
+
+
+def stage_masks(lengths, scales, t_stage, quantum=1, add=0):
+    """One launch for every length mask of a ragged vocoder call -> ([mask_s float [B, t_stage[s]]], len_eff int64 [B]);
+    len_eff = lengths // quantum * quantum + add, mask_s[b, t] = t < len_eff[b] * scales[s]   (ttsamd_stage_masks)."""
+    lengths = lengths.to(torch.int64).contiguous()
+    B, n = lengths.shape[0], len(scales)
+    flat = torch.empty(B * sum(int(t) for t in t_stage), dtype=torch.float32, device=lengths.device)
+    len_eff = torch.empty(B, dtype=torch.int64, device=lengths.device)
+    sc = (ctypes.c_int32 * n)(*[int(v) for v in scales])
+    ts = (ctypes.c_int32 * n)(*[int(v) for v in t_stage])
+    check(lib().ttsamd_stage_masks(P(flat), P(len_eff), P(lengths), B, int(quantum), int(add), sc, ts, n, stream_ptr()),
+          "stage_masks")
+    out, off = [], 0
+    for t in t_stage:
+        out.append(flat[off: off + B * int(t)].view(B, int(t)))
+        off += B * int(t)
+    return out, len_eff
+
+
+def replicate_pad(x, y, pad, lengths=None, len_bias=0):
     """y = F.pad(x, (pad, pad), 'replicate') on the last dim (hifigan_generator.py:281); with `lengths` [B] (int64)
     every item of the ragged batch replicates its own last valid frame."""
     if lengths is not None:
         B, C, T = x.shape
-        check(lib().ttsamd_replicate_pad_ragged(P(y), P(x), P(lengths.to(torch.int64).contiguous()), B, C, T, pad,
-                                                stream_ptr()), "replicate_pad_ragged")
+        check(lib().ttsamd_replicate_pad_ragged_ex(P(y), P(x), P(lengths.to(torch.int64).contiguous()),
+                                                   ctypes.c_int64(int(len_bias)), B, C, T, pad, stream_ptr()), "replicate_pad_ragged")
         return y
     rows = x.numel() // x.shape[-1]
     check(lib().ttsamd_replicate_pad(P(y), P(x), ctypes.c_int64(rows), x.shape[-1], pad, stream_ptr()),
@@ -363,10 +438,10 @@ def embed_cat(tokens, emb, mask, scale, extra, y):
     return y
 
 
-def sequence_mask(lengths, t):
-    """helpers.py:43-57 on the device; returns float [B, t]."""
+def sequence_mask(lengths, t, out=None):
+    """helpers.py:43-57 on the device; returns float [B, t] (written into `out` when given)."""
     lengths = lengths.to(torch.int64).contiguous()
-    mask = torch.empty((lengths.shape[0], t), dtype=torch.float32, device=lengths.device)
+    mask = torch.empty((lengths.shape[0], t), dtype=torch.float32, device=lengths.device) if out is None else out
     check(lib().ttsamd_sequence_mask(P(mask), P(lengths), lengths.shape[0], t, stream_ptr()), "sequence_mask")
     return mask
 
@@ -413,16 +488,19 @@ class _HostLengths:
         cls._tls.pool[n].append(item)
 
 
-def durations(logw, mask, length_scale, glow=False, durations_in=None, t_valid=None, want_max=False):
+def durations(logw, mask, length_scale, glow=False, durations_in=None, t_valid=None, want_max=False, out=None, host_out=None):
     """-> (w_ceil float [B,T], cum int32 [B,T], y_lengths int64 [B]) (include/tts_amd.h: ttsamd_durations_ex).
     t_valid: columns >= t_valid own no frames (text-length bucket padding).  want_max=True also returns max(y_lengths) as a
     Python int, read from a pinned host mirror the kernel writes (the request's ONE host wait) — not under stream capture."""
     src = logw if logw is not None else durations_in
     B, T = src.shape[0], src.shape[-1]
     dev = src.device
-    dur = torch.empty((B, T), dtype=torch.float32, device=dev)
-    cum = torch.empty((B, T), dtype=torch.int32, device=dev)
-    ylen = torch.empty((B,), dtype=torch.int64, device=dev)
+    if out is not None:         # (dur float [B,T], cum int32 [B,T], y_lengths int64 [B]): a model's per-stream scratch
+        dur, cum, ylen = out
+    else:
+        dur = torch.empty((B, T), dtype=torch.float32, device=dev)
+        cum = torch.empty((B, T), dtype=torch.int32, device=dev)
+        ylen = torch.empty((B,), dtype=torch.int64, device=dev)
     host = None
     if want_max:
         host = _HostLengths.take(B)
@@ -445,6 +523,8 @@ def durations(logw, mask, length_scale, glow=False, durations_in=None, t_valid=N
             elif now > deadline:
                 raise _lib.TtsAmdError("durations: the device did not publish y_lengths within 30 s (stalled stream?)")
     t_max = int(arr.max())
+    if host_out is not None:
+        host_out["y_lengths"] = [int(v) for v in arr]        # every item's frame count, already on the host
     _HostLengths.give(B, host)
     return dur, cum, ylen, t_max
 
@@ -458,7 +538,7 @@ def generate_path(cum, x_mask, y_lengths, t_y):
 
 
 def expand_prior(m, logs, noise, cum, x_mask, y_lengths, t_y, noise_scale, mask_out=False, want_stats=True,
-                 second_copy=False):
+                 second_copy=False, noise_packed=False):
     """vits.py:1152-1155 / glow_tts.py:137-148,361 as one gather -> dict(z_p, z_p2, m_p, logs_p, y_mask).
     m / logs [B,C,T_x] may be channel-slices of one projection buffer (row stride T_x, any batch stride)."""
     B, C, Tx = m.shape
@@ -470,9 +550,11 @@ def expand_prior(m, logs, noise, cum, x_mask, y_lengths, t_y, noise_scale, mask_
     m_p = new() if want_stats else None
     logs_p = new() if want_stats else None
     y_mask = torch.empty((B, t_y), dtype=torch.float32, device=dev)
-    check(lib().ttsamd_expand_prior(P(z_p), P(z_p2), P(m_p), P(logs_p), P(y_mask), P(m), P(logs), ctypes.c_int64(m.stride(0)), P(noise), P(cum),
-                                    P(x_mask), P(y_lengths), ctypes.c_float(noise_scale), int(mask_out), B, C, Tx,
-                                    t_y, stream_ptr()), "expand_prior")
+    # noise_packed: `noise` holds a contiguous [B, C, max(y_lengths)] draw at the head of a larger buffer (the draw at the
+    # reference's shape, placed in a graph's fixed scratch); columns beyond that extent read as zero
+    check(lib().ttsamd_expand_prior_ex(P(z_p), P(z_p2), P(m_p), P(logs_p), P(y_mask), P(m), P(logs), ctypes.c_int64(m.stride(0)), P(noise), P(cum),
+                                       P(x_mask), P(y_lengths), ctypes.c_float(noise_scale), int(mask_out), int(noise_packed), B, C, Tx,
+                                       t_y, stream_ptr()), "expand_prior")
     return {"z_p": z_p, "z_p2": z_p2, "m_p": m_p, "logs_p": logs_p, "y_mask": y_mask}
 
 

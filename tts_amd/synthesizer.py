@@ -65,6 +65,66 @@ def setup_tts_model(config):
     return _MODELS[name].init_from_config(cfg)
 
 
+class SentencePipeline:
+    """Glow-TTS -> mel seam -> HiFiGAN vocoder for one request (a sentence, or a ragged-exact batch of sentences) as TWO graph
+    replays around the request's one host wait — the reference runs `tts_model.inference`, two numpy normalisations and
+    `vocoder_model.inference` back to back per sentence (synthesizer.py:384-433):
+        graph 1   encoder + duration predictor                                   (GlowTTS.request_front)
+        eager     durations kernel; the host polls the output extent from a pinned mirror
+        graph 2   prior expansion -> 12 decoder flow blocks -> denormalize/normalize seam -> replicate pad + stage masks ->
+                  every vocoder conv, at the frame count padded to a multiple of 32 (the sentence runs ragged-exact inside)
+        eager     ONE copy of the valid samples out of the graph's fixed output buffer.
+    Nothing crosses to the host between the acoustic model and the vocoder; the mel never leaves channels-first layout."""
+
+    def __init__(self, tts_model, vocoder_g, tts_ap, vocoder_ap):
+        from . import graphs
+
+        self.tts, self.voc, self.ap_t, self.ap_v = tts_model, vocoder_g, tts_ap, vocoder_ap
+        self._graph = graphs.GraphCache(self._tail_eager, max_entries=12)
+        self._cfg = None
+        self.max_frames = 4096
+        self.launches = None       # kernel launches of the last captured tail (reported by bench.py)
+
+    def supported(self):
+        return isinstance(self.tts, GlowTTS) and self.tts.use_graphs and self.voc is not None
+
+    def clear(self):
+        self._graph.clear()
+
+    def _tail_eager(self, o_mean, o_logs, cum, x_mask, y_lengths, noise, g):
+        from . import ops
+
+        t_pad, noise_scale = self._cfg
+        pri = ops.expand_prior(o_mean, o_logs if o_logs.numel() else None, noise if noise.numel() else None, cum, x_mask,
+                               y_lengths, t_pad, noise_scale, mask_out=True, want_stats=False, noise_packed=True)
+        mel = self.tts.decoder(pri["z_p"], pri["y_mask"], g=g if g.numel() else None)            # [B, C, t_pad]
+        voc_in = mel_renorm_device(mel, self.ap_t, self.ap_v)                                    # synthesizer.py:412-416
+        # the vocoder reads every item as (y_lengths // num_squeeze) * num_squeeze frames long (+ its replicate padding)
+        return self.voc._inference_ragged(voc_in, y_lengths, quantum=self.tts.num_squeeze)
+
+    @torch.no_grad()
+    def __call__(self, x, aux_input=None, eager=False):
+        """-> (wav float32 [B, 1, max valid samples] on the device, [valid samples per item]) or None when the request does
+        not fit the fused path (the caller then runs the models one after the other).  eager=True issues the same launch
+        sequence one by one instead of replaying graphs (measurement / debugging)."""
+        from . import ops
+
+        tts = self.tts
+        ctx = tts.request_front(x, dict(aux_input or {}, no_graph=True) if eager else aux_input)
+        B, t_dec = ctx["B"], ctx["t_dec"]
+        t_pad = -(-t_dec // 32) * 32
+        if not ((ctx["graphing"] or eager) and (B == 1 or ctx["ragged"]) and B * t_pad <= self.max_frames):
+            return None
+        t_pad, inputs, stable = tts.tail_inputs(ctx, aux_input)
+        self._cfg = (t_pad, float(tts.inference_noise_scale))
+        self._graph.enabled = not eager
+        wav = self._graph(*inputs, key=self._cfg, stable=stable)
+        nsq, pad = tts.num_squeeze, self.voc.inference_padding
+        hop = wav.shape[-1] // (t_pad + 2 * pad)
+        lens = [((n // nsq) * nsq + 2 * pad) * hop for n in ctx["y_lengths_host"]]
+        return ops.clone_views([wav[:, :, : max(lens)]])[0], lens
+
+
 class Synthesizer:
     def __init__(self, tts_checkpoint="", tts_config_path="", tts_speakers_file="", tts_languages_file="",
                  vocoder_checkpoint="", vocoder_config="", encoder_checkpoint="", encoder_config="", vc_checkpoint="",
@@ -101,6 +161,9 @@ class Synthesizer:
             self.vocoder_model.cuda()
             self.output_sample_rate = _get(_get(self.vocoder_config, "audio", {}), "sample_rate", self.output_sample_rate)
         self.device = next(self.tts_model.parameters()).device if self.tts_model._sd is not None else torch.device("cuda")
+        self.pipeline = None
+        if self.vocoder_model is not None:
+            self.pipeline = SentencePipeline(self.tts_model, self.vocoder_model.model_g, self.tts_model.ap, self.vocoder_ap)
 
     @staticmethod
     def split_into_sentences(text):
@@ -203,6 +266,16 @@ class Synthesizer:
             for r, dr in enumerate(durations):
                 d[r, : len(ids[r])] = torch.as_tensor(dr, dtype=torch.float32).reshape(-1)[: len(ids[r])]
             aux["durations"] = d.to(dev)
+        sr_t = _get(_get(self.tts_config, "audio", {}), "sample_rate", 22050)
+        sr_v = _get(_get(self.vocoder_config, "audio", {}), "sample_rate", 22050) if self.vocoder_config is not None else sr_t
+        do_trim = trim and bool(_get(_get(self.tts_config, "audio", {}), "do_trim_silence", False))
+        if self.pipeline is not None and self.pipeline.supported() and sr_t == sr_v:
+            fused = self.pipeline(x.to(dev), aux)           # acoustic model -> seam -> vocoder without leaving the device
+            if fused is not None:
+                wav, lens = fused
+                wav = wav.float().cpu().numpy().reshape(len(ids), -1)
+                res = [wav[r, : int(lens[r])] for r in range(len(ids))]
+                return [w[: self.tts_model.ap.find_endpoint(w)] for w in res] if do_trim else res
         out = self.tts_model.inference(x.to(dev), aux)
         frames = out["y_lengths"]
         if self.vocoder_model is None:
@@ -210,8 +283,6 @@ class Synthesizer:
             lens = (frames * (wav.shape[-1] // out["y_mask"].shape[-1])).tolist()
         else:
             mel = out["model_outputs"].transpose(1, 2)                        # [B,C,T]
-            sr_t = _get(_get(self.tts_config, "audio", {}), "sample_rate", 22050)
-            sr_v = _get(_get(self.vocoder_config, "audio", {}), "sample_rate", 22050)
             voc_in = mel_renorm_device(mel, self.tts_model.ap, self.vocoder_ap)
             if isinstance(self.tts_model, GlowTTS):                           # squeeze drops an odd last frame
                 nsq = self.tts_model.num_squeeze
@@ -236,7 +307,6 @@ class Synthesizer:
             lens = ((frames + 2 * pad) * hop_total).tolist()
         wav = wav.float().cpu().numpy().reshape(len(ids), -1)
         res = []
-        do_trim = trim and bool(_get(_get(self.tts_config, "audio", {}), "do_trim_silence", False))
         for r in range(len(ids)):
             w = wav[r, : int(lens[r])]
             if do_trim:

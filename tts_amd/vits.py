@@ -43,6 +43,13 @@ class _Args(dict):
         self[k] = v
 
 
+def _pad_cols(d, T):
+    """[B, T0] -> [B, T] zero-extended."""
+    out = torch.zeros((d.shape[0], T), dtype=d.dtype, device=d.device)
+    out[:, : d.shape[1]] = d
+    return out
+
+
 class Vits:
     def __init__(self, config=None, ap=None, tokenizer=None, speaker_manager=None, language_manager=None):
         self.config = config
@@ -95,6 +102,7 @@ class Vits:
         # shape; set `use_graphs = False` for eager launches
         self.use_graphs = True
         self._front = graphs.GraphCache(self._front_eager)
+        self._scratch = graphs.StreamScratch()       # per-stream fixed buffers the graphs read in place (see inference)
         # Small requests (the reference's own call pattern is ONE sentence at a time, synthesizer.py:384) are launch-bound
         # end to end: everything after the one host sync (prior expansion, flows, waveform decoder: ~110 launches on three
         # streams) replays as a second hipGraph.  The decoder length is padded to a multiple of 32 frames so that requests
@@ -200,10 +208,13 @@ class Vits:
         t_pad, noise_scale = self._tail_cfg
         B, H = stats.shape[0], self.args.hidden_channels
         g = g if g.numel() else None
-        pri = ops.expand_prior(stats[:, :H], stats[:, H:], noise_z, cum, x_mask, y_lengths, t_pad, noise_scale, second_copy=True)
+        # noise_z: the packed [B, C, max(y_lengths)] draw at the head of the [B, C, t_pad] scratch buffer
+        pri = ops.expand_prior(stats[:, :H], stats[:, H:], noise_z, cum, x_mask, y_lengths, t_pad, noise_scale, second_copy=True,
+                               noise_packed=True)
         attn = ops.generate_path(cum, x_mask, y_lengths, t_pad)
         z = self.flow(pri["z_p2"], pri["y_mask"], g=g)
-        o = self.waveform_decoder.forward(z, g=g, in_mask=pri["y_mask"], lengths=y_lengths)
+        # (z * y_mask: the decoder's own stage-0 length mask IS y_mask — sequence_mask(y_lengths) — so no separate in_mask)
+        o = self.waveform_decoder.forward(z, g=g, lengths=y_lengths)
         return o, attn, z, pri["z_p"], pri["m_p"], pri["logs_p"], pri["y_mask"]
 
     def _speaker_g(self, aux_input, B, dev):
@@ -339,79 +350,122 @@ class Vits:
         # positions the values of the unpadded run), so 16 lengths share one capture; outputs are cut back at the end.
         T0 = T
         need_dp = durations is None or bool((aux_input or {}).get("run_duration_predictor"))
-        if self.use_graphs and not no_graph and need_dp and self.text_bucket > 1 and T % self.text_bucket:
+        graphing = bool(self.use_graphs) and not no_graph
+        if graphing and need_dp and self.text_bucket > 1 and T % self.text_bucket:
             T = -(-T // self.text_bucket) * self.text_bucket
+        H = a.hidden_channels
+        # Everything a graphed request writes before a replay lives in per-stream scratch at fixed addresses (the graphs read
+        # it in place): the request's eager launches are then ONE staging copy (ids, pinned noise), the mask, the noise draws,
+        # the durations kernel and ONE launch for all output copies — a tensor library issued ~30 small launches here.
+        sc = None
+        if graphing:
+            sc = self._scratch.get((B, T), lambda: dict(
+                x=torch.zeros((B, T), dtype=torch.int64, device=dev), x_mask=torch.empty((B, T), dtype=torch.float32, device=dev),
+                noise_dp=torch.zeros((B, 2, T), dtype=torch.float32, device=dev),
+                dur=torch.empty((B, T), dtype=torch.float32, device=dev), cum=torch.empty((B, T), dtype=torch.int32, device=dev),
+                ylen=torch.empty((B,), dtype=torch.int64, device=dev)))
+        stage_dst, stage_src = [], []
+        if sc is not None:
+            # pad ids beyond T0 (left over from an earlier request of the same bucket) are masked out by x_mask — exactly the
+            # situation of a shorter sentence inside a batch
+            stage_dst.append(sc["x"][:, :T0])
+            stage_src.append(x)
+            x = sc["x"]
+        elif T != T0:
             xp = torch.zeros((B, T), dtype=torch.int64, device=dev)
             xp[:, :T0] = x
             x = xp
-        x_mask = ops.sequence_mask(x_lengths.to(dev), T)
+        x_mask = ops.sequence_mask(x_lengths.to(dev), T, out=None if sc is None else sc["x_mask"])
         g = self._speaker_g(aux_input, B, dev)
         g_dp = g if a.condition_dp_on_speaker else None
         lang = self._language_emb(aux_input, B, dev)
-        H = a.hidden_channels
+        empty = torch.empty(0, device=dev)
         # the reference skips the duration predictor when durations are injected (vits.py:1124-1143);
         # "run_duration_predictor" keeps it in the pass anyway (bench.py: fixed output length, no work skipped)
         logw = None
         if need_dp:
             noise_dp = aux_input.get("noise_dp") if aux_input else None
-            if noise_dp is None:     # drawn at the reference's shape [B, 2, T0] (a fixed seed gives the same draw, bucketed or not)
-                noise_dp = torch.randn(B, 2, T0, device=dev, dtype=torch.float32) if a.use_sdp else torch.empty(0, device=dev)
-            noise_dp = noise_dp.to(dev, torch.float32).contiguous()
-            if T != T0 and noise_dp.numel():
-                nd = torch.zeros((B, 2, T), dtype=torch.float32, device=dev)
-                nd[:, :, :T0] = noise_dp
-                noise_dp = nd
-            gd = g_dp if g_dp is not None else torch.empty(0, device=dev)
-            self._front.enabled = bool(self.use_graphs) and not (aux_input or {}).get("no_graph", False)
-            ld = lang if lang is not None else torch.empty(0, device=dev)
-            h, stats, logw = self._front(x, x_mask, noise_dp, gd, ld, key=float(self.inference_noise_scale_dp))
+            if not a.use_sdp:
+                noise_dp = empty
+            elif sc is not None:
+                # drawn at the reference's shape [B, 2, T0] (a fixed seed gives the same draw, bucketed or not); columns of the
+                # bucket beyond T0 keep whatever an earlier request left there: masked positions, as in a batch
+                if noise_dp is None and T == T0:
+                    torch.randn((B, 2, T0), device=dev, dtype=torch.float32, out=sc["noise_dp"])
+                else:
+                    nd = torch.randn(B, 2, T0, device=dev, dtype=torch.float32) if noise_dp is None else \
+                        noise_dp.to(dev, torch.float32)
+                    stage_dst.append(sc["noise_dp"][:, :, :T0])
+                    stage_src.append(nd)
+                noise_dp = sc["noise_dp"]
+            else:
+                if noise_dp is None:
+                    noise_dp = torch.randn(B, 2, T0, device=dev, dtype=torch.float32)
+                noise_dp = noise_dp.to(dev, torch.float32).contiguous()
+                if T != T0:
+                    nd = torch.zeros((B, 2, T), dtype=torch.float32, device=dev)
+                    nd[:, :, :T0] = noise_dp
+                    noise_dp = nd
+            if stage_dst:
+                ops.copy_into(stage_dst, stage_src)
+            gd = g_dp if g_dp is not None else empty
+            self._front.enabled = graphing
+            ld = lang if lang is not None else empty
+            h, stats, logw = self._front(x, x_mask, noise_dp, gd, ld, key=float(self.inference_noise_scale_dp),
+                                         stable=(0, 1, 2) if (sc is not None and a.use_sdp) else ((0, 1) if sc is not None else ()))
         else:
+            if stage_dst:
+                ops.copy_into(stage_dst, stage_src)
             h, stats = self.text_encoder(x, x_mask, lang=None if lang is None else lang[:, :, 0])
+        dout = None if sc is None else (sc["dur"], sc["cum"], sc["ylen"])
         if durations is None:
-            w_ceil, cum, y_lengths, t_dec = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), want_max=True)
+            w_ceil, cum, y_lengths, t_dec = ops.durations(logw.contiguous(), x_mask, float(self.length_scale), want_max=True,
+                                                          out=dout)
         else:
             d = durations.to(dev, torch.float32).reshape(B, T0).contiguous()      # vits.py:1141-1143 (+ batches)
-            if T != T0:
-                dp = torch.zeros((B, T), dtype=torch.float32, device=dev)
-                dp[:, :T0] = d
-                d = dp
-            w_ceil, cum, y_lengths, t_dec = ops.durations(None, x_mask, 1.0, durations_in=d, want_max=True)
+            w_ceil, cum, y_lengths, t_dec = ops.durations(None, x_mask, 1.0, durations_in=d if T == T0 else _pad_cols(d, T),
+                                                          want_max=True, out=dout)
         # t_dec = max(y_lengths): the request's one host wait (the output extent), polled from a pinned mirror
         noise_z = aux_input.get("noise_z") if aux_input else None
         ragged = bool(aux_input.get("ragged_exact")) if aux_input else False
         t_pad = -(-t_dec // 32) * 32
-        if (self.use_graphs and not no_graph and (B == 1 or ragged) and self.interpolate_factor is None
+        if (graphing and sc is not None and (B == 1 or ragged) and self.interpolate_factor is None
                 and self.max_inference_len is None and B * t_pad <= self.graph_tail_max_frames):
             # The draw happens OUTSIDE the captured segment, at the reference's shape [B, C, t_dec] (randn_like(m_p),
             # vits.py:1155): with a fixed torch seed the audio is then the same whether the tail replays as a graph, runs
             # eagerly, or was captured earlier (a draw inside the segment would be [B, C, t_pad] and the capture's warm-up
-            # runs would advance the generator).  Zero-extended to the padded length (masked there).
+            # runs would advance the generator).  It lands packed at the head of the tail's fixed noise buffer; the kernel
+            # reads columns beyond t_dec as zero (masked there anyway).
+            nzb = self._scratch.get(("nz", B, t_pad), lambda: torch.zeros(B * H * t_pad, dtype=torch.float32, device=dev))
+            packed = nzb[: B * H * t_dec].view(B, H, t_dec)
             if noise_z is None:
-                noise_z = torch.randn(B, H, t_dec, device=dev, dtype=torch.float32)
-            nz = torch.zeros(B, H, t_pad, device=dev, dtype=torch.float32)
-            nz[:, :, :t_dec] = noise_z.to(dev, torch.float32)
+                torch.randn((B, H, t_dec), device=dev, dtype=torch.float32, out=packed)
+            else:
+                assert tuple(noise_z.shape) == (B, H, t_dec), "noise_z must be [B, C, T_dec]"
+                ops.copy_into([packed], [noise_z.to(dev, torch.float32)])
             self._tail.enabled = True
             self._tail_cfg = (t_pad, float(self.inference_noise_scale))
             o, attn, z, z_p, m_p, logs_p, y_mask = self._tail(
-                stats.contiguous(), cum, x_mask, y_lengths, nz, g if g is not None else torch.empty(0, device=dev),
-                key=self._tail_cfg)
+                stats, cum, x_mask, y_lengths, nzb.view(B, H, t_pad), g if g is not None else empty,
+                key=self._tail_cfg, stable=(0, 1, 2, 3, 4) if (need_dp and self._front.last_static) else (1, 2, 3, 4))
             hop = o.shape[-1] // t_pad
-            # the graph's outputs are static buffers (overwritten by its next replay): hand out copies, cut to the true extent
-            outputs = {
-                "model_outputs": o[:, :, : t_dec * hop].clone(),
-                "alignments": attn[:, :, :t_dec].clone(),
-                "durations": w_ceil.unsqueeze(1).clone(),
-                "z": z[:, :, :t_dec].clone(),
-                "z_p": z_p[:, :, :t_dec].clone(),
-                "m_p": m_p[:, :, :t_dec].clone(),
-                "logs_p": logs_p[:, :, :t_dec].clone(),
-                "y_mask": y_mask[:, :t_dec].unsqueeze(1).clone(),
-            }
-            if ragged:
-                outputs["y_lengths"] = y_lengths.clone()
-            if aux_input and aux_input.get("return_extras"):
-                outputs.update(x=h.clone(), logw=None if logw is None else logw.clone().unsqueeze(1), y_lengths=y_lengths.clone())
-            return self._cut_text(outputs, T0, T)
+            # the graph's outputs are static buffers (overwritten by its next replay): hand out copies, cut to the true
+            # extent (and to the caller's T0 tokens) — ONE launch for all of them
+            extras = bool(aux_input and aux_input.get("return_extras"))
+            views = [o[:, :, : t_dec * hop], attn[:, :T0, :t_dec], w_ceil[:, :T0].unsqueeze(1), z[:, :, :t_dec], z_p[:, :, :t_dec],
+                     m_p[:, :, :t_dec], logs_p[:, :, :t_dec], y_mask[:, :t_dec].unsqueeze(1),
+                     y_lengths if (ragged or extras) else None, h[:, :, :T0] if extras else None,
+                     logw[:, :T0].unsqueeze(1) if (extras and logw is not None) else None]
+            c = ops.clone_views(views)
+            outputs = {"model_outputs": c[0], "alignments": c[1], "durations": c[2], "z": c[3], "z_p": c[4], "m_p": c[5],
+                       "logs_p": c[6], "y_mask": c[7]}
+            if ragged or extras:
+                outputs["y_lengths"] = c[8]
+            if extras:
+                outputs.update(x=c[9], logw=c[10])
+            return outputs
+        if sc is not None:      # the eager tail hands its tensors out: they must not alias the per-stream scratch
+            w_ceil, cum, y_lengths, x_mask = ops.clone_views([w_ceil, cum, y_lengths, x_mask])
         if noise_z is None:
             noise_z = torch.randn(B, H, t_dec, device=dev, dtype=torch.float32)
         noise_z = noise_z.to(dev, torch.float32).contiguous()
@@ -433,7 +487,8 @@ class Vits:
         md = y_mask if self.max_inference_len is None else y_mask[:, : self.max_inference_len].contiguous()
         # "ragged_exact": every decoder conv treats row b as ending at y_lengths[b] -> row b equals a B=1 run (bitwise
         # when both runs take the same conv tile family, fp32 reassociation otherwise: see HifiganGenerator.forward)
-        o = self.waveform_decoder.forward(zd, g=g, in_mask=md, lengths=dec_lengths if ragged else None)  # (z*y_mask)[:, :, :max_len]
+        # (z*y_mask)[:, :, :max_len]; ragged: the decoder's stage-0 length mask equals md (sequence_mask(dec_lengths) cut at max_len)
+        o = self.waveform_decoder.forward(zd, g=g, in_mask=None if ragged else md, lengths=dec_lengths if ragged else None)
         outputs = {
             "model_outputs": o,
             "alignments": attn,
