@@ -103,8 +103,9 @@ int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, 
 #define TTSAMD_ACT_GELU 3  /* norm kernel only: exact erf GELU (F.gelu default) */
 
 #define TTSAMD_CONV_NORMAL 0
-/* WN gate: packed row tile 2a = tanh channels [32a,32a+32), tile 2a+1 = sigmoid channels; writes
- * tanh(.)*sigmoid(.) to out channel 32a+i (wavenet.py:6-13). c_out = number of packed rows (2H). */
+/* WN gate (ABI v2 row order): packed 32-row tile m = tanh channels [16m, 16m+16) then the matching sigmoid channels;
+ * writes tanh(.)*sigmoid(.) to out channel 16m+i (wavenet.py:6-13). c_out = number of packed rows (2H, H % 16 == 0 or the
+ * last tile zero-padded per half). */
 #define TTSAMD_CONV_GATE 1
 /* ConvTranspose1d (kernel 2u, stride u, pad u/2) in polyphase form: packed row m = co*u + r holds
  * the 2-tap filter of phase r; column q is written to y[b, co, q*u + r - shuffle_pad]. */
@@ -114,10 +115,10 @@ int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, 
 /* WN res/skip 1x1 conv (wavenet.py:109-114): rows < split_row: y[row] = (res[row] + v) * out_mask;
  * rows >= split_row: y2[row-split_row] = accum[row-split_row] + v (accum may be NULL: first layer). */
 #define TTSAMD_CONV_RES_SKIP 4
-/* Glow affine coupling (glow.py:216-224): packed row tile pairs like GATE: tile 2a = t rows, 2a+1 = s rows;
- * y[32a+i] = (res[32a+i] - t) * exp(-s) * out_mask.  c_out = packed rows (2 * coupled channels). */
+/* Glow affine coupling (glow.py:216-224): packed rows paired like GATE: tile m = t rows of channels [16m, 16m+16) then their
+ * s rows; y[16m+i] = (res[16m+i] - t) * exp(-s) * out_mask.  c_out = packed rows (32 per tile; split_row = coupled channels). */
 #define TTSAMD_CONV_COUPLE_AFFINE 5
-/* forward direction of the same coupling (glow.py:225): y[32a+i] = (t + exp(s) * res[32a+i]) * out_mask */
+/* forward direction of the same coupling (glow.py:225): y[16m+i] = (t + exp(s) * res[16m+i]) * out_mask */
 #define TTSAMD_CONV_COUPLE_AFFINE_FWD 6
 
 typedef struct ttsamd_conv1d_args {
@@ -173,9 +174,11 @@ int ttsamd_conv1d_supported(int kernel, int dilation);
 /* Launches that would put fewer than ~100 blocks on the chip (single-sentence requests): 0 = the large-grid tiles
  * everywhere, 1 = 64-column tiles with one 32x32 tile per wave (same summation order: bitwise the large-grid result),
  * 2 = those tiles plus, for c_in >= 128, wave groups that split the block's K loop and are reduced in a fixed order
- * (deterministic; fp32 reassociation relative to modes 0 / 1), 3 (default) = as 2, with the small-grid kernels of
+ * (deterministic; fp32 reassociation relative to modes 0 / 1), 3 = as 2, with the small-grid kernels of
  * conv_kernel_x3s.h for kernel sizes <= 5 at dilation 1: a wave per 32x32 tile and K slice, weights requested a whole
- * K iteration ahead, straight-line request streams.  Returns the previous mode. */
+ * K iteration ahead, straight-line request streams; 4 (default) = as 3, with the one-shot kernels of conv_kernel_x3o.h
+ * first where the reduction fits 16 waves (dilation 1, k in {1,3,5,7}, up to 640 32x32 tiles): no K loop, the epilogue
+ * spread over four waves.  Returns the previous mode. */
 int ttsamd_conv1d_set_small_grid(int mode);
 
 /* One ResBlock1 iteration of the HiFiGAN MRF as a single launch — replaces the body of the loop in

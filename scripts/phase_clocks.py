@@ -12,13 +12,18 @@ from tts_amd import ops  # noqa: E402
 
 
 def run(spec):
-    B, C, K, D, T, Cin = map(int, spec.split(","))
+    v = list(map(int, spec.split(",")))
+    B, C, K, D, T, Cin = v[:6]
+    mode = v[6] if len(v) > 6 else 0          # 1 = GATE (C = 2 * hidden rows in, hidden rows out)
     dev = "cuda:0"
     pc = ops.PackedConv(torch.randn(C, Cin, K) / (Cin * K) ** 0.5, torch.randn(C), dev, dilation=D)
     x = torch.randn(B, Cin, T, device=dev)
-    y = torch.empty(B, C, T, device=dev)
+    y = torch.empty(B, C // 2 if mode == 1 else C, T, device=dev)
     y2 = torch.zeros(1, 1, 16, device=dev, dtype=torch.float32)
-    f = lambda: ops.conv1d(pc, x, y, in_act=ops.ACT_LRELU, in_slope=0.1, y2=y2)  # noqa: E731
+    if mode == 1:
+        f = lambda: ops.conv1d(pc, x, y, mode=ops.CONV_GATE, y2=y2)  # noqa: E731
+    else:
+        f = lambda: ops.conv1d(pc, x, y, y2=y2)  # noqa: E731
     for _ in range(3):
         f()
     torch.cuda.synchronize()

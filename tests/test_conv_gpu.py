@@ -285,13 +285,16 @@ def test_single_output_channel_streaming_conv(gpu, case, conv_precision):
                                   (1, 200, 100, 7, 300, 0), (1, 144, 64, 3, 65, 0), (3, 256, 256, 3, 40, 0),
                                   (1, 192, 576, 1, 257, 0), (1, 256, 192, 1, 257, 0), (2, 208, 64, 1, 130, 0), (1, 400, 128, 1, 70, 0),
                                   (1, 192, 192, 5, 257, 0), (1, 130, 64, 5, 64, 0), (1, 192, 384, 3, 300, 1), (2, 256, 256, 5, 63, 1),
-                                  (1, 512, 256, 3, 770, 0), (1, 256, 256, 3, 6000, 0), (1, 192, 256, 1, 5000, 0)])
+                                  (1, 512, 256, 3, 770, 0), (1, 256, 256, 3, 6000, 0), (1, 192, 256, 1, 5000, 0),
+                                  (1, 80, 192, 1, 159, 0), (1, 80, 128, 7, 338, 0), (1, 192, 512, 7, 770, 0), (1, 192, 80, 1, 64, 0),
+                                  (1, 256, 1, 1, 64, 0), (1, 100, 104, 3, 33, 1), (1, 48, 40, 5, 20, 1), (2, 64, 96, 7, 31, 0)])
 def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
     """Launches that underfill the chip (single-sentence shapes): mode 1 (64-column tiles, one 32x32 tile per wave) is
     bitwise the large-grid result; mode 2 adds wave groups that split the K loop (chunk counts that do not divide by the
     group count included); mode 3 takes the small-grid kernels of conv_kernel_x3s.h (single-iteration 1x1 convs at <= 192 channels,
     multi-iteration ones with a partly filled last iteration, halo rounds of k = 3 / 5, paired gate rows, eight K slices at
-    >= 512 channels, 64x64 tiles on the longer launches).
+    >= 512 channels, 64x64 tiles on the longer launches); mode 4 (default) takes the one-shot kernels of conv_kernel_x3o.h
+    first (a wave per K slice, 4 / 8 / 12 / 16 of them, the epilogue spread over four waves).
     All stay within the conv tolerance of torch and of mode 0."""
     B, Cin, Cout, K, T, gate = case
     g = torch.Generator().manual_seed(sum(case))
@@ -309,7 +312,7 @@ def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
         want = pre + res
         pc = ops.PackedConv(w, b, gpu)
     outs = {}
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         was = ops.set_conv_small_grid(mode)
         try:
             y = torch.full(want.shape, float("nan"), device=gpu)
@@ -323,5 +326,67 @@ def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
         outs[mode] = y
     if conv_precision == "x3":
         assert torch.equal(outs[0], outs[1])
-        for mode in (2, 3):
+        for mode in (2, 3, 4):
             assert _rel(outs[mode], outs[0]) < 2e-6, mode
+
+
+@pytest.mark.parametrize("T", [159, 31, 770])
+def test_one_shot_kernel_fused_epilogues(gpu, T, conv_precision):
+    """The one-shot small-grid kernel (conv_kernel_x3o.h) under every fused 1x1 epilogue of the flows — WaveNet res/skip split,
+    mean-only coupling, Glow's affine coupling both ways with a partly filled last pair tile (80 channels) — with per-item
+    row biases and a ragged mask, against torch; and against the looping kernels (small-grid mode 3)."""
+    g = torch.Generator().manual_seed(T)
+    B, H = 2, 192
+    dev = gpu
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, max(1, T - 7)])[:, None]).float()
+    acts = torch.randn(B, H, T, generator=g)
+    outs = {}
+    for mode in (3, 4):
+        was = ops.set_conv_small_grid(mode)
+        try:
+            # res/skip: rows < H: x = (x + v) * mask, rows >= H: out = out + v
+            w = torch.randn(2 * H, H, 1, generator=torch.Generator().manual_seed(1)) / np.sqrt(H)
+            b = torch.randn(2 * H, generator=torch.Generator().manual_seed(2)) * 0.1
+            x0 = torch.randn(B, H, T, generator=torch.Generator().manual_seed(3))
+            o0 = torch.randn(B, H, T, generator=torch.Generator().manual_seed(4))
+            v = F.conv1d(acts, w, b)
+            want_x, want_o = (x0 + v[:, :H]) * mask[:, None], o0 + v[:, H:]
+            xg, og = x0.to(dev), o0.to(dev)
+            ops.conv1d(ops.PackedConv(w, b, dev), acts.to(dev), xg, mode=ops.CONV_RES_SKIP, res=xg, out_mask=mask.to(dev), y2=og,
+                       accum=og, split_row=H)
+            assert _rel(xg, want_x) < TOL and _rel(og, want_o) < TOL, mode
+            # Glow affine coupling, reverse and forward, 80 coupled channels of a 160-channel tensor, in place
+            half = 80
+            we = torch.randn(2 * half, H, 1, generator=torch.Generator().manual_seed(5)) / np.sqrt(H)
+            be = torch.randn(2 * half, generator=torch.Generator().manual_seed(6)) * 0.1
+            wp, bp = ops.pair_permute(we, be, half, half)
+            pc = ops.PackedConv(wp, bp, dev)
+            z = torch.randn(B, 2 * half, T, generator=torch.Generator().manual_seed(7))
+            ts = F.conv1d(acts, we, be)
+            t_, s_ = ts[:, :half], ts[:, half:]
+            want_r, want_f = z.clone(), z.clone()
+            want_r[:, half:] = (z[:, half:] - t_) * torch.exp(-s_) * mask[:, None]
+            want_f[:, half:] = (t_ + torch.exp(s_) * z[:, half:]) * mask[:, None]
+            for cmode, want in ((ops.CONV_COUPLE_AFFINE, want_r), (ops.CONV_COUPLE_AFFINE_FWD, want_f)):
+                zg = z.to(dev)
+                ops.conv1d(pc, acts.to(dev), zg, mode=cmode, res=zg, res_row_offset=half, y_row_offset=half, out_mask=mask.to(dev),
+                           split_row=half)
+                assert _rel(zg, want) < TOL, (mode, cmode)
+                outs[(mode, cmode)] = zg
+            # gate with a per-item row bias (speaker conditioning)
+            wg = torch.randn(2 * H, H, 5, generator=torch.Generator().manual_seed(8)) / np.sqrt(5 * H)
+            bg = torch.randn(2 * H, generator=torch.Generator().manual_seed(9)) * 0.1
+            rb = torch.randn(B, 2 * H, generator=torch.Generator().manual_seed(10)) * 0.3
+            pre = F.conv1d(acts, wg, bg, padding=2) + rb[:, :, None]
+            want_g = torch.tanh(pre[:, :H]) * torch.sigmoid(pre[:, H:])
+            wgp, bgp = ops.gate_permute(wg, bg, H)
+            idx = torch.tensor(ops.pair_index(H, H))
+            y = torch.empty(B, H, T, device=dev)
+            ops.conv1d(ops.PackedConv(wgp, bgp, dev), acts.to(dev), y, mode=ops.CONV_GATE, row_bias=rb[:, idx].contiguous().to(dev))
+            assert _rel(y, want_g) < TOL, mode
+            outs[(mode, "gate")] = y
+        finally:
+            ops.set_conv_small_grid(was)
+    if conv_precision == "x3":
+        for k in (ops.CONV_COUPLE_AFFINE, ops.CONV_COUPLE_AFFINE_FWD, "gate"):
+            assert _rel(outs[(4, k)], outs[(3, k)]) < 2e-6, k

@@ -100,8 +100,8 @@ def test_xtts_hifi_decoder_matches_oracle_and_reference_golden(gpu):
 
 @pytest.mark.parametrize("length_scale", [1.0, 1.25])
 def test_xtts_streaming_chunker(gpu, length_scale):
-    """Vocoder half of Xtts.inference_stream (xtts.py:653-687): chunks from the tail-window streamer are bit-identical
-    to the reference schedule (re-vocode the whole prefix per chunk) on the HIP path, and both match the oracle's
+    """Vocoder half of Xtts.inference_stream (xtts.py:653-687): chunks from the tail-window streamer equal (to fp32 re-association)
+    the reference schedule (re-vocode the whole prefix per chunk) on the HIP path, and both match the oracle's
     restatement run on the CPU; the window does O(n) generator work instead of O(n^2)."""
     from tts_amd.xtts_decoder import HifiDecoder
     from tts_amd.xtts_stream import XttsStreamer
@@ -121,16 +121,22 @@ def test_xtts_streaming_chunker(gpu, length_scale):
     assert len(a) == len(b) == len(want) == 5            # 4 full chunks + the final flush with the 7 leftover
     for ca, cb, cw in zip(a, b, want):
         assert ca.shape == cb.shape == cw.shape
-        assert torch.equal(ca, cb)
+        # (not bitwise: the window's short launches and the prefix's long ones may take different conv tile families — the
+        # small-grid kernels cut K into slices — which re-associates the fp32 sums)
+        if ca.numel():
+            assert _errs(ca, cb)[1] < 2e-6
         if cw.numel():
             rms, rel = _errs(ca, cw)
             assert rms < 1e-4 and rel < 1e-5, (rms, rel)
     assert win.frames_decoded < 0.6 * full.frames_decoded
 
 
-def test_inference_slabbed_equals_inference_bitwise(gpu):
+def test_inference_slabbed_equals_inference(gpu):
     """BASELINE configs[2] runs through `inference_slabbed` (the batch cut into slabs that fit HBM): items are independent,
-    so a 3-slab run must reproduce the unslabbed call bit for bit — device output, host output and preallocated `out`."""
+    so a 3-slab run reproduces the unslabbed call — device output, host output and preallocated `out` — up to the fp32
+    re-association of a different conv tile family (the launcher picks the small-grid kernels, which cut K into slices, from
+    the launch's total block count: a 1-item slab and the 7-item batch differ there); the device and the host path of the
+    SAME slabbing are bit-identical."""
     cfg = dict(W.HIFIGAN_V1, upsample_initial_channel=64)
     sd = O.make_hifigan_state(cfg, 80, seed=21)
     m = _make(cfg, 80, gpu, sd)
@@ -139,11 +145,11 @@ def test_inference_slabbed_equals_inference_bitwise(gpu):
     widest = max((64 >> (i + 1)) * h for i, h in enumerate((8, 64, 128, 256)))
     per_item = 6 * 4 * widest * (40 + 10)
     got = m.inference_slabbed(mel.to(gpu), max_live_bytes=3 * per_item)          # slabs of 3, 3, 1 items
-    assert torch.equal(got, want)
+    assert _errs(got, want)[1] < 2e-6
     host = torch.empty(want.shape, dtype=torch.float32)
     m.inference_slabbed(mel, out=host, max_live_bytes=3 * per_item)              # host mels -> host waveforms
     torch.cuda.synchronize()
-    assert torch.equal(host, want.cpu())
+    assert torch.equal(host, got.cpu())
 
 
 def test_inference_slabbed_full_width_against_oracle(gpu):

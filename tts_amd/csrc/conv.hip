@@ -7,18 +7,18 @@
 using namespace ttsamd;
 
 namespace ttsamd {
-// small-grid policy (see ttsamd_conv1d_set_small_grid); TTSAMD_CONV_SMALL_GRID=<0..3> overrides the default for A/B runs
+// small-grid policy (see ttsamd_conv1d_set_small_grid); TTSAMD_CONV_SMALL_GRID=<0..4> overrides the default for A/B runs
 int g_conv_small_grid = [] {
     const char *e = getenv("TTSAMD_CONV_SMALL_GRID");
-    const int m = e ? atoi(e) : 3;
-    return m < 0 ? 0 : (m > 3 ? 3 : m);
+    const int m = e ? atoi(e) : 4;
+    return m < 0 ? 0 : (m > 4 ? 4 : m);
 }();
 }
 
 extern "C" int ttsamd_conv1d_set_small_grid(int mode)
 {
     const int was = g_conv_small_grid;
-    g_conv_small_grid = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
+    g_conv_small_grid = mode < 0 ? 0 : (mode > 4 ? 4 : mode);
     return was;
 }
 
@@ -132,10 +132,10 @@ extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
     TTSAMD_CHECK_ARG(a.c_in > 0 && a.c_out > 0 && a.batch >= 0 && a.t_in >= 0 && a.t_out >= 0, "conv1d: bad shape");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_COUPLE || a.res, "conv1d: COUPLE needs res");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_SHUFFLE || a.shuffle_u > 0, "conv1d: SHUFFLE needs shuffle_u");
-    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_GATE || (a.c_out % 64) == 0, "conv1d: GATE needs c_out %% 64 == 0");
+    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_GATE || (a.c_out % 32) == 0, "conv1d: GATE needs c_out %% 32 == 0 (whole 16 + 16 row tiles)");
     TTSAMD_CHECK_ARG((a.mode != TTSAMD_CONV_COUPLE_AFFINE && a.mode != TTSAMD_CONV_COUPLE_AFFINE_FWD) ||
-                         ((a.c_out % 64) == 0 && a.res && a.split_row > 0),
-                     "conv1d: COUPLE_AFFINE needs c_out %% 64 == 0, res and split_row");
+                         ((a.c_out % 32) == 0 && a.res && a.split_row > 0),
+                     "conv1d: COUPLE_AFFINE needs c_out %% 32 == 0 (whole 16 + 16 row tiles), res and split_row");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_RES_SKIP || (a.res && a.y2 && a.split_row > 0 && a.split_row % 32 == 0),
                      "conv1d: RES_SKIP needs res, y2 and split_row %% 32 == 0");
     TTSAMD_CHECK_ARG(a.mode >= 0 && a.mode <= TTSAMD_CONV_COUPLE_AFFINE_FWD, "conv1d: unknown mode %d", a.mode);

@@ -3,6 +3,7 @@
 #include "conv_kernel.h"
 #include "conv_kernel_x3.h"
 #include "conv_kernel_x3s.h"
+#include "conv_kernel_x3o.h"
 
 namespace ttsamd {
 

@@ -134,9 +134,23 @@ __device__ __forceinline__ bool conv_acc_init(f32x16 (&acc)[MI][NI], const ttsam
 
 // Fused epilogue (bias, activation, residual, MRF accumulate, masks, gate, couplings, polyphase shuffle), shared by the
 // fp32-MFMA and the split-bf16 kernels: the 32x32 accumulator layout of every gfx950 MFMA is the same.
-template <int MODE, int MI, int NI, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int mb, int t0, int wm, int wn, int h, int j, bool folded)
+// Wave-uniform part of the accumulator row a lane holds in register r of a 32x32 tile (the lane adds 4 * h): the whole tile
+// (NR = 16), or — the small-grid one-shot kernel spreads a tile's epilogue over four waves — quarter `rq` of it (NR = 4):
+// registers {2q, 2q+1, 2q+8, 2q+9}, i.e. rows 2(q&1) + 8(q>>1) + {0, 1, 16, 17}: register r and r + NR/2 are 16 rows apart
+// in both forms, which is what the paired-row modes need.
+template <int NR>
+__device__ __forceinline__ int conv_erow(int r, int rq)
 {
+    if constexpr (NR == 16) return (r & 3) + 8 * (r >> 2);
+    return 2 * (rq & 1) + 8 * (rq >> 1) + (r & 1) + 16 * (r >> 1);
+}
+
+template <int MODE, int MI, int NI, int WM, int WN, int NR = 16>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int mb, int t0, int wm, int wn, int h, int j, bool folded,
+                                              int rq = 0)
+{
+    static_assert(NR == 16 || NR == 4, "whole tile or a quarter");
+    static_assert(NR == 16 || MODE != TTSAMD_CONV_SHUFFLE, "the polyphase stores take whole tiles");
     constexpr int kOob = kConvOob;
     // ---- epilogue --------------------------------------------------------------------------
     // MODE is a template parameter (each fusion gets its own lean kernel), and the epilogue-only
@@ -177,33 +191,91 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
     const float *res = res0 ? res0 + (long)b * res_bs : nullptr;
 
     if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
-        static_assert(MI == 2, "paired-row epilogues need MI == 2");
-        const long pair = (long)mb * WM + wm;
+        // Paired rows live in ONE 32-row tile (round 4; before: in two neighbouring tiles, which tied these modes to MI = 2):
+        // packed rows [32m, 32m+16) = the first halves (tanh / t) of output channels [16m, 16m+16), rows [32m+16, 32m+32) the
+        // second halves (sigmoid / s) — in the accumulator layout register r (< NR/2) and register r + NR/2 of the same lane.
+        // Branch-free passes like the unpaired modes below: the first version took a divergent branch per element
+        // with its bias / row-bias / coupling-operand loads INSIDE it — sixteen dependent global round trips per lane,
+        // 12 200 of a 29 700-cycle block at the single-sentence shapes (scripts/phase_clocks.py, 192 -> 384, k = 5, T = 159).
         constexpr bool gate = (MODE == TTSAMD_CONV_GATE);
+        constexpr int NP = NR / 2;                         // pairs per lane and tile
         const int nvalid = gate ? c_out / 2 : split_row;  // output channels
+        const int y_rs4 = (int)y_rs * 4, res_rs4 = (int)res_rs * 4;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + (long)b * y_bs, ((long)(nvalid - 1) * y_rs + t_out) * 4);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(res, (!gate && res) ? ((long)(nvalid - 1) * res_rs + t_out) * 4 : 0);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int mt = (mb * WM + wm) * MI + mi;
+            float b0[NP], b1[NP];     // bias (+ per-item row bias) of this lane's row pairs: packed rows 32 mt + i and + 16
+            bool rok[NP];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const long prow = pair * 64 + i;  // packed row of the first (tanh / t) half
-                const long oc = pair * 32 + i;    // output channel
-                if (prow + 32 < c_out && oc < nvalid && t < t_out) {
-                    float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
-                    if (bias) { v0 += bias[prow]; v1 += bias[prow + 32]; }
-                    if (rbias) { v0 += rbias[prow]; v1 += rbias[prow + 32]; }
+            for (int r = 0; r < NP; ++r) {
+                const int i = conv_erow<NR>(r, rq) + 4 * h;
+                rok[r] = (mt * 32 + i + 16 < c_out) && (mt * 16 + i < nvalid);
+                b0[r] = 0.f;
+                b1[r] = 0.f;
+            }
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+                    const int prow = mt * 32 + conv_erow<NR>(r, rq) + 4 * h;
+                    b0[r] = bias[rok[r] ? prow : 0];
+                    b1[r] = bias[rok[r] ? prow + 16 : 0];
+                }
+            }
+            if (rbias) {
+                float c0[NP], c1[NP];
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+                    const int prow = mt * 32 + conv_erow<NR>(r, rq) + 4 * h;
+                    c0[r] = rbias[rok[r] ? prow : 0];
+                    c1[r] = rbias[rok[r] ? prow + 16 : 0];
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < NP; ++r) {   // (v + bias) + row_bias
+                        acc[mi][ni][r] = (acc[mi][ni][r] + b0[r]) + c0[r];
+                        acc[mi][ni][r + NP] = (acc[mi][ni][r + NP] + b1[r]) + c1[r];
+                    }
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < NP; ++r) {
+                        acc[mi][ni][r] += b0[r];
+                        acc[mi][ni][r + NP] += b1[r];
+                    }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int t = t0 + wn * (32 * NI) + ni * 32 + j;
+                const bool tv = t < t_out;
+                float e1[NP];
+#pragma unroll
+                for (int r = 0; r < NP; ++r) e1[r] = 0.f;
+                float om = 1.f;
+                if constexpr (!gate) {
+                    om = omask ? omask[tv ? t : 0] : 1.f;
+#pragma unroll
+                    for (int r = 0; r < NP; ++r) {       // the coupled half x1 (may be the very rows y overwrites: read first)
+                        const int oc = mt * 16 + conv_erow<NR>(r, rq);             // wave-uniform part of the output channel
+                        e1[r] = ld_buf(rres, (tv && rok[r]) ? (4 * h * res_rs4 + t * 4) : kOob, oc * res_rs4);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+                    const float v0 = acc[mi][ni][r], v1 = acc[mi][ni][r + NP];
                     float o;
                     if constexpr (gate) {
                         o = tanhf(v0) * (1.f / (1.f + expf(-v1)));
                     } else if constexpr (MODE == TTSAMD_CONV_COUPLE_AFFINE) {
-                        const float m = omask ? omask[t] : 1.f;
-                        o = (res[oc * res_rs + t] - v0) * expf(-v1) * m;
+                        o = (e1[r] - v0) * expf(-v1) * om;
                     } else {
-                        const float m = omask ? omask[t] : 1.f;
-                        o = (v0 + expf(v1) * res[oc * res_rs + t]) * m;
+                        o = (v0 + expf(v1) * e1[r]) * om;
                     }
-                    y[(long)b * y_bs + oc * y_rs + t] = o;
+                    const int oc = mt * 16 + conv_erow<NR>(r, rq);
+                    st_buf(ry, o, (tv && rok[r]) ? (4 * h * y_rs4 + t * 4) : kOob, oc * y_rs4);
                 }
             }
         }
@@ -236,20 +308,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
         for (int mi = 0; mi < MI; ++mi) {
             const int row0 = ((mb * WM + wm) * MI + mi) * 32;
             const bool lower = (MODE == TTSAMD_CONV_RES_SKIP) && (row0 < split);   // res rows vs skip rows
-            float radd[16];   // bias (+ per-item row bias) of this lane's 16 rows of the m-tile
+            float radd[NR];   // bias (+ per-item row bias) of this lane's 16 rows of the m-tile
 #pragma unroll
-            for (int r = 0; r < 16; ++r) radd[r] = 0.f;
+            for (int r = 0; r < NR; ++r) radd[r] = 0.f;
             if (bias) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                for (int r = 0; r < NR; ++r) {
+                    const int row = row0 + conv_erow<NR>(r, rq) + 4 * h;
                     radd[r] = bias[row < c_out ? row : 0];
                 }
             }
             if (rbias) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                for (int r = 0; r < NR; ++r) {
+                    const int row = row0 + conv_erow<NR>(r, rq) + 4 * h;
                     radd[r] += rbias[row < c_out ? row : 0];
                 }
             }
@@ -260,16 +332,16 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                 const int t = t0 + wn * (32 * NI) + ni * 32 + j;
                 const bool tv = t < t_out;
                 const float om = omask ? omask[tv ? t : 0] : 1.f;
-                float e1[16], e2[16];   // optional operands of this 32x32 tile
+                float e1[NR], e2[NR];   // optional operands of this 32x32 tile
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { e1[r] = 0.f; e2[r] = 0.f; }
+                for (int r = 0; r < NR; ++r) { e1[r] = 0.f; e2[r] = 0.f; }
                 const bool need_res = (MODE == TTSAMD_CONV_COUPLE) || (MODE == TTSAMD_CONV_RES_SKIP && lower) ||
                                       (MODE == TTSAMD_CONV_NORMAL && res && !folded);
                 if (need_res) {
                     const int vo = tv ? (4 * h * res_rs4 + t * 4) : kOob;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rb = row0 + (r & 3) + 8 * (r >> 2);
+                    for (int r = 0; r < NR; ++r) {
+                        const int rb = row0 + conv_erow<NR>(r, rq);
                         e1[r] = ld_buf(rres, (rb + 4 * h < c_out) ? vo : kOob, rb * res_rs4);
                     }
                 }
@@ -277,8 +349,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                 if (need_acc) {
                     const int vo = tv ? (4 * h * acc_rs4 + t * 4) : kOob;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rb = row0 - split + (r & 3) + 8 * (r >> 2);
+                    for (int r = 0; r < NR; ++r) {
+                        const int rb = row0 - split + conv_erow<NR>(r, rq);
                         e2[r] = ld_buf(racc, (rb + 4 * h + split < c_out) ? vo : kOob, rb * acc_rs4);
                     }
                 }
@@ -289,33 +361,33 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                     // bias + activation in place on the accumulators; out_act is wave-uniform: its branches sit outside the
                     // unrolled element loop
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += radd[r];
+                    for (int r = 0; r < NR; ++r) acc[mi][ni][r] += radd[r];
                     if (out_act == TTSAMD_ACT_RELU) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
+                        for (int r = 0; r < NR; ++r) acc[mi][ni][r] = fmaxf(acc[mi][ni][r], 0.f);
                     } else if (out_act == TTSAMD_ACT_TANH) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = tanhf(acc[mi][ni][r]);
+                        for (int r = 0; r < NR; ++r) acc[mi][ni][r] = tanhf(acc[mi][ni][r]);
                     }
                     // residual, accumulate, mask, division: each behind ONE wave-uniform branch around its whole pass (inside
                     // the element loop hipcc evaluates the IEEE division sequence — 12 VALU instructions — for every element of
                     // every launch and selects afterwards).  Same operations in the same order as before.
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += e1[r];              // 0 when absent / folded
+                    for (int r = 0; r < NR; ++r) acc[mi][ni][r] += e1[r];              // 0 when absent / folded
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = e2[r] + acc[mi][ni][r];
+                    for (int r = 0; r < NR; ++r) acc[mi][ni][r] = e2[r] + acc[mi][ni][r];
                     if (omask) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= om;
+                        for (int r = 0; r < NR; ++r) acc[mi][ni][r] *= om;
                     }
                     if (has_div) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = acc[mi][ni][r] / out_div;
+                        for (int r = 0; r < NR; ++r) acc[mi][ni][r] = acc[mi][ni][r] / out_div;
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rb = row0 + (r & 3) + 8 * (r >> 2);
+                for (int r = 0; r < NR; ++r) {
+                    const int rb = row0 + conv_erow<NR>(r, rq);
                     const int row = rb + 4 * h;
                     const bool rok = row < c_out;
                     float v = (MODE == TTSAMD_CONV_NORMAL) ? acc[mi][ni][r] : acc[mi][ni][r] + radd[r];
@@ -543,13 +615,10 @@ template <int K, int D, int MODE>
 int conv1d_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     const int mtiles = (a.c_out + 31) / 32;
+    // (the paired-row modes pair inside a 32-row tile since round 4: they tile like every other mode)
     if (mtiles % 4 == 0) return conv1d_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
-    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
-        return conv1d_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
-    } else {
-        if (mtiles % 2 == 0) return conv1d_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
-        return conv1d_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
-    }
+    if (mtiles % 2 == 0) return conv1d_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
+    return conv1d_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
 }
 
 }  // namespace ttsamd

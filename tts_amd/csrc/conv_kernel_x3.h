@@ -36,7 +36,7 @@
 namespace ttsamd {
 constexpr long kConvSmallGridBlocks = 128;  // up to this many 128x128-class blocks a launch takes the small-grid tiles
 constexpr long kConvWaveTileBlocks = 1024;  // up to this many 32x32 tiles those kernels run a wave per tile and K slice
-extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = + K-split groups, 3 = + conv_kernel_x3s.h kernels (default)
+extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = + K-split groups, 3 = + conv_kernel_x3s.h kernels, 4 = + conv_kernel_x3o.h (default)
 }
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
@@ -408,6 +408,8 @@ int conv1d_x3_launch_cfg(const ttsamd_conv1d_args &a, hipStream_t st)
 
 template <int K, int D, int MI, int MODE>
 bool conv1d_x3s_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc);   // conv_kernel_x3s.h
+template <int K, int D, int MODE>
+bool conv1d_x3o_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc);   // conv_kernel_x3o.h
 
 template <int K, int D, int MODE>
 int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
@@ -425,54 +427,44 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     constexpr bool affine = (MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD);
     if constexpr (MODE == TTSAMD_CONV_NORMAL || (affine && K == 1) ||
                   (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE))) {
-        constexpr bool paired = (MODE == TTSAMD_CONV_GATE) || affine;
         const long tiles_n = (a.t_out + 127) / 128;
         const long blocks_default = tiles_n * ((mtiles + 3) / 4) * a.batch;      // 128x128-class blocks
         if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks) {
+            // mode 4 (default), first choice: the one-shot kernels of conv_kernel_x3o.h (every K slice its own wave, the whole
+            // reduction in flight at once, the epilogue spread over four waves)
+            if (g_conv_small_grid >= 4) {
+                int rc = TTSAMD_OK;
+                if (conv1d_x3o_launch<K, D, MODE>(a, st, &rc)) return rc;
+            }
             // >= 8 channel chunks (c_in >= 128): four wave groups split the chunks of the block's K loop between them
             const bool ksplit = g_conv_small_grid > 1 && a.c_in >= 8 * kConvCK;
             if constexpr (TTSAMD_X3S_ALL || (D == 1 && K <= 5)) {
-                // mode 3 (default): the small-grid kernels of conv_kernel_x3s.h
+                // the looping small-grid kernels of conv_kernel_x3s.h
                 if (ksplit && g_conv_small_grid >= 3) {
                     int rc = TTSAMD_OK;
-                    if (conv1d_x3s_launch<K, D, (paired ? 2 : 1), MODE>(a, st, &rc)) return rc;
+                    if (conv1d_x3s_launch<K, D, 1, MODE>(a, st, &rc)) return rc;
                 }
             }
-            if constexpr (paired) {
-                if (mtiles % 4 == 0) {                                                                 // 128 rows x 64 columns
-                    if (ksplit) return conv1d_x3_launch_cfg<K, D, 2, 1, 2, 2, MODE, 2>(a, st);   // 2 groups: 4 would cap the kernel at 128 VGPRs (spills)
-                    return conv1d_x3_launch_cfg<K, D, 2, 1, 2, 2, MODE>(a, st);
-                }
-                return conv1d_x3_launch_cfg<K, D, 2, 1, 1, 2, MODE>(a, st);                            // 64 rows x 64 columns
-            } else {
-                if (mtiles % 2 == 0) {                                                                 // 64 rows x 64 columns
-                    if (ksplit) return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE, 4>(a, st);
-                    return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE>(a, st);
-                }
-                return conv1d_x3_launch_cfg<K, D, 1, 1, 1, 2, MODE>(a, st);                            // 32 rows x 64 columns
+            // (the paired-row modes pair inside a 32-row tile since round 4: they tile like every other mode)
+            if (mtiles % 2 == 0) {                                                                 // 64 rows x 64 columns
+                if (ksplit) return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE, 4>(a, st);
+                return conv1d_x3_launch_cfg<K, D, 1, 1, 2, 2, MODE>(a, st);
             }
+            return conv1d_x3_launch_cfg<K, D, 1, 1, 1, 2, MODE>(a, st);                            // 32 rows x 64 columns
         }
     }
-    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
-        if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, 2, 2, 2, 2, MODE>(a, st);
-    } else {
-        // 128x128 block as four 32x128 wave tiles: 3 weight loads (L2) + 12 LDS fragment reads per 24 MFMAs instead of
-        // 6 + 6 — LDS has 4x the L1 bandwidth (scripts/ubench/x3_tiles.hip: 0.54 -> 0.56 of peak at the throttled clock,
-        // 0.70 -> 0.79 on zero operands)
-        // measured end to end (bench.py, two runs each): <2,2,2,2> 91.1 ms/step, <1,4,4,1> 87.3; 256-row blocks
-        // (<2,4,4,1>) for the 2-tap polyphase ConvTranspose launches: +-0.  Round 2, same method: 64x128 wave tiles
-        // (<2,4,2,1>, half the L1 bytes per MFMA, 20 spilled VGPRs) 79.5 -> 81.7 ms/step; 256-row blocks of 8 waves (<1,4,8,1>,
-        // the 256-channel layers stage their tile once instead of twice) 77.5 -> 77.9; the conflict-free planar LDS image
-        // (TTSAMD_X3_PLANAR) +-0 on the 128/256-row layers (SQ_LDS_BANK_CONFLICT 0, but LDS was not the limiter).
-        if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
-    }
-    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
-        return conv1d_x3_launch_cfg<K, D, 2, 2, 1, 4, MODE>(a, st);
-    } else {
-        // same bench, same box: <2,2,1,4> 90.6 ms/step, <1,4,2,2> 89.7; (<1,8,4,1> on the 128-row blocks: 93.4)
-        if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);
-        return conv1d_x3_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
-    }
+    // 128x128 block as four 32x128 wave tiles: 3 weight loads (L2) + 12 LDS fragment reads per 24 MFMAs instead of
+    // 6 + 6 — LDS has 4x the L1 bandwidth (scripts/ubench/x3_tiles.hip: 0.54 -> 0.56 of peak at the throttled clock,
+    // 0.70 -> 0.79 on zero operands)
+    // measured end to end (bench.py, two runs each): <2,2,2,2> 91.1 ms/step, <1,4,4,1> 87.3; 256-row blocks
+    // (<2,4,4,1>) for the 2-tap polyphase ConvTranspose launches: +-0.  Round 2, same method: 64x128 wave tiles
+    // (<2,4,2,1>, half the L1 bytes per MFMA, 20 spilled VGPRs) 79.5 -> 81.7 ms/step; 256-row blocks of 8 waves (<1,4,8,1>,
+    // the 256-channel layers stage their tile once instead of twice) 77.5 -> 77.9; the conflict-free planar LDS image
+    // (TTSAMD_X3_PLANAR) +-0 on the 128/256-row layers (SQ_LDS_BANK_CONFLICT 0, but LDS was not the limiter).
+    if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
+    // same bench, same box: <2,2,1,4> 90.6 ms/step, <1,4,2,2> 89.7; (<1,8,4,1> on the 128-row blocks: 93.4)
+    if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);
+    return conv1d_x3_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
 }
 
 }  // namespace ttsamd

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS * WM * WN >= 4 ? KS * WM * W
     pc[3] = clock64();
     __builtin_amdgcn_s_waitcnt(0);
     pc[4] = clock64();
-    if (MODE == TTSAMD_CONV_NORMAL && a.y2 && tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2) {
+    if ((MODE == TTSAMD_CONV_NORMAL || MODE == TTSAMD_CONV_GATE) && a.y2 && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2) {
         long long *o = reinterpret_cast<long long *>(a.y2);
         for (int i = 0; i < 5; ++i) o[i] = pc[i] - pc[0];
         o[5] = wall_clock64() - prt0;

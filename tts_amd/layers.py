@@ -269,9 +269,9 @@ class WN:
         if cond_channels and (p + "cond_layer.bias") in sd:
             self.cond_w = fold_weight_norm(sd, p + "cond_layer")
             self.cond = PackedConv(self.cond_w, sd[p + "cond_layer.bias"], device)
-            idx = []
-            for a in range(hidden // 32):
-                idx += list(range(32 * a, 32 * a + 32)) + list(range(hidden + 32 * a, hidden + 32 * a + 32))
+            idx = ops.pair_index(hidden, hidden)
+            if min(idx) < 0:
+                raise ops._lib.TtsAmdError("WN speaker conditioning needs hidden_channels %% %d == 0" % ops.PAIR_ROWS)
             self.gate_idx = torch.tensor(idx, device=device)
 
     def __call__(self, x, mask, out, g=None, out_kw=None):
@@ -417,20 +417,12 @@ class GlowDecoder:
         c = in_channels * num_squeeze
         self.c, self.half, self.hidden = c, c // 2, hidden
         half = self.half
-        ntile = (half + 31) // 32
         self.blocks = []
         for b in range(num_flow_blocks):
             pa, pi, pc = (p + "flows.%d." % (3 * b + j) for j in range(3))
             w_end, b_end = sd[pc + "end.weight"].float(), sd[pc + "end.bias"].float()   # [c, hidden, 1]: t rows | s rows
-            # pair-tile packing for the COUPLE_AFFINE epilogue: tile 2a = t rows [32a, 32a+32), tile 2a+1 = s rows
-            wp = torch.zeros(64 * ntile, w_end.shape[1], 1)
-            bp = torch.zeros(64 * ntile)
-            for a in range(ntile):
-                n = min(32, half - 32 * a)
-                wp[64 * a: 64 * a + n] = w_end[32 * a: 32 * a + n]
-                wp[64 * a + 32: 64 * a + 32 + n] = w_end[half + 32 * a: half + 32 * a + n]
-                bp[64 * a: 64 * a + n] = b_end[32 * a: 32 * a + n]
-                bp[64 * a + 32: 64 * a + 32 + n] = b_end[half + 32 * a: half + 32 * a + n]
+            # paired-row packing for the COUPLE_AFFINE epilogue: 32-row tile m = t rows [16m, 16m+16) then the matching s rows
+            wp, bp = ops.pair_permute(w_end, b_end, half, half)
             w_inv = sd[pi + "weight_inv"] if (pi + "weight_inv") in sd else torch.inverse(sd[pi + "weight"].float())
             self.blocks.append(dict(
                 start=PackedConv(fold_weight_norm(sd, pc + "start"), sd[pc + "start.bias"], device),

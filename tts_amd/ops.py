@@ -263,15 +263,39 @@ def convt_polyphase_weight(w_t, bias, u):
     return w.contiguous(), b
 
 
-def gate_permute(w, bias, hidden):
-    """Re-order the 2H output rows of a WN in_layer so packed 32-row tile 2a holds tanh channels
-    [32a, 32a+32) and tile 2a+1 the matching sigmoid channels (H must be a multiple of 32)."""
-    assert hidden % 32 == 0
+PAIR_ROWS = 16     # paired-row conv modes (GATE, COUPLE_AFFINE*): a packed 32-row tile = 16 first halves + the 16 matching second halves
+
+
+def pair_index(n, second_offset):
+    """Packed-row order of the paired modes for n output channels: tile m holds rows [16m, 16m+16) of the first operand
+    (tanh / t) followed by the same channels of the second (sigmoid / s, at +second_offset in the source); -1 marks the zero
+    rows that pad a last partial tile."""
     idx = []
-    for a in range(hidden // 32):
-        idx += list(range(32 * a, 32 * a + 32)) + list(range(hidden + 32 * a, hidden + 32 * a + 32))
-    idx = torch.tensor(idx)
-    return w[idx].contiguous(), (None if bias is None else bias[idx].contiguous())
+    for a in range((n + PAIR_ROWS - 1) // PAIR_ROWS):
+        lo, cnt = PAIR_ROWS * a, min(PAIR_ROWS, n - PAIR_ROWS * a)
+        idx += list(range(lo, lo + cnt)) + [-1] * (PAIR_ROWS - cnt)
+        idx += list(range(second_offset + lo, second_offset + lo + cnt)) + [-1] * (PAIR_ROWS - cnt)
+    return idx
+
+
+def pair_permute(w, bias, n, second_offset):
+    """Rows of a [2n(+), c_in, k] weight (first operand rows [0, n), second at [second_offset, second_offset + n)) -> the
+    paired modes' packed order (zero rows where a last tile is partial)."""
+    idx = torch.tensor(pair_index(n, second_offset))
+    keep = idx >= 0
+    wp = torch.zeros((idx.numel(),) + tuple(w.shape[1:]), dtype=w.dtype)
+    wp[keep] = w[idx[keep]]
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(idx.numel(), dtype=bias.dtype)
+        bp[keep] = bias[idx[keep]]
+    return wp.contiguous(), bp
+
+
+def gate_permute(w, bias, hidden):
+    """Re-order the 2H output rows of a WN in_layer into the GATE mode's packed order: 32-row tile m = tanh channels
+    [16m, 16m+16) then the matching sigmoid channels (include/tts_amd.h)."""
+    return pair_permute(w, bias, hidden, hidden)
 
 
 class CopySeg(ctypes.Structure):
