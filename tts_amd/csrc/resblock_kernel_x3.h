@@ -29,8 +29,8 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 template <int K, int D, int C, int WM, int WN, int NI>
 struct ResGeom {
     static constexpr int kThreads = 64 * WM * WN;
-    static constexpr int kMI = C / (32 * WM);      // m-tiles per wave
-    static constexpr int kNCh = C / 16;            // 16-channel chunks of the reduction
+    static constexpr int kMI = C >= 32 * WM ? C / (32 * WM) : 1;   // m-tiles per wave (C = 16: one 32-row tile, half of it padding)
+    static constexpr int kNCh = (C + 15) / 16;     // 16-channel chunks of the reduction
     static constexpr int kNM = 32 * NI * WN;       // mid columns computed (= conv2 columns computed)
     static constexpr int kBN = kNM - (K - 1);      // valid output columns per block
     static constexpr int kH2 = (K - 1) / 2;        // conv2 halo (dilation 1)
@@ -44,7 +44,7 @@ struct ResGeom {
     static constexpr size_t kLdsBytes = (size_t)3 * kNCh * 2 * kPlaneX;
     static constexpr int kOcc = (NI == 1 && kThreads <= 256 && 4 * kLdsBytes <= 160 * 1024) ? 4     // small tiles: 4 blocks / CU
                                 : (2 * kLdsBytes <= 160 * 1024 && kThreads <= 256) ? 2 : (kThreads >= 512 ? 2 : 1);
-    static_assert(C % (32 * WM) == 0 && kBN > 0, "bad tile");
+    static_assert((C % (32 * WM) == 0 || (C == 16 && WM == 1)) && kBN > 0, "bad tile");
 };
 
 // Main loop of one conv of the pair: acc[mi][ni] += sum over (chunk, tap) of the six split products.
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
                     }
                     // rows 8*rg + 4*h + i of m-tile (wm*MI + mi): chunk 2*mtile + rg/2, 8-channel half rg%2, channels 4h..4h+3
                     const int pl = (2 * (wm * MI + mi) + (rg >> 1)) * 2 + (rg & 1);
+                    if (2 * (wm * MI + mi) + (rg >> 1) >= NCH) continue;     // C = 16: rows 16..31 of the tile are padding
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         u32x2 w;
@@ -385,11 +386,20 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
         if (a.variant == 2 && a.c == 32) return resblock_pair_launch_cfg<K, D, 32, 1, 4, 1>(a, st);
         if (a.variant == 2 && a.c == 64) return resblock_pair_launch_cfg<K, D, 64, 2, 2, 1>(a, st);
     }
+    // Small grids (a single sentence through HiFiGAN-v2: the 64-channel stage is 2 700 columns = 11 of the default blocks, each
+    // walking 2 x 44 k-steps alone on its CU): narrow tiles — a quarter / half of the columns per block, 4-5x the blocks.  Same
+    // summation order per output: results do not depend on the tile width.
+    const long cols = (long)a.t * a.batch;
     switch (a.c) {
         case 8:
-        case 16:   // zero-padded to the 32-channel tile (the caller passes the weight images of the padded conv)
-        case 32: return resblock_pair_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
+        case 16:   // zero-padded weight images of the [32, 32, k] conv (the caller passes them); the reduction walks only the
+                   // first 16-channel chunk (round 4: the 32-channel tile did twice the MFMA and staging work on zeros)
+            return resblock_pair_launch_cfg<K, D, 16, 1, 4, 2>(a, st);
+        case 32:
+            if (a.variant == 0 && cols <= 128 * 236) return resblock_pair_launch_cfg<K, D, 32, 1, 4, 1>(a, st);
+            return resblock_pair_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:
+            if (a.variant == 0 && cols <= 64 * 118) return resblock_pair_launch_cfg<K, D, 64, 2, 2, 1>(a, st);
             // k = 11: the 8-wave / 256-column tile (4 % halo work instead of 8 %) wins by 3 %; k = 3, 7: the 4-wave tile
             if ((a.variant == 1) != (K == 11)) return resblock_pair_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
             return resblock_pair_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
