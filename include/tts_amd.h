@@ -120,6 +120,12 @@ int ttsamd_mask_lengths(int32_t *t_xs, int32_t *t_ys, const float *mask, int b, 
 #define TTSAMD_CONV_COUPLE_AFFINE 5
 /* forward direction of the same coupling (glow.py:225): y[16m+i] = (t + exp(s) * res[16m+i]) * out_mask */
 #define TTSAMD_CONV_COUPLE_AFFINE_FWD 6
+/* COUPLE_AFFINE followed, in the same epilogue, by the rest of the reverse flow block (glow.py:107-137, normalization.py:98-103):
+ * InvConvNear^-1 (the stored 4x4 inverse mixes channels {2i, 2i+1, C/2 + 2i, C/2 + 2i + 1}) and ActNorm^-1, IN PLACE on the whole
+ * [2 * split_row] channel tensor: `res` / `y` point at its coupled half (rows split_row..), the other half sits split_row rows
+ * before them.  `y2` points at the block's parameters on the device: 16 floats (4x4 inverse, row major), then bias[C], logs[C].
+ * Operation for operation what COUPLE_AFFINE + ttsamd_glow_invconv_actnorm(forward = 0) compute: bitwise the same result. */
+#define TTSAMD_CONV_COUPLE_AFFINE_MIX 7
 
 typedef struct ttsamd_conv1d_args {
     const float *x;        /* x[b,ci,t] = x[b*x_bstride + ci*x_rstride + t], t in [0,t_in) */

@@ -281,3 +281,34 @@ def test_glow_single_sentence_graphs_equal_eager(gpu):
     a = m.inference(x, dict(aux, no_graph=True))
     b = m.inference(x, aux)
     assert torch.equal(a["durations"], b["durations"]) and _rel(b["model_outputs"], a["model_outputs"]) < 2e-6
+
+
+@pytest.mark.parametrize("T", [159, 40, 333])
+def test_flow_block_tail_in_one_epilogue_is_bitwise_the_two_kernels(gpu, T):
+    """CONV_COUPLE_AFFINE_MIX (affine coupling + InvConvNear^-1 + ActNorm^-1 in the `end` conv's epilogue) against
+    CONV_COUPLE_AFFINE followed by ttsamd_glow_invconv_actnorm: the same operations in the same order — bit for bit — on the
+    one-shot small-grid kernel, the looping one and the large-grid tiles, ragged mask included."""
+    from tts_amd import layers
+
+    args = dict(num_flow_blocks_dec=1)
+    sd = W.make_glow_state(args, seed=77)
+    dec = layers.GlowDecoder(sd, "decoder.", gpu, 80, 192, 5, 1, 1, 4)
+    blk = dec.blocks[0]
+    g = torch.Generator().manual_seed(T)
+    B = 2
+    x = torch.randn(B, 160, T, generator=g)
+    out = torch.randn(B, 192, T, generator=g)
+    mask = (torch.arange(T)[None, :] < torch.tensor([T, max(1, T - 9)])[:, None]).float().to(gpu)
+    for mode in (0, 3, 4):
+        was = ops.set_conv_small_grid(mode)
+        try:
+            a = x.to(gpu).clone()
+            ops.conv1d(blk["end"], out.to(gpu), a, mode=ops.CONV_COUPLE_AFFINE, res=a, res_row_offset=80, y_row_offset=80,
+                       out_mask=mask, split_row=80)
+            ops.glow_invconv_actnorm(a, blk["w_inv"], blk["an_bias"], blk["an_logs"], mask, 4)
+            b_ = x.to(gpu).clone()
+            ops.conv1d(blk["end"], out.to(gpu), b_, mode=ops.CONV_COUPLE_AFFINE_MIX, res=b_, res_row_offset=80, y_row_offset=80,
+                       out_mask=mask, split_row=80, y2=blk["mix"])
+        finally:
+            ops.set_conv_small_grid(was)
+        assert torch.equal(a, b_), mode

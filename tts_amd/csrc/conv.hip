@@ -133,12 +133,14 @@ extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_COUPLE || a.res, "conv1d: COUPLE needs res");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_SHUFFLE || a.shuffle_u > 0, "conv1d: SHUFFLE needs shuffle_u");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_GATE || (a.c_out % 32) == 0, "conv1d: GATE needs c_out %% 32 == 0 (whole 16 + 16 row tiles)");
-    TTSAMD_CHECK_ARG((a.mode != TTSAMD_CONV_COUPLE_AFFINE && a.mode != TTSAMD_CONV_COUPLE_AFFINE_FWD) ||
+    TTSAMD_CHECK_ARG((a.mode != TTSAMD_CONV_COUPLE_AFFINE && a.mode != TTSAMD_CONV_COUPLE_AFFINE_FWD && a.mode != TTSAMD_CONV_COUPLE_AFFINE_MIX) ||
                          ((a.c_out % 32) == 0 && a.res && a.split_row > 0),
                      "conv1d: COUPLE_AFFINE needs c_out %% 32 == 0 (whole 16 + 16 row tiles), res and split_row");
     TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_RES_SKIP || (a.res && a.y2 && a.split_row > 0 && a.split_row % 32 == 0),
                      "conv1d: RES_SKIP needs res, y2 and split_row %% 32 == 0");
-    TTSAMD_CHECK_ARG(a.mode >= 0 && a.mode <= TTSAMD_CONV_COUPLE_AFFINE_FWD, "conv1d: unknown mode %d", a.mode);
+    TTSAMD_CHECK_ARG(a.mode != TTSAMD_CONV_COUPLE_AFFINE_MIX || (a.y2 && a.y == a.res && a.split_row % 2 == 0 && a.kernel == 1),
+                     "conv1d: COUPLE_AFFINE_MIX runs in place (y == res), needs the mix parameters in y2 and an even split_row");
+    TTSAMD_CHECK_ARG(a.mode >= 0 && a.mode <= TTSAMD_CONV_COUPLE_AFFINE_MIX, "conv1d: unknown mode %d", a.mode);
     TTSAMD_CHECK_ARG(a.in_act != TTSAMD_ACT_LRELU || (a.in_slope >= 0.f && a.in_slope <= 1.f),
                      "conv1d: leaky-ReLU slope %g outside [0, 1] (the kernels evaluate it as max(v, v * slope))", (double)a.in_slope);
     if (a.batch == 0 || a.t_out == 0) return TTSAMD_OK;

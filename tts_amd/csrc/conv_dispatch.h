@@ -46,6 +46,9 @@ int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
         case TTSAMD_CONV_COUPLE_AFFINE_FWD:
             if constexpr (K == 1) return conv1d_launch_prec<K, D, TTSAMD_CONV_COUPLE_AFFINE_FWD>(a, st);
             break;
+        case TTSAMD_CONV_COUPLE_AFFINE_MIX:
+            if constexpr (K == 1) return conv1d_launch_prec<K, D, TTSAMD_CONV_COUPLE_AFFINE_MIX>(a, st);
+            break;
     }
     return conv1d_mode_unsupported(a);
 }

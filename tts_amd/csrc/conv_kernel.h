@@ -175,9 +175,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
     const long accum_bs = ep->accum_bstride, accum_rs = ep->accum_rstride;
     const int out_act = ep->out_act;
     const float out_div = ep->out_div;
-    constexpr bool kUsesSplit = (MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD);
+    constexpr bool kUsesSplit = (MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD || MODE == TTSAMD_CONV_COUPLE_AFFINE_MIX);
     const int split_row = kUsesSplit ? ep->split_row : 0;
-    float *const y2_0 = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2 : nullptr;
+    float *const y2_0 = (MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE_AFFINE_MIX) ? ep->y2 : nullptr;
     const long y2_bs = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2_bstride : 0, y2_rs = (MODE == TTSAMD_CONV_RES_SKIP) ? ep->y2_rstride : 0;
     const int shuffle_u = (MODE == TTSAMD_CONV_SHUFFLE) ? ep->shuffle_u : 1;
     const int shuffle_pad = (MODE == TTSAMD_CONV_SHUFFLE) ? ep->shuffle_pad : 0;
@@ -190,7 +190,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
     const float *omask = omask0 ? omask0 + (long)b * t_out : nullptr;
     const float *res = res0 ? res0 + (long)b * res_bs : nullptr;
 
-    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD) {
+    if constexpr (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD ||
+                  MODE == TTSAMD_CONV_COUPLE_AFFINE_MIX) {
         // Paired rows live in ONE 32-row tile (round 4; before: in two neighbouring tiles, which tied these modes to MI = 2):
         // packed rows [32m, 32m+16) = the first halves (tanh / t) of output channels [16m, 16m+16), rows [32m+16, 32m+32) the
         // second halves (sigmoid / s) — in the accumulator layout register r (< NR/2) and register r + NR/2 of the same lane.
@@ -263,19 +264,58 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                         e1[r] = ld_buf(rres, (tv && rok[r]) ? (4 * h * res_rs4 + t * 4) : kOob, oc * res_rs4);
                     }
                 }
+                if constexpr (MODE == TTSAMD_CONV_COUPLE_AFFINE_MIX) {
+                    // the coupled values stay in registers; InvConvNear^-1 mixes channel pairs (2i, 2i+1) of the untouched half
+                    // (read here) with the same pair of the coupled half (registers r, r+1: consecutive rows of one lane), then
+                    // ActNorm^-1 — the operations of glow_invconv_actnorm_kernel in its order
+                    static_assert(NP % 2 == 0, "channel pairs");
+                    const float *const mixp = y2_0;                      // [16] w_inv, [C] bias, [C] logs
+                    const int Cc = 2 * nvalid;
+                    float w[4][4];
 #pragma unroll
-                for (int r = 0; r < NP; ++r) {
-                    const float v0 = acc[mi][ni][r], v1 = acc[mi][ni][r + NP];
-                    float o;
-                    if constexpr (gate) {
-                        o = tanhf(v0) * (1.f / (1.f + expf(-v1)));
-                    } else if constexpr (MODE == TTSAMD_CONV_COUPLE_AFFINE) {
-                        o = (e1[r] - v0) * expf(-v1) * om;
-                    } else {
-                        o = (v0 + expf(v1) * e1[r]) * om;
+                    for (int a4 = 0; a4 < 4; ++a4)
+#pragma unroll
+                        for (int b4 = 0; b4 < 4; ++b4) w[a4][b4] = mixp[a4 * 4 + b4];
+                    const float *const x0base = res - (long)nvalid * res_rs;       // the untouched half sits nvalid rows before
+                    float *const y0base = y + (long)b * y_bs - (long)nvalid * y_rs;
+#pragma unroll
+                    for (int r = 0; r < NP; r += 2) {
+                        const int oc = mt * 16 + conv_erow<NR>(r, rq) + 4 * h;     // even channel of the pair
+                        const bool ok = tv && rok[r] && rok[r + 1];
+                        float v[4];
+                        v[0] = ok ? x0base[(long)oc * res_rs + t] : 0.f;
+                        v[1] = ok ? x0base[(long)(oc + 1) * res_rs + t] : 0.f;
+                        v[2] = (e1[r] - acc[mi][ni][r]) * expf(-acc[mi][ni][r + NP]) * om;
+                        v[3] = (e1[r + 1] - acc[mi][ni][r + 1]) * expf(-acc[mi][ni][r + 1 + NP]) * om;
+#pragma unroll
+                        for (int go = 0; go < 4; ++go) {
+                            float z = 0.f;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) z += w[go][g] * v[g];
+                            const int ch = (go >> 1) * nvalid + oc + (go & 1);
+                            z *= om;
+                            z = (z - mixp[16 + (ok ? ch : 0)]) * expf(-mixp[16 + Cc + (ok ? ch : 0)]) * om;
+                            if (ok) {
+                                if (go < 2) y0base[(long)(oc + go) * y_rs + t] = z;
+                                else y[(long)b * y_bs + (long)(oc + go - 2) * y_rs + t] = z;
+                            }
+                        }
                     }
-                    const int oc = mt * 16 + conv_erow<NR>(r, rq);
-                    st_buf(ry, o, (tv && rok[r]) ? (4 * h * y_rs4 + t * 4) : kOob, oc * y_rs4);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NP; ++r) {
+                        const float v0 = acc[mi][ni][r], v1 = acc[mi][ni][r + NP];
+                        float o;
+                        if constexpr (gate) {
+                            o = tanhf(v0) * (1.f / (1.f + expf(-v1)));
+                        } else if constexpr (MODE == TTSAMD_CONV_COUPLE_AFFINE) {
+                            o = (e1[r] - v0) * expf(-v1) * om;
+                        } else {
+                            o = (v0 + expf(v1) * e1[r]) * om;
+                        }
+                        const int oc = mt * 16 + conv_erow<NR>(r, rq);
+                        st_buf(ry, o, (tv && rok[r]) ? (4 * h * y_rs4 + t * 4) : kOob, oc * y_rs4);
+                    }
                 }
             }
         }

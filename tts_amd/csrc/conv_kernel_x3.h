@@ -424,7 +424,7 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     // channel stages of a single utterance) and the dilation-1 gate / res-skip / coupling convs of the flows.
     // (round 3: + the 1x1 affine-coupling convs of the Glow decoder — a single sentence launched THREE 64x256 blocks per flow
     // block there, 30 us each: 11 % of the Glow-TTS + HiFiGAN-v2 sentence)
-    constexpr bool affine = (MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD);
+    constexpr bool affine = (MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD || MODE == TTSAMD_CONV_COUPLE_AFFINE_MIX);
     if constexpr (MODE == TTSAMD_CONV_NORMAL || (affine && K == 1) ||
                   (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE))) {
         const long tiles_n = (a.t_out + 127) / 128;

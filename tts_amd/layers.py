@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import ops
-from .ops import (ACT_GELU, ACT_NONE, ACT_RELU, CONV_COUPLE, CONV_COUPLE_AFFINE, CONV_COUPLE_AFFINE_FWD, CONV_GATE, CONV_RES_SKIP,
+from .ops import (ACT_GELU, ACT_NONE, ACT_RELU, CONV_COUPLE, CONV_COUPLE_AFFINE, CONV_COUPLE_AFFINE_FWD, CONV_COUPLE_AFFINE_MIX, CONV_GATE, CONV_RES_SKIP,
                   PackedConv, fold_weight_norm)
 
 
@@ -432,6 +432,11 @@ class GlowDecoder:
                 w_inv=_dev(w_inv.reshape(num_splits, num_splits), device),     # store_inverse(), glow.py:139-141
                 w_fwd=_dev(sd[pi + "weight"].float().reshape(num_splits, num_splits), device) if (pi + "weight") in sd else None,
                 an_bias=_dev(sd[pa + "bias"].reshape(-1), device), an_logs=_dev(sd[pa + "logs"].reshape(-1), device)))
+            blk = self.blocks[-1]
+            # the reverse block's InvConvNear^-1 + ActNorm^-1 parameters as ONE device block: they ride in the `end` conv's
+            # epilogue (CONV_COUPLE_AFFINE_MIX) — a flow block is then 10 launches, not 11
+            blk["mix"] = torch.cat([blk["w_inv"].reshape(-1), blk["an_bias"], blk["an_logs"]]).contiguous()
+        self.fuse_mix = num_splits == 4 and c % 4 == 0 and self.half % 2 == 0
 
     def __call__(self, z, y_mask, g=None):
         """z [B,C,T] (masked), y_mask [B,T] -> mel [B,C,T]; reverse pass: for every block (last to first)
@@ -444,9 +449,13 @@ class GlowDecoder:
         for blk in reversed(self.blocks):
             ops.conv1d(blk["start"], x, h, out_mask=mq)                       # start(x0) * mask   (x0 = first half)
             blk["wn"](h, mq, out, g=g)
-            ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE, res=x, res_row_offset=self.half,
-                       y_row_offset=self.half, out_mask=mq, split_row=self.half)
-            ops.glow_invconv_actnorm(x, blk["w_inv"], blk["an_bias"], blk["an_logs"], mq, self.ns)
+            if self.fuse_mix:
+                ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE_MIX, res=x, res_row_offset=self.half,
+                           y_row_offset=self.half, out_mask=mq, split_row=self.half, y2=blk["mix"])
+            else:
+                ops.conv1d(blk["end"], out, x, mode=CONV_COUPLE_AFFINE, res=x, res_row_offset=self.half,
+                           y_row_offset=self.half, out_mask=mq, split_row=self.half)
+                ops.glow_invconv_actnorm(x, blk["w_inv"], blk["an_bias"], blk["an_logs"], mq, self.ns)
         return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)
 
     def forward_flow(self, y, y_mask, g=None):

@@ -16,6 +16,7 @@ from ._lib import P, check, lib, stream_ptr
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 1, 2, 3
 CONV_NORMAL, CONV_GATE, CONV_SHUFFLE, CONV_COUPLE, CONV_RES_SKIP, CONV_COUPLE_AFFINE, CONV_COUPLE_AFFINE_FWD = 0, 1, 2, 3, 4, 5, 6
+CONV_COUPLE_AFFINE_MIX = 7       # affine coupling + InvConvNear^-1 + ActNorm^-1 in one epilogue (y2 = the block's mix parameters)
 
 
 class Conv1dArgs(ctypes.Structure):
@@ -164,8 +165,10 @@ def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, 
         a.accum_bstride, a.accum_rstride = accum.shape[1] * accum.shape[2], accum.shape[2]
     a.out_mask, a.out_div = _dp(out_mask), out_div
     a.shuffle_u, a.shuffle_pad, a.shuffle_t_out = shuffle_u, shuffle_pad, T_y
-    if y2 is not None:
+    if y2 is not None and y2.dim() == 3:
         a.y2, a.y2_bstride, a.y2_rstride = y2.data_ptr(), y2.shape[1] * y2.shape[2], y2.shape[2]
+    elif y2 is not None:          # CONV_COUPLE_AFFINE_MIX: the flow block's mix parameters (flat)
+        a.y2 = y2.data_ptr()
     a.split_row, a.row_bias = split_row, _dp(row_bias)
     a.w_split = pc.w_split.data_ptr() if _PRECISION == "x3" else None
     if _TIMER is not None and not torch.cuda.is_current_stream_capturing():
