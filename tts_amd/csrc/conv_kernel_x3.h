@@ -424,6 +424,15 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     // channel stages of a single utterance) and the dilation-1 gate / res-skip / coupling convs of the flows.
     // (round 3: + the 1x1 affine-coupling convs of the Glow decoder — a single sentence launched THREE 64x256 blocks per flow
     // block there, 30 us each: 11 % of the Glow-TTS + HiFiGAN-v2 sentence)
+    if constexpr (MODE == TTSAMD_CONV_SHUFFLE && K == 2) {
+        // a single sentence's polyphase ConvTranspose launches (HiFiGAN-v2 ups[0]: 12 of the 128x128-class blocks): the
+        // one-shot small-grid kernel, whole-tile epilogue (conv_kernel_x3o.h)
+        const long blocks_default = (long)((a.t_out + 127) / 128) * ((mtiles + 3) / 4) * a.batch;
+        if (g_conv_small_grid >= 4 && blocks_default <= kConvSmallGridBlocks) {
+            int rc = TTSAMD_OK;
+            if (conv1d_x3o_launch<K, D, MODE>(a, st, &rc)) return rc;
+        }
+    }
     constexpr bool affine = (MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD || MODE == TTSAMD_CONV_COUPLE_AFFINE_MIX);
     if constexpr (MODE == TTSAMD_CONV_NORMAL || (affine && K == 1) ||
                   (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE))) {

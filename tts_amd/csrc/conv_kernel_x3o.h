@@ -175,6 +175,19 @@ __global__ __launch_bounds__(64 * KS) void conv1d_x3o_kernel(const ttsamd_conv1d
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[((size_t)grp * 16 + r) * 64 + lane] = acc[0][0][r];
     __syncthreads();
+    if constexpr (MODE == TTSAMD_CONV_SHUFFLE) {
+        // the polyphase stores write a lane's four consecutive rows as one vector: the whole tile stays with wave 0
+        if (grp >= 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = red[(size_t)r * 64 + lane];
+#pragma unroll
+            for (int g = 1; g < KS; ++g) s += red[((size_t)g * 16 + r) * 64 + lane];
+            acc[0][0][r] = s;
+        }
+        conv_epilogue<MODE, 1, 1, 1, 1>(acc, b, mb, t0, 0, 0, h, j, folded);
+        return;
+    }
     if (grp >= 4) return;
     f32x16 q4[1][1];
 #pragma unroll
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(64 * KS) void conv1d_x3o_kernel(const ttsamd_conv1d
         for (int g = 1; g < KS; ++g) s += red[((size_t)g * 16 + r) * 64 + lane];
         q4[0][0][rr] = s;
     }
-    conv_epilogue<MODE, 1, 1, 1, 1, 4>(q4, b, mb, t0, 0, 0, h, j, folded, grp);
+    if constexpr (MODE != TTSAMD_CONV_SHUFFLE) conv_epilogue<MODE, 1, 1, 1, 1, 4>(q4, b, mb, t0, 0, 0, h, j, folded, grp);
 }
 
 template <int K, int D, int MODE, int KS, int CPI>
@@ -209,13 +222,15 @@ constexpr long kConvOneShotBlocks = 640;   // up to this many 32x32 tiles (a 12-
 template <int K, int D, int MODE>
 bool conv1d_x3o_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc)
 {
-    if constexpr (D != 1 || K == 2 || K > 7 || MODE == TTSAMD_CONV_SHUFFLE) {
+    if constexpr (D != 1 || K > 7 || (MODE == TTSAMD_CONV_SHUFFLE) != (K == 2)) {
         return false;
     } else {
         const int mtiles = (a.c_out + 31) / 32;
         const int nchunks = (a.c_in + kConvCK - 1) / kConvCK;
         const long blocks = (long)((a.t_out + 31) / 32) * mtiles * a.batch;
-        if (blocks > kConvOneShotBlocks || a.t_out < 1) return false;
+        // up to 640 twelve-wave blocks (a 32x32 tile each); lighter blocks (fewer K slices) in proportion
+        const int ks_est = (K == 1) ? (nchunks <= 12 ? 4 : (nchunks <= 24 ? 8 : 16)) : (nchunks <= 4 ? 4 : (nchunks <= 8 ? 8 : (nchunks <= 12 ? 12 : 16)));
+        if (blocks * ks_est > kConvOneShotBlocks * 12 || a.t_out < 1) return false;
         // chunks per wave: three for 1x1 convs (36 weight registers), else one
         if constexpr (K == 1) {
             if (nchunks <= 12) *rc = conv1d_x3o_launch_one<K, D, MODE, 4, 3>(a, st);
@@ -227,7 +242,8 @@ bool conv1d_x3o_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc)
             // one chunk per wave; k >= 5 keeps K * 12 weight registers per wave: up to 12 waves (168 registers each), k = 3 up to 16
             if (nchunks <= 4) *rc = conv1d_x3o_launch_one<K, D, MODE, 4, 1>(a, st);
             else if (nchunks <= 8) *rc = conv1d_x3o_launch_one<K, D, MODE, 8, 1>(a, st);
-            else if (nchunks <= 12) *rc = conv1d_x3o_launch_one<K, D, MODE, 12, 1>(a, st);
+            else if (K == 2) return false;      // (the whole-tile polyphase epilogue spills beyond eight waves' register budget)
+            else if (nchunks <= 12) *rc = conv1d_x3o_launch_one<K, D, MODE, (K == 2 ? 8 : 12), 1>(a, st);
             else {
                 if constexpr (K == 3) {
                     if (nchunks <= 16) {

@@ -332,7 +332,10 @@ bool conv1d_x3s_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc)
         // a wave per (32-row, 32-column) tile and K slice; eight slices when the reduction is long (k = 3 at >= 512 channels)
         if constexpr (K == 3 && MODE == TTSAMD_CONV_NORMAL) {
             if (a.c_in >= 32 * kConvCK) {
-                *rc = conv1d_x3s_launch_geom<K, D, MI, 1, 1, MODE, 8, CPI>(a, st);
+                // round 4: sixteen slices (FFN conv_2, 768 channels: three K iterations instead of six) while the launch is a
+                // handful of tiles; eight beyond
+                if (blocks32 <= 64) *rc = conv1d_x3s_launch_geom<K, D, MI, 1, 1, MODE, 16, CPI>(a, st);
+                else *rc = conv1d_x3s_launch_geom<K, D, MI, 1, 1, MODE, 8, CPI>(a, st);
                 return true;
             }
         }
