@@ -114,6 +114,29 @@ def test_rel_attention_long_kernel_on_the_short_cases(gpu):
     assert p.returncode == 0 and "long attention OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 
+@pytest.mark.parametrize("force", ["0", "1"])
+def test_rel_attention_both_block_shapes_on_the_same_cases(gpu, force):
+    """Launches of up to 96 blocks take the 8-wave small-grid kernel (attention_v2.h), larger ones the 4-wave kernel; here each
+    is forced onto every ordinary case in a fresh process (TTSAMD_ATT_V2=0 / 1): windows, ragged masks, T < 5, head sizes that
+    are not multiples of 32, one and several key tiles per wave."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from tests import test_text_gpu as t\n"
+            "gpu = torch.device('cuda:0')\n"
+            "for c in [(4, 257, [257, 200], 192), (None, 64, [64, 31], 192), (4, 3, [3, 2], 192), (4, 40, [40, 1], 192),\n"
+            "          (4, 70, [70, 33], 196), (None, 50, [50, 9], 20), (4, 129, [129, 128], 192), (4, 600, [600, 311], 192),\n"
+            "          (None, 1000, [1000, 999], 64)]:\n"
+            "    t.test_rel_attention_matches_oracle(gpu, *c)\n"
+            "print('attention OK')\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280,
+                       env=dict(os.environ, TTSAMD_ATT_V2=force), cwd=root)
+    assert p.returncode == 0 and "attention OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
 def test_text_encoder_matches_oracle(gpu):
     a = dict(O.VITS_DEFAULTS)
     sd = W.make_vits_state(dict(upsample_initial_channel_decoder=32), seed=21, with_decoder=False)

@@ -430,6 +430,12 @@ __global__ __launch_bounds__(kAttThreads, 2) void rel_attention_long_kernel(
     }
 }
 
+}  // namespace ttsamd
+#include "attention_v2.h"
+namespace ttsamd {
+
+constexpr long kAttV2MaxBlocks = 96;     // (query tile, head, item) blocks up to which the 8-wave small-grid kernel is taken
+
 template <int DK>
 static int launch_att(float *out, const float *q, const float *k, const float *v, long bstride, const float *mask,
                       const float *ek, const float *ev, int window, int batch, int heads, int dk, int T, hipStream_t st)
@@ -453,6 +459,22 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
                            window, heads, dk, T);
         TTSAMD_LAUNCH_CHECK();
         return TTSAMD_OK;
+    }
+    {
+        // small grids (a single request: 18 blocks at T = 257): the 8-wave kernel of attention_v2.h.  TTSAMD_ATT_V2=0 / 1 forces
+        // the choice (tests run both kernels on the same inputs)
+        static const char *force_v2 = getenv("TTSAMD_ATT_V2");
+        const bool small = (long)ntiles * heads * batch <= kAttV2MaxBlocks;
+        const size_t lds_v2 = (size_t)(att2::kRows * (ntiles * 32 + 4) + ntiles * 32 + 2 * nrel * DK + att2::kWaves * 1024) * sizeof(float);
+        if ((force_v2 ? force_v2[0] == '1' : small) && lds_v2 <= 160 * 1024) {
+            auto k2 = att2::rel_attention_v2_kernel<DK>;
+            static std::atomic<unsigned long long> lds_attr_v2{0};
+            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), (int)(160 * 1024), lds_attr_v2));
+            hipLaunchKernelGGL(k2, dim3(ntiles, heads, batch), dim3(att2::kThreads), lds_v2, st, out, q, k, v, bstride, mask, ek, ev,
+                               window, heads, dk, T, ntiles * 32 + 4);
+            TTSAMD_LAUNCH_CHECK();
+            return TTSAMD_OK;
+        }
     }
     auto kern = rel_attention_kernel<DK>;
     static std::atomic<unsigned long long> lds_attr_done{0};   // per device, see ensure_dynamic_lds

@@ -13,6 +13,12 @@ int g_conv_small_grid = [] {
     const int m = e ? atoi(e) : 4;
     return m < 0 ? 0 : (m > 4 ? 4 : m);
 }();
+// TTSAMD_SMALL_GRID_BLOCKS=<n>: launches of up to n 128x128-class blocks take the small-grid tiles (A/B runs)
+long g_conv_small_grid_blocks = [] {
+    const char *e = getenv("TTSAMD_SMALL_GRID_BLOCKS");
+    const long m = e ? atol(e) : 128;
+    return m < 0 ? 0 : m;
+}();
 }
 
 extern "C" int ttsamd_conv1d_set_small_grid(int mode)

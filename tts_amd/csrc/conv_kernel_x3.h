@@ -34,7 +34,8 @@
 #define TTSAMD_X3_CFG64 1, 4, 2, 2
 #endif
 namespace ttsamd {
-constexpr long kConvSmallGridBlocks = 128;  // up to this many 128x128-class blocks a launch takes the small-grid tiles
+extern long g_conv_small_grid_blocks;       // conv.hip (default 128): up to this many 128x128-class blocks a launch takes the small-grid tiles
+#define kConvSmallGridBlocks g_conv_small_grid_blocks
 constexpr long kConvWaveTileBlocks = 1024;  // up to this many 32x32 tiles those kernels run a wave per tile and K slice
 extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = + K-split groups, 3 = + conv_kernel_x3s.h kernels, 4 = + conv_kernel_x3o.h (default)
 }

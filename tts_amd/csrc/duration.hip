@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void expand_prior_kernel(
     long tn = Ty;                     // extent (and row stride) of the noise tensor
     if (noise && noise_packed) {      // a contiguous [B, C, max(y_lengths)] draw: beyond that extent the noise is zero
         tn = 1;
-        for (int i = 0; i < (int)gridDim.y; ++i) tn = y_lengths[i] > tn ? y_lengths[i] : tn;
+        for (int i = 0; i < (int)gridDim.y; ++i) tn = y_lengths[i] > tn ? y_lengths[i] : tn;    // gridDim.y = batch
     }
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int grp = threadIdx.y;
@@ -252,8 +252,11 @@ __global__ __launch_bounds__(256) void expand_prior_kernel(
     const bool in_len = y < y_lengths[b];
     const bool valid = in_len && x < Tx && (!x_mask || x_mask[(long)b * Tx + x] != 0.f);
     const float ym = in_len ? 1.f : 0.f;
-    if (grp == 0 && y_mask) y_mask[(long)b * Ty + y] = ym;
-    for (int c = grp; c < C; c += 4) {
+    // channels are cut into slices of 16 along blockIdx.z (a single request launches 13 column tiles: one block per tile
+    // walked its 48 channel rounds alone for 50 us)
+    const int c_lo = blockIdx.z * 16, c_hi = min(C, c_lo + 16);
+    if (grp == 0 && y_mask && blockIdx.z == 0) y_mask[(long)b * Ty + y] = ym;
+    for (int c = c_lo + grp; c < c_hi; c += 4) {
         const long src = (long)b * stats_bstride + (long)c * Tx + x;
         const long dst = ((long)b * C + c) * Ty + y;
         const float mv = valid ? m[src] : 0.f;
@@ -434,7 +437,7 @@ extern "C" int ttsamd_expand_prior_ex(float *z_p, float *z_p2, float *m_p, float
                      "expand_prior: bad args");
     if (batch == 0 || t_y == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(batch <= 65535, "expand_prior: batch > 65535");
-    hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(t_y, 64), batch), dim3(64, 4), 0, as_stream(stream), z_p, z_p2,
+    hipLaunchKernelGGL(expand_prior_kernel, dim3(cdiv(t_y, 64), batch, cdiv(c, 16)), dim3(64, 4), 0, as_stream(stream), z_p, z_p2,
                        m_p, logs_p, y_mask, m, logs, (long)stats_bstride, noise, cum, x_mask,
                        reinterpret_cast<const long *>(y_lengths),
                        noise_scale, mask_out, noise_packed, c, t_x, t_y);
