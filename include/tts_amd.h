@@ -175,8 +175,12 @@ int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, 
  * groups of prefetch slack); part q of a weight = round-to-nearest bf16 of what parts < q left of it. */
 size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kernel);
 int ttsamd_conv1d_pack_weights_split(void *dst, const float *w, int c_out, int c_in, int kernel);
-/* 1 if (kernel, dilation) has a tuned instantiation. */
+/* 1 if ttsamd_conv1d takes this (kernel, dilation): any kernel <= 31 at any dilation <= 27.  ttsamd_conv1d_tuned: 1 for the pairs
+ * with tuned template instantiations (k in {1,2,5} at d = 1; k in {3,7,11} at d in {1,3,5}; k = 3, d = 9); every other pair — and a
+ * tuned pair in a mode it has no instantiation for — runs on a generic split-bf16 kernel (conv_generic.hip: one wave per 32x32
+ * tile, correct for any reference-legal config, not fast): NORMAL, GATE and SHUFFLE modes, split image (w_split) required. */
 int ttsamd_conv1d_supported(int kernel, int dilation);
+int ttsamd_conv1d_tuned(int kernel, int dilation);
 /* Launches that would put fewer than ~100 blocks on the chip (single-sentence requests): 0 = the large-grid tiles
  * everywhere, 1 = 64-column tiles with one 32x32 tile per wave (same summation order: bitwise the large-grid result),
  * 2 = those tiles plus, for c_in >= 128, wave groups that split the block's K loop and are reduced in a fixed order

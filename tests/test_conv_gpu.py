@@ -390,3 +390,62 @@ def test_one_shot_kernel_fused_epilogues(gpu, T, conv_precision):
     if conv_precision == "x3":
         for k in (ops.CONV_COUPLE_AFFINE, ops.CONV_COUPLE_AFFINE_FWD, "gate"):
             assert _rel(outs[(4, k)], outs[(3, k)]) < 2e-6, k
+
+
+@pytest.mark.parametrize("case", [(2, 40, 48, 9, 2, 130), (1, 192, 70, 13, 1, 77), (1, 16, 16, 4, 1, 50), (2, 33, 20, 31, 27, 900),
+                                  (1, 64, 64, 3, 2, 200), (1, 96, 32, 6, 7, 65)])
+def test_generic_conv_any_kernel_and_dilation(gpu, case):
+    """Shapes without a tuned instantiation (ttsamd_conv1d_tuned == 0: k = 9 d = 2, k = 13, even kernels, k = 31 d = 27, a tuned
+    kernel size at an untuned dilation) run on the generic split-bf16 kernel with the full NORMAL epilogue — against torch."""
+    from tts_amd import _lib
+
+    B, Cin, Cout, K, D, T = case
+    assert _lib.lib().ttsamd_conv1d_supported(K, D) == 1 and _lib.lib().ttsamd_conv1d_tuned(K, D) == 0
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / np.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g)
+    pad = (K - 1) * D // 2
+    t_out = T + 2 * pad - (K - 1) * D
+    res = torch.randn(B, Cout, t_out, generator=g)
+    acc = torch.randn(B, Cout, t_out, generator=g)
+    lens = torch.tensor([T, max(1, T - 13)])[:B]
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()
+    omask = mask[:, :t_out] if t_out <= T else torch.ones(B, t_out)
+    want = (F.conv1d(F.leaky_relu(x * mask[:, None], 0.1), w, b, padding=pad, dilation=D) + res + acc) * omask[:, None] / 3.0
+    y = torch.full(want.shape, float("nan"), device=gpu)
+    pc = ops.PackedConv(w, b, gpu, dilation=D)
+    assert not pc.tuned
+    ops.conv1d(pc, x.to(gpu), y, t_out=t_out, in_act=ops.ACT_LRELU, in_slope=0.1, in_mask=mask.to(gpu), res=res.to(gpu),
+               accum=acc.to(gpu), out_mask=omask.contiguous().to(gpu), out_div=3.0)
+    assert _rel(y, want) < TOL
+    assert _lib.lib().ttsamd_conv1d_supported(32, 1) == 0 and _lib.lib().ttsamd_conv1d_supported(3, 28) == 0
+
+
+def test_generic_gate_conv_and_polyphase_transposed_conv(gpu):
+    """A WaveNet gate conv at k = 7, dilation 2 (VitsArgs kernel_size / dilation_rate are free parameters) and ConvTranspose1d
+    layers whose kernel is not twice the stride — k = 7 u = 3 (three taps per phase, k - u even), k = 4 u = 4 (one tap),
+    k = 6 u = 4 — in polyphase form on the generic kernel, against torch."""
+    g = torch.Generator().manual_seed(11)
+    B, H, T = 2, 64, 90
+    x = torch.randn(B, H, T, generator=g)
+    w = torch.randn(2 * H, H, 7, generator=g) / np.sqrt(H * 7)
+    b = torch.randn(2 * H, generator=g) * 0.1
+    pre = F.conv1d(x, w, b, padding=6, dilation=2)
+    want = torch.tanh(pre[:, :H]) * torch.sigmoid(pre[:, H:])
+    wg, bg = ops.gate_permute(w, b, H)
+    y = torch.empty(B, H, T, device=gpu)
+    ops.conv1d(ops.PackedConv(wg, bg, gpu, dilation=2), x.to(gpu), y, mode=ops.CONV_GATE)
+    assert _rel(y, want) < TOL
+    for k, u, cin, cout in ((7, 3, 48, 24), (4, 4, 32, 16), (6, 4, 40, 20), (16, 8, 64, 32)):
+        wt = torch.randn(cin, cout, k, generator=g) / np.sqrt(cin * k)
+        bt = torch.randn(cout, generator=g) * 0.1
+        xin = torch.randn(B, cin, 37, generator=g)
+        pad = (k - u) // 2
+        want = F.conv_transpose1d(F.leaky_relu(xin, 0.1), wt, bt, u, pad)
+        wp, bp = ops.convt_polyphase_weight(wt, bt, u)
+        pc = ops.PackedConv(wp, bp, gpu, pad_left=wp.shape[2] - 1)
+        y = torch.full(want.shape, float("nan"), device=gpu)
+        ops.conv1d(pc, xin.to(gpu), y, t_out=37 + wp.shape[2] - 1, in_act=ops.ACT_LRELU, in_slope=0.1, mode=ops.CONV_SHUFFLE,
+                   shuffle_u=u, shuffle_pad=pad)
+        assert y.shape == want.shape and _rel(y, want) < TOL, (k, u)

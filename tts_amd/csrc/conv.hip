@@ -28,13 +28,21 @@ extern "C" int ttsamd_conv1d_set_small_grid(int mode)
     return was;
 }
 
-extern "C" int ttsamd_conv1d_supported(int kernel, int dilation)
+// (kernel, dilation) pairs with tuned template instantiations; everything else up to k = 31, d = 27 takes the generic kernel
+static int conv1d_tuned(int kernel, int dilation)
 {
     switch (kernel) {
         case 1: case 2: case 5: return dilation == 1;
         case 3: case 7: case 11: return dilation == 1 || dilation == 3 || dilation == 5 || (kernel == 3 && dilation == 9);
         default: return 0;
     }
+}
+
+extern "C" int ttsamd_conv1d_tuned(int kernel, int dilation) { return conv1d_tuned(kernel, dilation); }
+
+extern "C" int ttsamd_conv1d_supported(int kernel, int dilation)
+{
+    return kernel >= 1 && kernel <= 31 && dilation >= 1 && dilation <= 27;
 }
 
 extern "C" size_t ttsamd_conv1d_packed_floats(int c_out, int c_in, int kernel)
@@ -163,10 +171,11 @@ extern "C" int ttsamd_conv1d(const ttsamd_conv1d_args *args, void *stream)
         }
     }
     if (!ttsamd_conv1d_supported(a.kernel, a.dilation)) {
-        set_error("conv1d: (kernel=%d, dilation=%d) has no instantiation", a.kernel, a.dilation);
+        set_error("conv1d: (kernel=%d, dilation=%d) outside the supported range (kernel <= 31, dilation <= 27)", a.kernel, a.dilation);
         return TTSAMD_ERR_UNSUPPORTED;
     }
     hipStream_t st = as_stream(stream);
+    if (!conv1d_tuned(a.kernel, a.dilation)) return conv1d_launch_generic(a, st);      // any other (k, d): conv_generic.hip
     if (conv_post_eligible(a)) return conv_post_launch(a, st);   // C -> 1 (HiFiGAN conv_post): pure HBM streaming
     switch (a.kernel) {
         case 1: return conv1d_launch_k1(a, st);

@@ -7,11 +7,11 @@
 
 namespace ttsamd {
 
-inline int conv1d_mode_unsupported(const ttsamd_conv1d_args &a)
-{
-    set_error("conv1d: mode %d has no instantiation for kernel=%d dilation=%d", a.mode, a.kernel, a.dilation);
-    return TTSAMD_ERR_UNSUPPORTED;
-}
+int conv1d_launch_generic(const ttsamd_conv1d_args &a, hipStream_t st);   // conv_generic.hip: any (kernel, dilation), NORMAL / GATE / SHUFFLE
+
+// a (kernel, dilation) with tuned NORMAL kernels but no instantiation of this mode (a WaveNet gate conv at k = 7, a polyphase
+// ConvTranspose with three taps): the generic kernel
+inline int conv1d_mode_unsupported(const ttsamd_conv1d_args &a, hipStream_t st) { return conv1d_launch_generic(a, st); }
 
 // Fused epilogues exist where the models use them: GATE on the WaveNet in_layers (k=3/5, d=1), SHUFFLE on the
 // polyphase transposed conv (k=2), COUPLE / RES_SKIP / COUPLE_AFFINE on 1x1 convs.
@@ -50,7 +50,7 @@ int conv1d_launch_kd(const ttsamd_conv1d_args &a, hipStream_t st)
             if constexpr (K == 1) return conv1d_launch_prec<K, D, TTSAMD_CONV_COUPLE_AFFINE_MIX>(a, st);
             break;
     }
-    return conv1d_mode_unsupported(a);
+    return conv1d_mode_unsupported(a, st);
 }
 
 // single-output-channel streaming kernel (conv_post.hip)

@@ -50,8 +50,13 @@ class HifiganGenerator:
         self.num_kernels = len(self.resblock_kernel_sizes)
         self.num_upsamples = len(self.upsample_factors)
         for u, k in zip(self.upsample_factors, self.upsample_kernel_sizes):
-            if k != 2 * u or u % 2:
-                raise _lib.TtsAmdError("HIP ConvTranspose1d path needs kernel == 2*stride, even stride (got k=%d u=%d)" % (k, u))
+            if k < u:
+                raise _lib.TtsAmdError("ConvTranspose1d with kernel < stride (k=%d u=%d) leaves output samples without any tap: "
+                                       "the reference's padding (k - u) // 2 is negative there" % (k, u))
+        # any (kernel, stride): ConvTranspose1d runs in polyphase form, a ceil(k / u)-tap Conv1d with a pixel-shuffle epilogue
+        # (k = 2u: the tuned 2-tap kernels; everything else: the generic kernel).  With k - u odd the reference's output is one
+        # sample longer than T * u per stage: fine for forward(); ragged batching / length buckets then do not apply
+        self.exact_hop = all((k - u) % 2 == 0 for u, k in zip(self.upsample_factors, self.upsample_kernel_sizes))
         self.device = torch.device("cpu")
         self._sd = None
         self._packed = None
@@ -130,7 +135,7 @@ class HifiganGenerator:
             P["cond_layer"] = PackedConv(sd["cond_layer.weight"], sd.get("cond_layer.bias"), dev)
         for i, u in enumerate(self.upsample_factors):
             w, b = ops.convt_polyphase_weight(ops.fold_weight_norm(sd, "ups.%d" % i), sd.get("ups.%d.bias" % i), u)
-            P["ups.%d" % i] = PackedConv(w, b, dev, pad_left=1)
+            P["ups.%d" % i] = PackedConv(w, b, dev, pad_left=w.shape[2] - 1)
             if self.cond_in_each_up_layer and ("conds.%d.weight" % i) in sd:
                 # conds[i] is a 1x1 conv of g: its output (one offset per (b, channel)) rides in the transposed conv's
                 # epilogue; rows are repeated per polyphase row (packed row = channel*u + phase)
@@ -213,6 +218,8 @@ class HifiganGenerator:
         ch = self.upsample_initial_channel
         o = new(ch, T)
         sm = [None] * (self.num_upsamples + 1)        # per-stage length masks [B, T_stage]
+        if (lengths is not None or _masks is not None) and not self.exact_hop:
+            raise _lib.TtsAmdError("ragged batching needs upsample kernels with k - stride even (output = frames * hop exactly)")
         if _masks is not None:
             sm = list(_masks)
             in_mask = sm[0] if in_mask is None else in_mask * sm[0]
@@ -234,11 +241,13 @@ class HifiganGenerator:
         concurrent = (parallel.active_lanes() <= 1) if self.concurrent_branches == "auto" else bool(self.concurrent_branches)
         for i, u in enumerate(self.upsample_factors):
             ch //= 2
-            T_up = T * u
+            k_up = self.upsample_kernel_sizes[i]
+            pad_up = (k_up - u) // 2                                  # hifigan_generator.py:216
+            T_up = (T - 1) * u - 2 * pad_up + k_up                    # = T * u when k - u is even
             up = new(ch, T_up)
             rb = ops.speaker_cond(P["conds.%d" % i], g) if (g is not None and ("conds.%d" % i) in P) else None
             ops.conv1d(P["ups.%d" % i], o, up, in_act=ACT_LRELU, in_slope=LRELU_SLOPE, mode=CONV_SHUFFLE,
-                       shuffle_u=u, shuffle_pad=u // 2, in_mask=sm[i], row_bias=rb)
+                       shuffle_u=u, shuffle_pad=pad_up, in_mask=sm[i], row_bias=rb, t_out=T + P["ups.%d" % i].kernel - 1)
             msk = sm[i + 1]
             T = T_up
             o_next = new(ch, T)
@@ -340,7 +349,7 @@ class HifiganGenerator:
         `lengths` [B] (frames, optional) = ragged-exact batching (see forward): row b's first
         (lengths[b] + 2*pad)*hop samples equal `inference(c[b:b+1, :, :lengths[b]])`."""
         c = c.to(self.device).contiguous().float()
-        if (self.use_graphs and lengths is None and c.shape[0] == 1 and 0 < c.shape[2] <= self.graph_max_frames):
+        if (self.use_graphs and self.exact_hop and lengths is None and c.shape[0] == 1 and 0 < c.shape[2] <= self.graph_max_frames):
             T = c.shape[2]
             t_pad = -(-T // 32) * 32
             cp = torch.zeros((1, c.shape[1], t_pad), dtype=torch.float32, device=c.device)

@@ -62,8 +62,6 @@ class RelativePositionTransformer:
         self.proj = None
         if (p + "proj.weight") in sd:  # only when out_channels != hidden (transformer.py:398-399,426-427)
             self.proj = PackedConv(sd[p + "proj.weight"], sd.get(p + "proj.bias"), device)
-        if kernel_size % 2 == 0:
-            raise ops._lib.TtsAmdError("FFN kernel_size must be odd for the HIP conv path")
 
     def __call__(self, x, mask):
         """x [B,H,T] already multiplied by mask, mask [B,T] -> [B,H_out,T] (masked).  transformer.py:409-432.
@@ -79,17 +77,18 @@ class RelativePositionTransformer:
             ops.conv1d(L["o"], att, xy, res=x)                                  # x + attn(x)
             x1 = ops.channel_norm(xy, _new(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, out_mask=mask)
             hid = _new(x, L["f1"].c_out)
-            ops.conv1d(L["f1"], x1, hid, out_act=ACT_RELU, out_mask=mask)       # relu(conv_1(x*mask)) * mask
+            # (t_out = T: an even FFN kernel pads (k-1)//2 left, k//2 right — transformer.py:306-313 — and keeps the length)
+            ops.conv1d(L["f1"], x1, hid, out_act=ACT_RELU, out_mask=mask, t_out=T)       # relu(conv_1(x*mask)) * mask
             last = (i + 1) == self.num_layers
             if last and self.proj is not None:
                 xo = _new(x, self.proj.c_out)
                 ops.conv1d(self.proj, x1, xo)
                 y = _new(xo)
-                ops.conv1d(L["f2"], hid, y, out_mask=mask)
+                ops.conv1d(L["f2"], hid, y, out_mask=mask, t_out=T)
                 x = ops.channel_norm(y, _new(xo), L["n2"].gamma, L["n2"].beta, L["n2"].eps, pre_res=xo, out_mask=mask)
             else:
                 y = _new(x)
-                ops.conv1d(L["f2"], hid, y, res=x1, out_mask=mask)              # x + ffn(x) (x1 is masked)
+                ops.conv1d(L["f2"], hid, y, res=x1, out_mask=mask, t_out=T)    # x + ffn(x) (x1 is masked)
                 x = ops.channel_norm(y, _new(x), L["n2"].gamma, L["n2"].beta, L["n2"].eps, out_mask=mask)
         return x
 

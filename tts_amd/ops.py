@@ -106,7 +106,9 @@ class PackedConv:
         self.pad_left = (self.kernel - 1) * dilation // 2 if pad_left is None else pad_left
         L = lib()
         if not L.ttsamd_conv1d_supported(self.kernel, dilation):
-            raise _lib.TtsAmdError("conv1d kernel=%d dilation=%d has no HIP instantiation" % (self.kernel, dilation))
+            raise _lib.TtsAmdError("conv1d kernel=%d dilation=%d is outside the HIP path's range (kernel <= 31, dilation <= 27)"
+                                   % (self.kernel, dilation))
+        self.tuned = bool(L.ttsamd_conv1d_tuned(self.kernel, dilation))      # else: the generic split-bf16 kernel
         L.ttsamd_conv1d_packed_floats.restype = ctypes.c_size_t
         n = L.ttsamd_conv1d_packed_floats(self.c_out, self.c_in, self.kernel)
         packed = torch.empty(n, dtype=torch.float32)
@@ -170,7 +172,8 @@ def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, 
     elif y2 is not None:          # CONV_COUPLE_AFFINE_MIX: the flow block's mix parameters (flat)
         a.y2 = y2.data_ptr()
     a.split_row, a.row_bias = split_row, _dp(row_bias)
-    a.w_split = pc.w_split.data_ptr() if _PRECISION == "x3" else None
+    # (shapes without a tuned instantiation run on the generic kernel, which is split-bf16 whatever the precision switch says)
+    a.w_split = pc.w_split.data_ptr() if (_PRECISION == "x3" or not pc.tuned or mode == CONV_SHUFFLE and pc.kernel != 2) else None
     if _TIMER is not None and not torch.cuda.is_current_stream_capturing():
         key = _TIMER.select(pc, a)
         if key is not None:
@@ -254,14 +257,17 @@ def fold_weight_norm(sd, name):
 
 
 def convt_polyphase_weight(w_t, bias, u):
-    """ConvTranspose1d weight [C_in, C_out, 2u] (stride u, pad u/2) -> equivalent 2-tap Conv1d weight
-    [C_out*u, C_in, 2] with packed row m = co*u + r:  W'[m, ci, j'] = w[ci, co, r + (1-j')*u]
-    (out[co, q*u + r - pad] = sum_ci sum_j x[ci, q-j] w[ci, co, r + j*u])."""
+    """ConvTranspose1d weight [C_in, C_out, k] (stride u, any k >= 1) -> the equivalent J-tap Conv1d weight [C_out*u, C_in, J],
+    J = ceil(k / u), with packed row m = co*u + r (phase r of output channel co):
+        out[co, q*u + r - pad] = sum_ci sum_j x[ci, q - j] w[ci, co, r + j*u]      (taps with r + j*u >= k are zero)
+    as a Conv1d with pad_left = J - 1:  W'[m, ci, j'] = w[ci, co, r + (J - 1 - j')*u].  HiFiGAN's k = 2u gives J = 2."""
     cin, cout, k = w_t.shape
-    assert k == 2 * u, "polyphase path needs kernel == 2*stride (HiFiGAN upsamplers)"
-    w = w_t.permute(1, 2, 0).reshape(cout, 2, u, cin)       # [co, j, r, ci]  (k = j*u + r)
+    J = -(-k // u)
+    wz = torch.zeros(cin, cout, J * u, dtype=w_t.dtype)
+    wz[:, :, :k] = w_t
+    w = wz.permute(1, 2, 0).reshape(cout, J, u, cin)         # [co, j, r, ci]  (tap index = j*u + r)
     w = w.permute(0, 2, 3, 1)                                # [co, r, ci, j]
-    w = torch.flip(w, [3]).reshape(cout * u, cin, 2)         # j' = 1 - j
+    w = torch.flip(w, [3]).reshape(cout * u, cin, J)         # j' = J - 1 - j
     b = None if bias is None else bias.repeat_interleave(u)
     return w.contiguous(), b
 
