@@ -205,6 +205,49 @@ def pmc_state(name):
             else "null: committed PMC file is stale (recorded with stamp %s, running %s)" % (d.get("code_stamp"), code_stamp()))
 
 
+def pmc_traffic_live(precision, kernel_sub, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel instantiation measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE,
+    then WRITE_SIZE — one counter set per pass, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a child process
+    that launches the kernel at its two headline shapes (scripts/pmc_dominant_target.py).  Corrections of the same guide:
+    both counters are KiB; FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (x2).
+    -> (bytes per launch or None, description)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="ttsamd_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
+            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                                os.path.join(ROOT, "scripts", "pmc_dominant_target.py"), precision],
+                               capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, env=env)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc=%d)" % (ctr, r.returncode)
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == ctr and kernel_sub in row["Kernel_Name"].replace(" ", ""):
+                    per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, "no dispatch of %s in the counter file" % kernel_sub
+            vals[ctr] = (sum(per.values()) / len(per), len(per))
+    except Exception as e:          # the measurement is an extra: never cost the bench line
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return fetch + write, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over %d launches of the kernel at "
+                           "its two headline shapes; fetch %.4g B (KiB x1024 x2, gfx950 correction) + write %.4g B per launch"
+                           % (vals["FETCH_SIZE"][1], fetch, write))
+
+
 def timer_table(res):
     return {k: {"launches": r["launches"], "avg_us": r["ms"] * 1e3 / r["launches"],
                 "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12, "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
@@ -413,6 +456,11 @@ def wl_vits_e2e(args, ctx):
     line["rtf_x"] = value / SAMPLE_RATE
     line["rtf_x_per_gpu"] = value / SAMPLE_RATE / ctx.world
     pmc = "pmc_dominant_%s.json" % args.precision
+    kern_tmpl = "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0"
+    live_traffic, live_note = (None, "skipped (--no-live-pmc)")
+    if ctx.world == 1 and not args.no_live_pmc:
+        live_traffic, live_note = pmc_traffic_live(args.precision, ("conv1d_x3_kernel<%s," if args.precision == "x3" else
+                                                                    "conv1d_mfma_kernel<%s,") % kern_tmpl)
     line["roofline"] = {
         "bound": "mfma",
         "kernel": conv_kernel_name(args.precision, "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0")
@@ -423,7 +471,8 @@ def wl_vits_e2e(args, ctx):
         # against the 157.3 TF fp32 vector/fp32-MFMA peak (the split-bf16 kernels run on the bf16 pipe, so this one can exceed 1)
         "frac_of_8TBps": (dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS) if dom["launches"] else 0.0,
         "frac_of_157TF": ach / PEAK_FP32_MFMA_TFLOPS,
-        "traffic": load_pmc(pmc), "traffic_source": pmc_state(pmc),
+        "traffic": live_traffic if live_traffic is not None else load_pmc(pmc),
+        "traffic_source": live_note if live_traffic is not None else (pmc_state(pmc) + "; live pass: " + live_note),
         # from the same PMC passes: fraction of kernel cycles the matrix pipe is busy and the kernel's cycle count
         "pmc_mfma_busy_frac": load_pmc(pmc, "mfma_busy_frac"), "pmc_kernel_cycles": load_pmc(pmc, "kernel_cycles"),
         "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B) / HIP-event launch time; peak = bf16 dense MFMA "
@@ -868,6 +917,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--chars", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic (the committed, stamped PMC file is used)")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline run only: skip the configs[0] / configs[2] lines carried under extra_workloads at N=1")
     ap.add_argument("--serial-branches", action="store_true",

@@ -35,7 +35,7 @@ def test_rccl_process_group_and_weight_broadcast_on_one_gpu(gpu):
 def test_headline_workload_runs_through_the_process_group(gpu):
     """The headline workload itself under --force-pg (two short steps): weights arrive through the RCCL broadcast, the timed
     region is fenced by the group's barrier, value / time go through its all-reduces."""
-    p = _run(["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"])
+    p = _run(["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-live-pmc"])
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["value"] > 1e6 and line["config"]["weight_broadcast_bytes"] > 100e6
