@@ -464,7 +464,9 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
         // small grids (a single request: 18 blocks at T = 257): the 8-wave kernel of attention_v2.h.  TTSAMD_ATT_V2=0 / 1 forces
         // the choice (tests run both kernels on the same inputs)
         static const char *force_v2 = getenv("TTSAMD_ATT_V2");
-        const bool small = (long)ntiles * heads * batch <= kAttV2MaxBlocks;
+        // (from five key tiles up: at T = 64 — two key tiles, six of its eight waves without one — it measured 36 us against the
+        // 4-wave kernel's 16)
+        const bool small = (long)ntiles * heads * batch <= kAttV2MaxBlocks && ntiles >= 5;
         const size_t lds_v2 = (size_t)(att2::kRows * (ntiles * 32 + 4) + ntiles * 32 + 2 * nrel * DK + att2::kWaves * 1024) * sizeof(float);
         if ((force_v2 ? force_v2[0] == '1' : small) && lds_v2 <= 160 * 1024) {
             auto k2 = att2::rel_attention_v2_kernel<DK>;
