@@ -229,33 +229,6 @@ int ttsamd_resblock_pair(const ttsamd_resblock_args *args /* host */, void *stre
 int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
 
 /* ------------------------------------------------------------------------------------------
- * The seam between two Glow-TTS flow blocks, reverse direction, as one launch (single-sentence latency path):
- *   out = (out + res_skip_last(acts) + b_rs) * mask        last WaveNet layer's 1x1 conv (wavenet.py:109-115; `accumulate`)
- *   ttsamd_conv1d(mode COUPLE_AFFINE_MIX) with CouplingBlock.end (glow.py:214-224, :107-137, normalization.py:98-103): x in place
- *   h_next = (start_next(x[:half]) + b_start) * mask       the NEXT block's CouplingBlock.start (glow.py:199-201; w_start may be
- *                                                           NULL: last block of the stack)
- * Weights: split images (ttsamd_conv1d_pack_weights_split) of [hidden, hidden, 1], the pair-packed [end_rows, hidden, 1] (end_rows =
- * 32 * ceil(half / 16), biases in packed order) and [hidden, half, 1]; `mix` as for COUPLE_AFFINE_MIX.  hidden = 192, half <= 96.
- * Equal to the separate launches up to fp32 re-association of the reductions. */
-typedef struct ttsamd_flow_seam_args {
-    const float *acts;      /* [B, hidden, T] gate output of the last WaveNet layer */
-    const float *out;       /* [B, hidden, T] skip sum of the earlier layers (read when accumulate != 0) */
-    float *out_store;       /* or NULL: receives the finished WaveNet output */
-    float *x;               /* [B, 2 * half, T] flow state, updated in place */
-    const float *mask;      /* [B, T] or NULL */
-    const void *w_rs;
-    const float *b_rs;
-    const void *w_end;
-    const float *b_end;
-    const float *mix;
-    const void *w_start;    /* or NULL */
-    const float *b_start;
-    float *h_next;          /* [B, hidden, T] */
-    int32_t hidden, half, end_rows, t, batch, accumulate;
-} ttsamd_flow_seam_args;
-int ttsamd_glow_flow_seam(const ttsamd_flow_seam_args *args /* host */, void *stream);
-
-/* ------------------------------------------------------------------------------------------
  * Channel LayerNorm on [B, C, T] (normalise over C for every (b, t)), with the fusions the text
  * encoder / duration predictors need.
  * replaces: TTS/tts/layers/generic/normalization.py:5-28 (LayerNorm, eps 1e-4) and :31-53

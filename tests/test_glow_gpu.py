@@ -312,41 +312,3 @@ def test_flow_block_tail_in_one_epilogue_is_bitwise_the_two_kernels(gpu, T):
         finally:
             ops.set_conv_small_grid(was)
         assert torch.equal(a, b_), mode
-
-
-@pytest.mark.parametrize("T,B", [(318, 1), (64, 3), (33, 1)])
-def test_flow_seam_launch_equals_the_separate_launches(gpu, T, B):
-    """ops.glow_flow_seam (last res/skip conv + end conv + coupling + mix + the next block's start conv in one launch) against
-    the separate launches: the whole reverse decoder with the seam on and off (three blocks, ragged masks, an odd frame count),
-    and one seam call's WaveNet output against the plain conv."""
-    args = dict(num_flow_blocks_dec=3)
-    sd = W.make_glow_state(args, seed=91)
-    dec = layers.GlowDecoder(sd, "decoder.", gpu, 80, 192, 5, 1, 3, 4)
-    g = torch.Generator().manual_seed(T + B)
-    z = torch.randn(B, 80, T, generator=g).to(gpu)
-    lens = torch.tensor([T, max(2, T - 11), max(2, T // 2)][:B])
-    mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(gpu)
-    z = z * mask[:, None]
-    assert dec.fuse_seam
-    got = dec(z.clone(), mask)
-    dec.fuse_seam = False
-    want = dec(z.clone(), mask)
-    assert got.shape == want.shape and _rel(got, want) < 2e-6
-    # one call: the finished WaveNet output it hands back == the plain last res/skip conv
-    blk, nxt = dec.blocks[2], dec.blocks[1]
-    Tq = T // 2
-    acts = torch.randn(B, 192, Tq, generator=torch.Generator().manual_seed(1)).to(gpu)
-    out0 = torch.randn(B, 192, Tq, generator=torch.Generator().manual_seed(2)).to(gpu)
-    x = torch.randn(B, 160, Tq, generator=torch.Generator().manual_seed(3)).to(gpu)
-    mq = mask[:, 1::2][:, :Tq].contiguous()
-    want_out = out0.clone()
-    ops.conv1d(blk["wn"].rs_layers[-1], acts, want_out, accum=want_out, out_mask=mq)
-    xa = x.clone()
-    ops.conv1d(blk["end"], want_out, xa, mode=ops.CONV_COUPLE_AFFINE_MIX, res=xa, res_row_offset=80, y_row_offset=80, out_mask=mq,
-               split_row=80, y2=blk["mix"])
-    want_h = torch.empty(B, 192, Tq, device=gpu)
-    ops.conv1d(nxt["start"], xa, want_h, out_mask=mq)
-    xb, got_out, got_h = x.clone(), torch.empty_like(out0), torch.empty(B, 192, Tq, device=gpu)
-    ops.glow_flow_seam(acts, out0, xb, mq, blk["wn"].rs_layers[-1], blk["end"], blk["mix"], 80, start=nxt["start"], h_next=got_h,
-                       out_store=got_out)
-    assert _rel(got_out, want_out) < 2e-6 and _rel(xb, xa) < 2e-6 and _rel(got_h, want_h) < 2e-6

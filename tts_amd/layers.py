@@ -273,11 +273,9 @@ class WN:
                 raise ops._lib.TtsAmdError("WN speaker conditioning needs hidden_channels %% %d == 0" % ops.PAIR_ROWS)
             self.gate_idx = torch.tensor(idx, device=device)
 
-    def __call__(self, x, mask, out, g=None, out_kw=None, stop_before_last=False):
+    def __call__(self, x, mask, out, g=None, out_kw=None):
         """x [B,H,T] is updated IN PLACE layer by layer; `out` receives sum of skips * mask.
-        wavenet.py:92-116; the tanh*sigmoid gate (:6-13) lives in the in_layer conv's epilogue.
-        stop_before_last=True returns the last layer's gate output instead of running its res/skip conv (the caller fuses it
-        with what follows: ops.glow_flow_seam); `out` then holds the skip sum of the earlier layers."""
+        wavenet.py:92-116; the tanh*sigmoid gate (:6-13) lives in the in_layer conv's epilogue."""
         H = self.hidden
         gl = None
         if g is not None and self.cond is not None:   # cond_layer(g) sliced per layer (wavenet.py:98-105), gate row order
@@ -288,8 +286,6 @@ class WN:
             if i < self.num_layers - 1:
                 ops.conv1d(self.rs_layers[i], acts, x, mode=CONV_RES_SKIP, res=x, out_mask=mask, y2=out,
                            accum=out if i > 0 else None, split_row=H)
-            elif stop_before_last:
-                return acts
             else:
                 ops.conv1d(self.rs_layers[i], acts, out, accum=out if i > 0 else None, out_mask=mask)
         return out
@@ -440,10 +436,6 @@ class GlowDecoder:
             # epilogue (CONV_COUPLE_AFFINE_MIX) — a flow block is then 10 launches, not 11
             blk["mix"] = torch.cat([blk["w_inv"].reshape(-1), blk["an_bias"], blk["an_logs"]]).contiguous()
         self.fuse_mix = num_splits == 4 and c % 4 == 0 and self.half % 2 == 0
-        import os
-
-        self.fuse_seam = hidden == 192 and self.half <= 96 and os.environ.get("TTSAMD_GLOW_SEAM", "1") != "0"   # ttsamd_glow_flow_seam's build (env: A/B)
-        self.seam_max_blocks = 64          # (item, 32-column tile) blocks up to which the seam launch replaces the four
 
     def __call__(self, z, y_mask, g=None):
         """z [B,C,T] (masked), y_mask [B,T] -> mel [B,C,T]; reverse pass: for every block (last to first)
@@ -453,21 +445,6 @@ class GlowDecoder:
         x, mq = ops.glow_squeeze(z, y_mask, self.nsq)
         h = _new(x, self.hidden)
         out = _new(x, self.hidden)
-        Tq = x.shape[2]
-        if (self.fuse_seam and self.fuse_mix and ops.conv_precision() == "x3" and B * ((Tq + 31) // 32) <= self.seam_max_blocks):
-            # single sentences: the four pointwise launches between two blocks' WaveNets (last res/skip conv, end conv + coupling
-            # + mix, the next block's start conv) as ONE (ops.glow_flow_seam): 7 launches per flow block
-            rev = list(reversed(self.blocks))
-            h2 = _new(x, self.hidden)
-            ops.conv1d(rev[0]["start"], x, h, out_mask=mq)
-            for k, blk in enumerate(rev):
-                acts = blk["wn"](h, mq, out, g=g, stop_before_last=True)
-                nxt = rev[k + 1] if k + 1 < len(rev) else None
-                ops.glow_flow_seam(acts, out, x, mq, blk["wn"].rs_layers[-1], blk["end"], blk["mix"], self.half,
-                                   start=None if nxt is None else nxt["start"], h_next=None if nxt is None else h2,
-                                   accumulate=blk["wn"].num_layers > 1)
-                h, h2 = h2, h
-            return ops.glow_unsqueeze(x, mq, self.nsq, (T // self.nsq) * self.nsq)
         for blk in reversed(self.blocks):
             ops.conv1d(blk["start"], x, h, out_mask=mq)                       # start(x0) * mask   (x0 = first half)
             blk["wn"](h, mq, out, g=g)

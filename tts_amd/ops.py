@@ -242,32 +242,6 @@ def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, a
     return y
 
 
-class FlowSeamArgs(ctypes.Structure):
-    """Mirror of `ttsamd_flow_seam_args` (include/tts_amd.h)."""
-
-    _fields_ = [("acts", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_store", ctypes.c_void_p), ("x", ctypes.c_void_p),
-                ("mask", ctypes.c_void_p), ("w_rs", ctypes.c_void_p), ("b_rs", ctypes.c_void_p), ("w_end", ctypes.c_void_p),
-                ("b_end", ctypes.c_void_p), ("mix", ctypes.c_void_p), ("w_start", ctypes.c_void_p), ("b_start", ctypes.c_void_p),
-                ("h_next", ctypes.c_void_p), ("hidden", ctypes.c_int32), ("half", ctypes.c_int32), ("end_rows", ctypes.c_int32),
-                ("t", ctypes.c_int32), ("batch", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
-
-
-def glow_flow_seam(acts, out, x, mask, rs: "PackedConv", end: "PackedConv", mix, half, start=None, h_next=None, accumulate=True,
-                   out_store=None):
-    """Last res/skip conv of a flow block's WaveNet -> end conv + affine coupling + InvConvNear^-1 + ActNorm^-1 (x in place) ->
-    the NEXT block's start conv (h_next), one launch (ttsamd_glow_flow_seam)."""
-    B, H, T = acts.shape
-    assert acts.is_contiguous() and out.is_contiguous() and x.is_contiguous() and x.shape == (B, 2 * half, T)
-    a = FlowSeamArgs()
-    a.acts, a.out, a.out_store, a.x, a.mask = acts.data_ptr(), out.data_ptr(), _dp(out_store), x.data_ptr(), _dp(mask)
-    a.w_rs, a.b_rs, a.w_end, a.b_end, a.mix = rs.w_split.data_ptr(), _dp(rs.bias), end.w_split.data_ptr(), _dp(end.bias), mix.data_ptr()
-    if start is not None:
-        assert h_next is not None and h_next.shape == (B, H, T) and h_next.is_contiguous()
-        a.w_start, a.b_start, a.h_next = start.w_split.data_ptr(), _dp(start.bias), h_next.data_ptr()
-    a.hidden, a.half, a.end_rows, a.t, a.batch, a.accumulate = H, half, end.c_out, T, B, int(bool(accumulate))
-    check(lib().ttsamd_glow_flow_seam(ctypes.byref(a), stream_ptr()), "glow_flow_seam")
-
-
 def fold_weight_norm(sd, name):
     """Effective conv weight from a reference-layout state_dict entry: plain `.weight`, torch>=2.1
     parametrizations (`original0`=g, `original1`=v) or legacy `weight_g/weight_v`.
