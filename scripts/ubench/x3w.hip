@@ -45,9 +45,11 @@ struct Geom {
     static constexpr int kPad = (K - 1) / 2;
     static constexpr int kBN = 128;                         // output columns per block = 64 pairs
     static constexpr int kXS = kBN + 3 * kG + 1;            // signal positions 0 .. 2*63 + 3(G-1) + 1
-    static constexpr int kPlaneCols = (kXS + 1) / 2 + 1;    // per parity plane (+ one dump column)
+    static constexpr int kPlaneMin = (kXS + 1) / 2 + 1;     // per parity plane (+ one dump column)
+    static constexpr int kPlaneCols = kPlaneMin + ((11 - kPlaneMin % 16) + 16) % 16;   // = 11 mod 16: the two 8-channel halves of a
+                                                            // fragment read land 176 mod 256 bytes apart, as in the direct kernel
     static constexpr int kPlaneBytes = kPlaneCols * 16;
-    static constexpr int kSigBytes = 3 * 2 * 2 * kPlaneBytes;   // [part][half][parity]
+    static constexpr int kSigBytes = 3 * 2 * 2 * kPlaneBytes;   // [part][parity][half]
     static constexpr int kLdsBytes = 3 * kSigBytes;             // A, P, M
     static constexpr int kThreads = 256;
     static constexpr int kItems = 2 * kXS;                  // (half, position)
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3w_kernel(const Args a)
             soff[r][d] = (live && gt >= 0 && gt < T) ? (int)(((long)(half * 8) * T + gt) * 4) : kOob;
         }
         // idle lanes of the last round write the dump column of their plane
-        lplane[r] = (half * 2 + (s & 1)) * G::kPlaneBytes + (live ? (s >> 1) : G::kPlaneCols - 1) * 16;
+        lplane[r] = ((s & 1) * 2 + half) * G::kPlaneBytes + (live ? (s >> 1) : G::kPlaneCols - 1) * 16;
     }
     float st[G::kRounds][3][8];
     auto stage_load = [&](int chunk) {
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3w_kernel(const Args a)
             constexpr int sigs[4] = {0, 1, 2, 0};
             constexpr int offs[4] = {0, 1, 1, 1};
             const int pos = 3 * g + offs[i];
-            const unsigned char *base = lds + sigs[i] * G::kSigBytes + (h * 2 + (pos & 1)) * G::kPlaneBytes + (j + (pos >> 1)) * 16;
+            const unsigned char *base = lds + sigs[i] * G::kSigBytes + ((pos & 1) * 2 + h) * G::kPlaneBytes + (j + (pos >> 1)) * 16;
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 u32x4 bq[3];
