@@ -243,27 +243,6 @@ int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
  *   y[c,t]  = v * out_mask[t]                                (if out_mask)
  * Any channel count (up to 512 a thread keeps its channels in registers between the passes; beyond, the passes re-read x:
  * y must then not alias x). */
-/* One DilatedDepthSeparableConv layer (stochastic_duration_predictor.py:46-63) as one launch, for text-length tensors:
- *   y = x + GELU(LN_c(W GELU(LN_c(depthwise_k(x * mask))) + b))   [* out_mask: after the last layer]
- * = ttsamd_channel_norm(dw prologue, GELU) -> ttsamd_conv1d(1x1) -> ttsamd_channel_norm(GELU, post_res) up to fp32 summation
- * order.  Built for 192 channels (VitsArgs hidden_channels) and odd depthwise kernels <= 7 (ttsamd_dds_layer_supported);
- * w_split = split-bf16 image of the 1x1 conv's [c, c, 1] weight; y must not alias x. */
-typedef struct ttsamd_dds_layer_args {
-    const float *x;          /* [B, c, t] */
-    float *y;                /* [B, c, t] */
-    const float *mask;       /* [B, t] or NULL: multiplies x inside the depthwise conv */
-    const float *out_mask;   /* [B, t] or NULL */
-    const float *dw_w, *dw_bias;     /* [c, dw_kernel], [c] or NULL */
-    const float *gamma1, *beta1;     /* [c] */
-    const void *w_split;
-    const float *bias;               /* [c] or NULL */
-    const float *gamma2, *beta2;     /* [c] */
-    float eps;
-    int32_t c, t, batch, dw_kernel, dw_dilation;
-} ttsamd_dds_layer_args;
-int ttsamd_dds_layer(const ttsamd_dds_layer_args *args /* host */, void *stream);
-int ttsamd_dds_layer_supported(int channels, int dw_kernel);
-
 typedef struct ttsamd_norm_args {
     const float *x;
     int64_t x_bstride, x_rstride;

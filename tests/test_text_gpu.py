@@ -243,33 +243,3 @@ def test_duration_predictor_matches_oracle(gpu):
     want = O.duration_predictor(sd, "duration_predictor.", x, mask[:, None])
     got = layers.DurationPredictor(sd, "duration_predictor.", gpu)(x.to(gpu), mask.to(gpu))
     assert _rel(got, want[:, 0]) < TOL
-
-
-@pytest.mark.parametrize("T,B", [(257, 1), (45, 3), (31, 2)])
-def test_dds_layer_single_launch_equals_the_three_launches(gpu, T, B):
-    """ops.dds_layer (depthwise conv + LayerNorm + GELU -> 1x1 conv -> LayerNorm + GELU + residual in ONE launch; what a single
-    request's duration predictor takes) against the three launches it replaces, layer by layer (dilations 1, 3, 9, ragged masks,
-    the output mask of the last layer), and the whole DDSConv both ways."""
-    sd = W.make_vits_state(dict(upsample_initial_channel_decoder=32), seed=23, with_decoder=False)
-    dds = layers.DDSConv(sd, "duration_predictor.convs.", gpu, 192, 3, 3)
-    g = _g(T + B)
-    x = torch.randn(B, 192, T, generator=g).to(gpu)
-    lens = [T, max(1, T - 7), max(1, T // 2)][:B]
-    mask = _mask(lens, T).to(gpu)
-    assert ops.dds_layer_supported(192, 3)
-    for i, L in enumerate(dds.layers):
-        last = i == 2
-        y = ops.channel_norm(x, torch.empty_like(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, dw_w=L["dw_w"], dw_bias=L["dw_b"],
-                             dw_dilation=L["dil"], in_mask=mask, act=ops.ACT_GELU)
-        y2 = torch.empty_like(x)
-        ops.conv1d(L["pw"], y, y2)
-        want = ops.channel_norm(y2, torch.empty_like(x), L["n2"].gamma, L["n2"].beta, L["n2"].eps, act=ops.ACT_GELU, post_res=x,
-                                out_mask=mask if last else None)
-        got = ops.dds_layer(x, torch.empty_like(x), mask, L["dw_w"], L["dw_b"], L["dil"], L["n1"], L["pw"], L["n2"],
-                            out_mask=mask if last else None)
-        for b, n in enumerate(lens):
-            assert _rel(got[b, :, :n], want[b, :, :n]) < 5e-6, (i, b)
-    fused = dds(x, mask)
-    dds.fuse_max_blocks = 0
-    unfused = dds(x, mask)
-    assert _rel(fused, unfused) < 5e-6

@@ -133,20 +133,9 @@ class DDSConv:
                 pw=PackedConv(sd[p + "convs_1x1.%d.weight" % i], sd[p + "convs_1x1.%d.bias" % i], device),
                 n1=_Norm(sd, p + "norms_1.%d" % i, device, 1e-5), n2=_Norm(sd, p + "norms_2.%d" % i, device, 1e-5)))
 
-    # (item, 32-column tile) blocks up to which a layer runs as ONE launch (ops.dds_layer); TTSAMD_DDS_FUSE=0: never (A/B runs)
-    fuse_max_blocks = 0 if __import__("os").environ.get("TTSAMD_DDS_FUSE", "1") == "0" else 64
-
     def __call__(self, x, mask):
         """x [B,C,T] (conditioning already added) -> DDSConv(x) * mask."""
         n = len(self.layers)
-        B, C, T = x.shape
-        if (self.fuse_max_blocks and B * ((T + 31) // 32) <= self.fuse_max_blocks
-                and ops.dds_layer_supported(C, self.layers[0]["dw_w"].shape[-1]) and self.layers[0]["n1"].eps == self.layers[0]["n2"].eps):
-            # text-length tensors of a single request: three launches per layer -> one
-            for i, L in enumerate(self.layers):
-                x = ops.dds_layer(x, _new(x), mask, L["dw_w"], L["dw_b"], L["dil"], L["n1"], L["pw"], L["n2"],
-                                  out_mask=mask if i == n - 1 else None)
-            return x
         for i, L in enumerate(self.layers):
             y = ops.channel_norm(x, _new(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, dw_w=L["dw_w"], dw_bias=L["dw_b"],
                                  dw_dilation=L["dil"], in_mask=mask, act=ACT_GELU)

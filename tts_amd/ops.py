@@ -438,33 +438,6 @@ def channel_norm(x, y, gamma, beta, eps, *, dw_w=None, dw_bias=None, dw_dilation
     return y
 
 
-class DdsLayerArgs(ctypes.Structure):
-    """Mirror of `ttsamd_dds_layer_args` (include/tts_amd.h)."""
-
-    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("out_mask", ctypes.c_void_p),
-                ("dw_w", ctypes.c_void_p), ("dw_bias", ctypes.c_void_p), ("gamma1", ctypes.c_void_p), ("beta1", ctypes.c_void_p),
-                ("w_split", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("gamma2", ctypes.c_void_p), ("beta2", ctypes.c_void_p),
-                ("eps", ctypes.c_float), ("c", ctypes.c_int32), ("t", ctypes.c_int32), ("batch", ctypes.c_int32),
-                ("dw_kernel", ctypes.c_int32), ("dw_dilation", ctypes.c_int32)]
-
-
-def dds_layer_supported(channels, dw_kernel):
-    return _PRECISION == "x3" and bool(lib().ttsamd_dds_layer_supported(int(channels), int(dw_kernel)))
-
-
-def dds_layer(x, y, mask, dw_w, dw_b, dil, n1, pw: "PackedConv", n2, out_mask=None):
-    """One DilatedDepthSeparableConv layer as one launch (ttsamd_dds_layer): y = x + GELU(LN2(W GELU(LN1(dw(x * mask))) + b))."""
-    B, C, T = x.shape
-    assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and y.data_ptr() != x.data_ptr()
-    a = DdsLayerArgs()
-    a.x, a.y, a.mask, a.out_mask = x.data_ptr(), y.data_ptr(), _dp(mask), _dp(out_mask)
-    a.dw_w, a.dw_bias, a.gamma1, a.beta1 = dw_w.data_ptr(), _dp(dw_b), n1.gamma.data_ptr(), n1.beta.data_ptr()
-    a.w_split, a.bias, a.gamma2, a.beta2 = pw.w_split.data_ptr(), _dp(pw.bias), n2.gamma.data_ptr(), n2.beta.data_ptr()
-    a.eps, a.c, a.t, a.batch, a.dw_kernel, a.dw_dilation = n1.eps, C, T, B, dw_w.shape[-1], int(dil)
-    check(lib().ttsamd_dds_layer(ctypes.byref(a), stream_ptr()), "dds_layer")
-    return y
-
-
 def rel_attention(qkv, out, mask, heads, emb_rel_k=None, emb_rel_v=None, window=0):
     """qkv [B, 3*H*dk, T] (rows: q | k | v) -> out [B, H*dk, T] (include/tts_amd.h: ttsamd_rel_attention)."""
     B, C3, T = qkv.shape
