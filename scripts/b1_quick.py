@@ -27,3 +27,15 @@ for _ in range(n):
     lat.append((time.perf_counter() - t0) * 1e3)
 lat.sort()
 print("VITS B=1 request: p50 %.3f ms  p10 %.3f  p90 %.3f" % (lat[n // 2], lat[n // 10], lat[(9 * n) // 10]))
+import ctypes  # noqa: E402
+
+from tts_amd import _lib  # noqa: E402
+
+L = _lib.lib()
+L.ttsamd_launch_count.restype = ctypes.c_uint64
+m.inference(x, dict(aux, no_graph=True))
+torch.cuda.synchronize()
+n0 = int(L.ttsamd_launch_count())
+m.inference(x, dict(aux, no_graph=True))
+torch.cuda.synchronize()
+print("kernel launches per request (library launches of one eager run of the same chain): %d" % (int(L.ttsamd_launch_count()) - n0))
