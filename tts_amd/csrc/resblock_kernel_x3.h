@@ -22,6 +22,8 @@
 #pragma once
 #include "conv_kernel_x3.h"
 
+#include <cstdlib>
+
 namespace ttsamd {
 
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
@@ -394,6 +396,8 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
         case 8:
         case 16:   // zero-padded weight images of the [32, 32, k] conv (the caller passes them); the reduction walks only the
                    // first 16-channel chunk (round 4: the 32-channel tile did twice the MFMA and staging work on zeros)
+            // a sentence's 40-90 k columns: 128-column tiles (twice the blocks, half the chain per block: sentence -1 %, same box)
+            if (a.variant == 0 && cols <= 512 * 236) return resblock_pair_launch_cfg<K, D, 16, 1, 4, 1>(a, st);
             return resblock_pair_launch_cfg<K, D, 16, 1, 4, 2>(a, st);
         case 32:
             if (a.variant == 0 && cols <= 128 * 236) return resblock_pair_launch_cfg<K, D, 32, 1, 4, 1>(a, st);
