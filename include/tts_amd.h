@@ -227,6 +227,16 @@ typedef struct ttsamd_resblock_args {
 size_t ttsamd_resblock_weight_bytes(int c, int kernel);
 int ttsamd_resblock_pair(const ttsamd_resblock_args *args /* host */, void *stream);
 int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
+/* The three branches of one MRF stage at one dilation — kernel sizes 3, 7, 11 in slots 0, 1, 2 of args3 (a slot with x == NULL is
+ * absent), same c / t / batch / dilation — as ONE launch (hifigan_generator.py:255-261: the resblocks of a stage are independent).
+ * For the small grids of a single sentence only (ttsamd_resblock_group_supported: c in {8,16,32,64} and t * batch within the
+ * narrow-tile range of ttsamd_resblock_pair): there a stage's nine 10-20 us launches on three branch streams spend as long in
+ * cross-stream joins as in kernels.  Each slot computes exactly what ttsamd_resblock_pair computes for it (bitwise). */
+int ttsamd_resblock_group(const ttsamd_resblock_args *args3 /* host, [3] */, void *stream);
+int ttsamd_resblock_group_supported(int c, int t, int batch);
+/* y[i] = ((a[i] + b[i]) [+ c[i]]) / div — z_sum / num_kernels over branch outputs written separately (c may be NULL; n % 4 == 0,
+ * 16-byte aligned). */
+int ttsamd_sum_div(float *y, const float *a, const float *b, const float *c, float div, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Channel LayerNorm on [B, C, T] (normalise over C for every (b, t)), with the fusions the text

@@ -164,3 +164,65 @@ def test_hifigan_fused_equals_unfused(gpu, ragged):
         a, b = fused.double().cpu(), want.double()
         rms = float((a - b).pow(2).mean().sqrt())
         assert rms < 1e-4 and rms / float(b.pow(2).mean().sqrt()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(64, 1, 1, 2624, False), (32, 3, 2, 5000, True), (16, 5, 1, 41984, False), (8, 1, 3, 700, True),
+                                  (32, 5, 1, 37, False)])
+def test_grouped_branches_bitwise_equal_the_single_pairs(gpu, case):
+    """ttsamd_resblock_group: the k = 3 / 7 / 11 branches of one MRF stage in ONE launch (blockIdx.y = branch) write exactly the
+    bits of three ttsamd_resblock_pair launches — ragged masks, tensors shorter than a tile, two-branch groups (an absent slot),
+    different inputs per branch — and ttsamd_sum_div averages them in the reference's order (hifigan_generator.py:255-261)."""
+    C, D, B, T, masked = case
+    g = torch.Generator().manual_seed(C + D + T)
+    pairs = []
+    for K in (11, 3, 7):                                   # any order: the slot follows the kernel size
+        _, pc1, pc2, _ = _pair(C, K, D, 100 + K, gpu)
+        pairs.append((pc1, pc2))
+    xs = [torch.randn(B, C, T, generator=g).to(gpu) for _ in pairs]
+    lens = torch.tensor([T, max(1, T - 29), max(1, T // 3)][:B])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(gpu) if masked else None
+    assert ops.resblock_group_supported(pairs, B, C, T)
+    want = [ops.resblock_pair(pc1, pc2, x, torch.empty_like(x), slope=SLOPE, mask=mask) for (pc1, pc2), x in zip(pairs, xs)]
+    got = [torch.full_like(x, float("nan")) for x in xs]
+    ops.resblock_group(pairs, xs, got, slope=SLOPE, mask=mask)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    two = [torch.full_like(x, float("nan")) for x in xs[:2]]
+    ops.resblock_group(pairs[:2], xs[:2], two, slope=SLOPE, mask=mask)
+    assert torch.equal(two[0], want[0]) and torch.equal(two[1], want[1])
+    if T % 4 == 0:
+        y = torch.empty_like(xs[0])
+        ops.sum_div(got, y, 3.0)
+        w = [t.cpu() for t in want]          # true division on the CPU (torch's GPU division by a scalar multiplies by 1 / div)
+        assert torch.equal(y.cpu(), ((w[0] + w[1]) + w[2]) / 3.0)
+        ops.sum_div(got[:2], y, 2.0)
+        assert torch.equal(y.cpu(), (w[0] + w[1]) / 2.0)
+    # not a small-grid shape / a kernel size without a slot: refused, the caller launches the pairs one by one
+    assert not ops.resblock_group_supported(pairs, 32, C, 200000)
+    _, q1, q2, _ = _pair(C, 3, D, 7, gpu)
+    assert not ops.resblock_group_supported(pairs[:2] + [(q1, q2)], B, C, T)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_hifigan_grouped_stages_equal_branch_streams(gpu, ragged):
+    """HiFiGAN-v2 on a single sentence: every MRF stage as grouped launches (3 per stage + the average) vs the nine launches on
+    branch streams with the accumulate chained through the last convs — identical waveform bits, also through graph replay."""
+    cfg = dict(W.HIFIGAN_V2)
+    sd = O.make_hifigan_state(cfg, 80, seed=15)
+    m = HifiganGenerator(80, 1, cfg["resblock_type"], cfg["resblock_dilation_sizes"], cfg["resblock_kernel_sizes"],
+                         cfg["upsample_kernel_sizes"], cfg["upsample_initial_channel"], cfg["upsample_factors"],
+                         inference_padding=cfg["inference_padding"])
+    m.load_state_dict(sd)
+    m.to(gpu)
+    B = 2 if ragged else 1
+    mel = torch.randn(B, 80, 61, generator=torch.Generator().manual_seed(16))
+    lengths = torch.tensor([61, 40]).to(gpu) if ragged else None
+    m.use_graphs = False
+    assert m.group_branches
+    grouped = m.inference(mel.to(gpu), lengths=lengths)
+    m.group_branches = False
+    plain = m.inference(mel.to(gpu), lengths=lengths)
+    assert torch.equal(grouped, plain)
+    m.group_branches, m.use_graphs = True, True
+    for _ in range(3):
+        assert torch.equal(m.inference(mel.to(gpu), lengths=lengths), plain)

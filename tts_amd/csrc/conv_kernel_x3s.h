@@ -346,6 +346,18 @@ bool conv1d_x3s_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc)
     // rows never get here with a small grid (their 32-column tiling has 8x the default blocks, the unpaired one 16x).
     if constexpr (MI == 1) {
         if (mtiles % 2 == 0) {
+            // round 4: K >= 3 at >= 128 output rows (one utterance's 256-channel decoder stage: 256 -> 256, T = 6160) — the general
+            // kernel's 128-row x 64-column blocks (four waves of 32 x 64: a weight fragment serves two column tiles, half the L1
+            // bytes per MFMA of the 32 x 32 wave tiles below) with the K loop split between two wave groups.  Same box, us per
+            // launch k = 3 / 7 / 11: 30.0 / 49.6 / 69.4 -> 24.3 / 39.0 / 56.2; the B = 1 request 4.27 -> 4.11 ms
+            // (TTSAMD_X3S_WIDE=0 restores the 64 x 64 tiles for A/B runs)
+            static const bool wide = [] { const char *e = getenv("TTSAMD_X3S_WIDE"); return !e || atoi(e) != 0; }();
+            if constexpr (MODE == TTSAMD_CONV_NORMAL && K >= 3) {
+                if (wide && mtiles % 4 == 0 && (long)(mtiles / 4) * ((a.t_out + 63) / 64) * a.batch >= 128) {   // else too few blocks (128 rows, T = 2624: 41)
+                    *rc = conv1d_x3_launch_cfg<K, D, 1, 2, 4, 1, MODE, 2>(a, st);
+                    return true;
+                }
+            }
             *rc = conv1d_x3s_launch_geom<K, D, 1, 2, 2, MODE, (K > 5 ? 2 : 4), CPI>(a, st);   // k = 7 / 11 (TTSAMD_X3S_ALL): K weight slots need > 128 VGPRs
             return true;
         }

@@ -279,6 +279,22 @@ __global__ void scale_kernel(float *__restrict__ y, const float *__restrict__ x,
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
 
+// y = ((a + b) [+ c]) / div: the MRF's z_sum / num_kernels over separately written branch outputs, in the reference's order
+// (hifigan_generator.py:255-261)
+__global__ void sum_div_kernel(float *__restrict__ y, const float *__restrict__ a, const float *__restrict__ b,
+                               const float *__restrict__ c, float div, long n4)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 va = reinterpret_cast<const float4 *>(a)[i], vb = reinterpret_cast<const float4 *>(b)[i];
+        float4 v{va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w};
+        if (c) {
+            const float4 vc = reinterpret_cast<const float4 *>(c)[i];
+            v = float4{v.x + vc.x, v.y + vc.y, v.z + vc.z, v.w + vc.w};
+        }
+        reinterpret_cast<float4 *>(y)[i] = float4{v.x / div, v.y / div, v.z / div, v.w / div};
+    }
+}
+
 // z[b,c,t] = (m[b,c,t] + noise[b,c,t] * exp(logs[b,c,t])) * mask[b,t]; m / logs are the halves of one [B,2C,T] buffer
 __global__ void sample_gaussian_kernel(float *__restrict__ z, const float *__restrict__ stats,
                                        const float *__restrict__ noise, const float *__restrict__ mask, int C, int T)
@@ -452,6 +468,19 @@ extern "C" int ttsamd_scale(float *y, const float *x, float s, int64_t n, void *
     const long blocks = (n + kTxtThreads - 1) / kTxtThreads;
     hipLaunchKernelGGL(scale_kernel, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(kTxtThreads), 0, as_stream(stream),
                        y, x, s, (long)n);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_sum_div(float *y, const float *a, const float *b, const float *c, float div, int64_t n, void *stream)
+{
+    TTSAMD_CHECK_ARG(y && a && b && n >= 0 && div != 0.f, "sum_div: bad args");
+    TTSAMD_CHECK_ARG(n % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                                     reinterpret_cast<uintptr_t>(c)) & 15) == 0, "sum_div: 16-byte aligned tensors of a multiple of 4 elements");
+    if (n == 0) return TTSAMD_OK;
+    const long n4 = n / 4, blocks = (n4 + kTxtThreads - 1) / kTxtThreads;
+    hipLaunchKernelGGL(sum_div_kernel, dim3((int)(blocks > 8192 ? 8192 : blocks)), dim3(kTxtThreads), 0, as_stream(stream), y, a, b, c,
+                       div, n4);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

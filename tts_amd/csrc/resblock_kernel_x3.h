@@ -114,8 +114,12 @@ static __device__ long long g_res_clk[16];     // one per translation unit (no r
 #define RES_STAMP(i) do { } while (0)
 #endif
 
+typedef const ttsamd_resblock_args __attribute__((address_space(4))) *ResArgsKernargPtr;
+
+// The block's work.  `a`: the pair's arguments (a kernel parameter of the caller), `ep`: the same struct inside the kernarg
+// segment (the epilogue re-reads its arguments from there, see below), `tile`: (time tile, -, batch item) of this block.
 template <int K, int D, int C, int WM, int WN, int NI>
-__global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_x3_kernel(const ttsamd_resblock_args a)
+__device__ __forceinline__ void resblock_pair_body(const ttsamd_resblock_args &a, ResArgsKernargPtr ep, const ConvTile tile)
 {
 #ifdef TTSAMD_PHASE_CLOCKS
     const bool stamp = threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.z == gridDim.z / 2;
@@ -133,7 +137,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
     const int wn = wave % WN;
     const int h = lane >> 5;
     const int j = lane & 31;
-    const ConvTile tile = conv_tile_of_block();
     const int b = tile.b;
     const int t0 = tile.nb * G::kBN;      // first output column of this block
     const int T = a.t;
@@ -312,8 +315,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
 
     // ---- output epilogue: + bias2 (+ accum) (/ div) -------------------------------------------------------------------
     {
-        const ttsamd_resblock_args __attribute__((address_space(4))) *ep =
-            (const ttsamd_resblock_args __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ep) : : "memory");
         const float out_div = ep->out_div;
         const bool has_accum = ep->accum != nullptr;
@@ -358,6 +359,35 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc))
     __builtin_amdgcn_s_waitcnt(0);
 #endif
     RES_STAMP(8);
+}
+
+template <int K, int D, int C, int WM, int WN, int NI>
+__global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_x3_kernel(const ttsamd_resblock_args a)
+{
+    resblock_pair_body<K, D, C, WM, WN, NI>(a, (ResArgsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr(), conv_tile_of_block());
+}
+
+// The MRF's three branches (kernel sizes 3, 7, 11 — slot 0, 1, 2; a slot with x == NULL is absent) at one dilation as ONE launch:
+// blockIdx.y selects the branch.  A single sentence runs 9 fused pairs per stage on three branch streams — 10-20 us kernels of
+// 40-700 blocks whose cross-stream joins cost as much as the kernels (hipGraph replays them with ~10 us per cross-queue edge);
+// grouped, a stage is three launches on one stream, each as long as its longest branch.  The grid is sized for the branch with
+// the most time tiles (k = 11: the widest halo, the fewest valid columns per block); the others' surplus blocks return at once.
+struct ResGroupArgs {
+    ttsamd_resblock_args br[3];
+};
+template <int D, int C, int WM, int WN, int NI>
+__global__ __launch_bounds__(64 * WM * WN, (ResGeom<11, D, C, WM, WN, NI>::kOcc)) void resblock_group_x3_kernel(const ResGroupArgs g)
+{
+    const ResArgsKernargPtr ep = (ResArgsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const ConvTile tile{(int)blockIdx.x, 0, (int)blockIdx.z};
+    const int br = blockIdx.y;
+    if (br == 0) {
+        if (g.br[0].x && tile.nb * ResGeom<3, D, C, WM, WN, NI>::kBN < g.br[0].t) resblock_pair_body<3, D, C, WM, WN, NI>(g.br[0], ep, tile);
+    } else if (br == 1) {
+        if (g.br[1].x && tile.nb * ResGeom<7, D, C, WM, WN, NI>::kBN < g.br[1].t) resblock_pair_body<7, D, C, WM, WN, NI>(g.br[1], ep + 1, tile);
+    } else {
+        if (g.br[2].x && tile.nb * ResGeom<11, D, C, WM, WN, NI>::kBN < g.br[2].t) resblock_pair_body<11, D, C, WM, WN, NI>(g.br[2], ep + 2, tile);
+    }
 }
 
 template <int K, int D, int C, int WM, int WN, int NI>
@@ -413,6 +443,38 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
     return TTSAMD_ERR_UNSUPPORTED;
 }
 
+// small-grid tile of a channel count (the narrow tiles of resblock_pair_launch_kd): the grouped launch exists for these only
+inline bool resblock_group_small(int c, long cols)
+{
+    return ((c == 8 || c == 16) && cols <= 512 * 236) || (c == 32 && cols <= 128 * 236) || (c == 64 && cols <= 64 * 118);
+}
+
+template <int D, int C, int WM, int WN, int NI>
+int resblock_group_launch_cfg(const ResGroupArgs &g, int t, int batch, hipStream_t st)
+{
+    using G = ResGeom<11, D, C, WM, WN, NI>;      // the largest LDS image and the most blocks of the three
+    auto kern = resblock_group_x3_kernel<D, C, WM, WN, NI>;
+    static std::atomic<unsigned long long> lds_attr_done{0};
+    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)G::kLdsBytes, lds_attr_done));
+    const int nblocks = (t + G::kBN - 1) / G::kBN;
+    hipLaunchKernelGGL(kern, dim3(nblocks, 3, batch), dim3(G::kThreads), G::kLdsBytes, st, g);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+template <int D>
+int resblock_group_launch_d(const ResGroupArgs &g, int c, int t, int batch, hipStream_t st)
+{
+    switch (c) {
+        case 8:
+        case 16: return resblock_group_launch_cfg<D, 16, 1, 4, 1>(g, t, batch, st);
+        case 32: return resblock_group_launch_cfg<D, 32, 1, 4, 1>(g, t, batch, st);
+        case 64: return resblock_group_launch_cfg<D, 64, 2, 2, 1>(g, t, batch, st);
+    }
+    set_error("resblock_group: c = %d has no instantiation (8, 16, 32, 64)", c);
+    return TTSAMD_ERR_UNSUPPORTED;
+}
+
 template <int K>
 int resblock_pair_launch_k(const ttsamd_resblock_args &a, hipStream_t st)
 {
@@ -428,5 +490,8 @@ int resblock_pair_launch_k(const ttsamd_resblock_args &a, hipStream_t st)
 int resblock_pair_launch_k3(const ttsamd_resblock_args &a, hipStream_t st);
 int resblock_pair_launch_k7(const ttsamd_resblock_args &a, hipStream_t st);
 int resblock_pair_launch_k11(const ttsamd_resblock_args &a, hipStream_t st);
+int resblock_group_launch_d1(const ResGroupArgs &g, int c, int t, int batch, hipStream_t st);
+int resblock_group_launch_d3(const ResGroupArgs &g, int c, int t, int batch, hipStream_t st);
+int resblock_group_launch_d5(const ResGroupArgs &g, int c, int t, int batch, hipStream_t st);
 
 }  // namespace ttsamd

@@ -71,6 +71,9 @@ class HifiganGenerator:
         self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
         self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "8,16,32,64,128").split(",") if c)
         self.fuse_max_kernel = {128: 3}     # channel count -> largest kernel size fused (absent = all)
+        # small grids (a single sentence): the three MRF branches of a stage as ONE launch per ResBlock iteration instead of nine
+        # launches on three branch streams (forward())
+        self.group_branches = os.environ.get("TTSAMD_GROUP_BRANCHES", "1") != "0"
         self._side_streams = collections.OrderedDict()     # current stream handle -> its MRF branch streams (LRU first)
         self._retired = []          # evicted sets: parked, destroyed only by release_streams()
         self._torch_streams = set()
@@ -156,6 +159,19 @@ class HifiganGenerator:
         P["conv_post"] = PackedConv(ops.fold_weight_norm(sd, "conv_post"), sd.get("conv_post.bias"), dev)
         self._graph.clear()          # captured graphs hold raw pointers to the previous weight tensors
         self._packed = P
+
+    def _group_stage(self, i, ch, B, T, P):
+        """Can stage i's MRF run as grouped launches (ops.resblock_group)?  All branches ResBlock1 with the same dilation list,
+        fusable pairs of distinct kernel sizes from {3, 7, 11}, a small-grid shape, 2-3 branches."""
+        nk = self.num_kernels
+        dils = self.resblock_dilation_sizes[:nk]
+        if not (self.fuse_resblocks and ch in self.fuse_channels and 2 <= nk <= 3 and T % 4 == 0 and all(d == dils[0] for d in dils)):
+            return False
+        for m in range(len(dils[0])):
+            pairs = [(P["resblocks.%d.convs1.%d" % (i * nk + j, m)], P["resblocks.%d.convs2.%d" % (i * nk + j, m)]) for j in range(nk)]
+            if any(pc1.kernel > self.fuse_max_kernel.get(ch, 99) for pc1, _ in pairs) or not ops.resblock_group_supported(pairs, B, ch, T):
+                return False
+        return True
 
     def weight_bytes(self):
         return sum(p.nbytes() for p in self._packed.values())
@@ -255,6 +271,22 @@ class HifiganGenerator:
             # The MRF's resblocks are independent until their last conv (which chains the accumulate r1 + r2 + r3 in
             # the reference's order): each branch runs on its own HIP stream so that one branch's launch tail / ramp
             # overlaps another branch's compute; events order only the accumulating convs.
+            if self.group_branches and self.resblock_type == "1" and self._group_stage(i, ch, B, T, P):
+                # a single sentence (small grids): the stage's branches as ONE launch per iteration on this stream, their
+                # outputs averaged by one more (ttsamd_resblock_group, ttsamd_sum_div) — no branch streams, no joins
+                dil = self.resblock_dilation_sizes[0]
+                cur = [up] * nk
+                bufs = [(new(ch, T), new(ch, T)) for _ in range(nk)]
+                for m in range(len(dil)):
+                    pairs = [(P["resblocks.%d.convs1.%d" % (i * nk + j, m)], P["resblocks.%d.convs2.%d" % (i * nk + j, m)]) for j in range(nk)]
+                    dsts = [bufs[j][m & 1] for j in range(nk)]
+                    ops.resblock_group(pairs, cur, dsts, slope=LRELU_SLOPE, mask=msk)
+                    cur = dsts
+                if T % 4 == 0:
+                    ops.sum_div(cur, o_next, float(nk))
+                    o = o_next
+                    continue
+                raise _lib.TtsAmdError("grouped MRF stage with T % 4 != 0")     # _group_stage excludes it
             main = torch.cuda.current_stream()
             side = self._streams(nk) if concurrent and nk > 1 else None
             ev_up = torch.cuda.Event() if side else None

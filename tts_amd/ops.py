@@ -242,6 +242,43 @@ def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, a
     return y
 
 
+_GROUP_SLOT = {3: 0, 7: 1, 11: 2}
+
+
+def resblock_group_supported(pairs, B, C, T):
+    """True when `pairs` [(pc1, pc2), ...] — the MRF branches of one stage at one iteration — can run as ONE launch
+    (ttsamd_resblock_group): every pair fusable, kernel sizes distinct and from {3, 7, 11}, one dilation, a small-grid shape."""
+    ks = [pc1.kernel for pc1, _ in pairs]
+    return (1 < len(pairs) <= 3 and len(set(ks)) == len(ks) and all(k in _GROUP_SLOT for k in ks)
+            and len({pc1.dilation for pc1, _ in pairs}) == 1 and all(resblock_pair_supported(pc1, pc2) for pc1, pc2 in pairs)
+            and bool(lib().ttsamd_resblock_group_supported(C, T, B)))
+
+
+def resblock_group(pairs, xs, ys, *, slope, mask=None):
+    """ys[i] = ResBlock1 iteration `pairs[i]` of xs[i] (resblock_pair, no accumulate), all branches in one launch."""
+    arr = (ResblockArgs * 3)()
+    for (pc1, pc2), x, y in zip(pairs, xs, ys):
+        B, C, T = x.shape
+        assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and x.dtype == y.dtype == torch.float32
+        a = arr[_GROUP_SLOT[pc1.kernel]]
+        a.x, a.y, a.accum, a.mask = x.data_ptr(), y.data_ptr(), None, _dp(mask)
+        ws1, ws2 = (pc1.w_split, pc2.w_split) if C >= 32 else (pc1.w_split_pad32, pc2.w_split_pad32)
+        a.w1_split, a.bias1, a.w2_split, a.bias2 = ws1.data_ptr(), _dp(pc1.bias), ws2.data_ptr(), _dp(pc2.bias)
+        a.w1_bytes, a.w2_bytes = ws1.numel(), ws2.numel()
+        a.c, a.t, a.batch, a.kernel, a.dilation = C, T, B, pc1.kernel, pc1.dilation
+        a.slope, a.out_div, a.variant = slope, 0.0, 0
+    check(lib().ttsamd_resblock_group(arr, stream_ptr()), "resblock_group")
+    return ys
+
+
+def sum_div(srcs, y, div):
+    """y = ((srcs[0] + srcs[1]) [+ srcs[2]]) / div — the MRF average over separately written branch outputs."""
+    assert 2 <= len(srcs) <= 3 and all(t.is_contiguous() and t.shape == y.shape for t in srcs) and y.is_contiguous()
+    check(lib().ttsamd_sum_div(P(y), P(srcs[0]), P(srcs[1]), P(srcs[2]) if len(srcs) > 2 else None, ctypes.c_float(div),
+                               ctypes.c_int64(y.numel()), stream_ptr()), "sum_div")
+    return y
+
+
 def fold_weight_norm(sd, name):
     """Effective conv weight from a reference-layout state_dict entry: plain `.weight`, torch>=2.1
     parametrizations (`original0`=g, `original1`=v) or legacy `weight_g/weight_v`.
