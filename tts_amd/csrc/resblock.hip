@@ -80,7 +80,7 @@ extern "C" int ttsamd_resblock_group(const ttsamd_resblock_args *args3, void *st
     TTSAMD_CHECK_ARG(first->c > 0 && first->t >= 0 && first->batch >= 0, "resblock_group: bad shape");
     if (first->batch == 0 || first->t == 0) return TTSAMD_OK;
     if (!ttsamd_resblock_group_supported(first->c, first->t, first->batch)) {
-        set_error("resblock_group: c=%d, t=%d, batch=%d is not a small-grid shape (ttsamd_resblock_group_supported): launch the pairs one by one",
+        set_error("resblock_group: c=%d, t=%d, batch=%d is outside the grouped range (ttsamd_resblock_group_supported): launch the pairs one by one",
                   first->c, first->t, first->batch);
         return TTSAMD_ERR_UNSUPPORTED;
     }

@@ -443,7 +443,8 @@ int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
     return TTSAMD_ERR_UNSUPPORTED;
 }
 
-// small-grid tile of a channel count (the narrow tiles of resblock_pair_launch_kd): the grouped launch exists for these only
+// Grouped launches exist for the narrow small-grid tiles of resblock_pair_launch_kd (a single sentence).  One utterance's 64- /
+// 32-channel stages (100-200 k columns, the default 4-wave tiles) were measured too: B = 1 request 4.74 -> 4.79 ms, not kept.
 inline bool resblock_group_small(int c, long cols)
 {
     return ((c == 8 || c == 16) && cols <= 512 * 236) || (c == 32 && cols <= 128 * 236) || (c == 64 && cols <= 64 * 118);
