@@ -176,7 +176,7 @@ def code_stamp():
     h = hashlib.sha256()
     for d in ("tts_amd/csrc", "include"):
         for f in sorted(os.listdir(os.path.join(ROOT, d))):
-            if f.endswith((".hip", ".h")):
+            if f.endswith((".hip", ".h", ".inc")):
                 src = open(os.path.join(ROOT, d, f), "r", encoding="utf-8", errors="replace").read()
                 src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
                 src = re.sub(r"//[^\n]*", "", src)

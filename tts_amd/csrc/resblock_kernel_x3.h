@@ -116,255 +116,22 @@ static __device__ long long g_res_clk[16];     // one per translation unit (no r
 
 typedef const ttsamd_resblock_args __attribute__((address_space(4))) *ResArgsKernargPtr;
 
-// The block's work.  `a`: the pair's arguments (a kernel parameter of the caller), `ep`: the same struct inside the kernarg
-// segment (the epilogue re-reads its arguments from there, see below), `tile`: (time tile, -, batch item) of this block.
-template <int K, int D, int C, int WM, int WN, int NI>
-__device__ __forceinline__ void resblock_pair_body(const ttsamd_resblock_args &a, ResArgsKernargPtr ep, const ConvTile tile)
-{
-#ifdef TTSAMD_PHASE_CLOCKS
-    const bool stamp = threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.z == gridDim.z / 2;
-#endif
-    RES_STAMP(0);
-    using G = ResGeom<K, D, C, WM, WN, NI>;
-    constexpr int MI = G::kMI;
-    constexpr int NCH = G::kNCh;
-    extern __shared__ __attribute__((aligned(16))) unsigned char rs3[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int h = lane >> 5;
-    const int j = lane & 31;
-    const int b = tile.b;
-    const int t0 = tile.nb * G::kBN;      // first output column of this block
-    const int T = a.t;
-    constexpr int kOob = kConvOob;
-
-    // a.c may be smaller than the instantiation's C (HiFiGAN-v2's 16- and 8-channel stages run on the C = 32 kernel with
-    // zero-padded weight images): every tensor is addressed with the REAL channel count, rows beyond it read as zeros
-    // through the buffer range check and their stores are dropped by it
-    const int creal = a.c;
-    const long slab = (long)creal * T * 4;    // one item's [c, T] tensor (contiguous rows)
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * creal * T, slab);
-    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(a.mask ? a.mask + (long)b * T : nullptr, a.mask ? (long)T * 4 : 0);
-    const bool has_mask = a.mask != nullptr;
-
-    // ---- stage the x tile: columns [t0 - H2 - H1, +kXW) of all C channels, leaky-ReLU'd and split, into LDS ----------
-    {
-        const int tx0 = t0 - G::kH2 - G::kH1;
-        const int row_bytes = T * 4;
-        constexpr int kBatch = G::kRounds < 6 ? G::kRounds : 6;   // rounds whose loads are in flight together (8 dwords each)
-#pragma unroll 1
-        for (int r0 = 0; r0 < G::kRounds; r0 += kBatch) {
-            float st[kBatch][8];
-            float sm[kBatch];
-#pragma unroll
-            for (int rr = 0; rr < kBatch; ++rr) {
-                const int e = tid + (r0 + rr) * G::kThreads;
-                const int pl = e / G::kXW;                 // chunk * 2 + half
-                const int col = e - pl * G::kXW;
-                const int gt = tx0 + col;
-                const bool ok = (e < G::kItems) && (gt >= 0) && (gt < T);
-                const int off = ok ? (pl * 8 * row_bytes + gt * 4) : kOob;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off == kOob ? kOob : off + i * row_bytes, 0);
-                sm[rr] = has_mask ? ld_buf(rmask, ok ? gt * 4 : kOob, 0) : 1.f;
-            }
-#pragma unroll
-            for (int rr = 0; rr < kBatch; ++rr) {
-                const int e = tid + (r0 + rr) * G::kThreads;
-                const int pl = e / G::kXW;
-                const int col = e - pl * G::kXW;
-                if (e < G::kItems) {
-                    // two values per conversion instruction, parts stay packed (conv_split3x2: the same round-to-nearest-even
-                    // conversions and exact residuals as conv_split3, bit for bit)
-                    unsigned pw[3][4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        conv_split3x2(conv_lrelu(st[rr][2 * i] * sm[rr], a.slope), conv_lrelu(st[rr][2 * i + 1] * sm[rr], a.slope),
-                                      pw[0][i], pw[1][i], pw[2][i]);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        u32x4 w;
-                        w.x = pw[q][0];
-                        w.y = pw[q][1];
-                        w.z = pw[q][2];
-                        w.w = pw[q][3];
-                        *reinterpret_cast<u32x4 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneX + col * 16) = w;
-                    }
-                }
-            }
-        }
-    }
-
-    RES_STAMP(1);
-    // ---- conv1 ------------------------------------------------------------------------------------------------------
-    const u32x4 *wp1[MI], *wp2[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const long mtile = (long)wm * MI + mi;
-        wp1[mi] = reinterpret_cast<const u32x4 *>(a.w1_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
-        wp2[mi] = reinterpret_cast<const u32x4 *>(a.w2_split) + mtile * ((long)NCH * K * 3 * 64) + lane;
-    }
-    u32x4 a_cur[MI][3], a_n1[MI][3];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            a_cur[mi][q] = wp1[mi][q * 64];
-            a_n1[mi][q] = wp1[mi][(3 + q) * 64];
-        }
-
-    // conv2's accumulators start from the residual x — the tile's own columns, requested NOW: the lines were fetched for
-    // the staging pass microseconds ago (L2 hits; requested after conv1 they had been evicted: PMC fetch 2.1x the tensor)
-    // and their latency hides behind conv1's main loop
-    f32x16 acc2[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row0 = (wm * MI + mi) * 32;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int o = (wn * NI + ni) * 32 + j;
-            const int t = t0 + o;
-            const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-        }
-    }
-    // operands of the mid epilogue, requested here so that their latency hides behind conv1's main loop
-    float mk[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int t = t0 - G::kH2 + (wn * NI + ni) * 32 + j;      // time of this lane's mid column
-        const bool ok = (t >= 0) && (t < T);                      // outside the tensor conv2 sees its zero padding
-        mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
-    }
-    // biases through buffer resources: an absent bias is a zero-length resource (reads 0) — no branch per element
-    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(a.bias1, a.bias1 ? creal * 4 : 0);
-    const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(a.bias2, a.bias2 ? creal * 4 : 0);
-    float bia[MI][16];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bia[mi][r] = ld_buf(rb1, 16 * h, ((wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2)) * 4);
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    __syncthreads();
-    RES_STAMP(2);
-    res_conv_mainloop<K, D, MI, NI, NCH, G::kPlaneX>(acc, wp1, a_cur, a_n1, rs3 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
-    RES_STAMP(3);
-
-    // conv2's first weight fragments: requested before the mid epilogue so that their latency hides behind it
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            a_cur[mi][q] = wp2[mi][q * 64];
-            a_n1[mi][q] = wp2[mi][(3 + q) * 64];
-        }
-
-    // ---- mid epilogue: (acc + bias1) * mask -> leaky ReLU -> 3-way split -> LDS (same bytes as the x tile) ------------
-    {
-        __syncthreads();                                               // every wave is done reading the x tile
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int col = (wn * NI + ni) * 32 + j;
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    unsigned pw[3][2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float v0 = (acc[mi][ni][rg * 4 + 2 * i] + bia[mi][rg * 4 + 2 * i]) * mk[ni];
-                        const float v1 = (acc[mi][ni][rg * 4 + 2 * i + 1] + bia[mi][rg * 4 + 2 * i + 1]) * mk[ni];
-                        conv_split3x2(conv_lrelu(v0, a.slope), conv_lrelu(v1, a.slope), pw[0][i], pw[1][i], pw[2][i]);
-                    }
-                    // rows 8*rg + 4*h + i of m-tile (wm*MI + mi): chunk 2*mtile + rg/2, 8-channel half rg%2, channels 4h..4h+3
-                    const int pl = (2 * (wm * MI + mi) + (rg >> 1)) * 2 + (rg & 1);
-                    if (2 * (wm * MI + mi) + (rg >> 1) >= NCH) continue;     // C = 16: rows 16..31 of the tile are padding
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        u32x2 w;
-                        w.x = pw[q][0];
-                        w.y = pw[q][1];
-                        *reinterpret_cast<u32x2 *>(rs3 + (q * (NCH * 2) + pl) * G::kPlaneM + col * 16 + h * 8) = w;
-                    }
-                }
-            }
-    }
-
-    // ---- conv2 (its accumulators hold the residual x, requested before conv1) ---------------------------------------------
-    float bia2[MI][16];      // output bias: requested ahead of conv2's main loop
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bia2[mi][r] = ld_buf(rb2, 16 * h, ((wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2)) * 4);
-    RES_STAMP(4);
-    __syncthreads();                                                   // the mid tile is complete
-    RES_STAMP(5);
-    res_conv_mainloop<K, 1, MI, NI, NCH, G::kPlaneM>(acc2, wp2, a_cur, a_n1, rs3 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
-    RES_STAMP(6);
-
-    // ---- output epilogue: + bias2 (+ accum) (/ div) -------------------------------------------------------------------
-    {
-        asm volatile("" : "+s"(ep) : : "memory");
-        const float out_div = ep->out_div;
-        const bool has_accum = ep->accum != nullptr;
-        const __amdgpu_buffer_rsrc_t ry = make_rsrc(ep->y + (long)b * creal * T, slab);
-        const __amdgpu_buffer_rsrc_t racc = make_rsrc(has_accum ? ep->accum + (long)b * creal * T : nullptr, has_accum ? slab : 0);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int row0 = (wm * MI + mi) * 32;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                __builtin_amdgcn_sched_barrier(0);
-                const int o = (wn * NI + ni) * 32 + j;
-                const int t = t0 + o;
-                const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-                // every optional pass behind ONE wave-uniform branch (inside the element loop hipcc evaluates the IEEE division
-                // sequence for every element of every launch and selects afterwards); operations and their order are those of
-                // the unfused conv epilogue
-                float vout[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    vout[r] = acc2[mi][ni][r] + bia2[mi][r];
-                    vout[r] += 0.f;              // (the unfused epilogue's absent-operand add: keeps -0.0 handling identical)
-                }
-                if (has_accum) {
-                    float e2[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) vout[r] = e2[r] + vout[r];
-                }
-                if (out_div != 0.f) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) vout[r] = vout[r] / out_div;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st_buf(ry, vout[r], vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-            }
-        }
-    }
-    RES_STAMP(7);
-#ifdef TTSAMD_PHASE_CLOCKS
-    __builtin_amdgcn_s_waitcnt(0);
-#endif
-    RES_STAMP(8);
-}
-
 template <int K, int D, int C, int WM, int WN, int NI>
 __global__ __launch_bounds__(64 * WM * WN, (ResGeom<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_x3_kernel(const ttsamd_resblock_args a)
 {
-    resblock_pair_body<K, D, C, WM, WN, NI>(a, (ResArgsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr(), conv_tile_of_block());
+    const ConvTile tile = conv_tile_of_block();
+#define RES_KERNARG_SLOT 0
+#include "resblock_body.inc"
+#undef RES_KERNARG_SLOT
+}
+
+// the same body as a function of the kernarg slot, for the grouped kernel below
+template <int K, int D, int C, int WM, int WN, int NI, int SLOT>
+__device__ __forceinline__ void resblock_pair_body(const ttsamd_resblock_args &a, const ConvTile tile)
+{
+#define RES_KERNARG_SLOT SLOT
+#include "resblock_body.inc"
+#undef RES_KERNARG_SLOT
 }
 
 // The MRF's three branches (kernel sizes 3, 7, 11 — slot 0, 1, 2; a slot with x == NULL is absent) at one dilation as ONE launch:
@@ -378,15 +145,14 @@ struct ResGroupArgs {
 template <int D, int C, int WM, int WN, int NI>
 __global__ __launch_bounds__(64 * WM * WN, (ResGeom<11, D, C, WM, WN, NI>::kOcc)) void resblock_group_x3_kernel(const ResGroupArgs g)
 {
-    const ResArgsKernargPtr ep = (ResArgsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const ConvTile tile{(int)blockIdx.x, 0, (int)blockIdx.z};
     const int br = blockIdx.y;
     if (br == 0) {
-        if (g.br[0].x && tile.nb * ResGeom<3, D, C, WM, WN, NI>::kBN < g.br[0].t) resblock_pair_body<3, D, C, WM, WN, NI>(g.br[0], ep, tile);
+        if (g.br[0].x && tile.nb * ResGeom<3, D, C, WM, WN, NI>::kBN < g.br[0].t) resblock_pair_body<3, D, C, WM, WN, NI, 0>(g.br[0], tile);
     } else if (br == 1) {
-        if (g.br[1].x && tile.nb * ResGeom<7, D, C, WM, WN, NI>::kBN < g.br[1].t) resblock_pair_body<7, D, C, WM, WN, NI>(g.br[1], ep + 1, tile);
+        if (g.br[1].x && tile.nb * ResGeom<7, D, C, WM, WN, NI>::kBN < g.br[1].t) resblock_pair_body<7, D, C, WM, WN, NI, 1>(g.br[1], tile);
     } else {
-        if (g.br[2].x && tile.nb * ResGeom<11, D, C, WM, WN, NI>::kBN < g.br[2].t) resblock_pair_body<11, D, C, WM, WN, NI>(g.br[2], ep + 2, tile);
+        if (g.br[2].x && tile.nb * ResGeom<11, D, C, WM, WN, NI>::kBN < g.br[2].t) resblock_pair_body<11, D, C, WM, WN, NI, 2>(g.br[2], tile);
     }
 }
 
