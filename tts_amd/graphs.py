@@ -9,6 +9,7 @@ the allocator cache — which also stalls the other request lane), and real traf
 every request.  So a shape is captured only once it has been seen `capture_after` times; until then — and whenever
 capture fails — the segment runs as eager launches."""
 import collections
+import gc
 
 import torch
 
@@ -48,8 +49,19 @@ class GraphedSegment:
                 fn(*self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            self.static_out = fn(*self.static_in)
+        # No garbage collection inside the capture: finalisers of cyclic garbage left by earlier requests (a dropped model's
+        # graphs, streams, events) call HIP, and under global capture mode an unsafe call from this thread aborts the process
+        # from inside a C++ destructor (seen once in eight full test runs: "Fatal Python error: Aborted", GC running under
+        # torch.cuda.current_stream() in the middle of a capture).  torch.cuda.graph() itself no longer collects on entry.
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph, stream=side):
+                self.static_out = fn(*self.static_in)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
 
     def __call__(self, *inputs):
         if len(self.copied) == 1:
