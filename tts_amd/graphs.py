@@ -57,7 +57,9 @@ class GraphedSegment:
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(self.graph, stream=side):
+            # thread_local: only this thread's calls are policed while it captures — another host thread (a second serving
+            # thread, a data loader) may allocate or synchronise meanwhile without invalidating the capture
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.static_out = fn(*self.static_in)
         finally:
             if gc_was_enabled:
