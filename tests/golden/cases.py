@@ -27,6 +27,28 @@ def hifigan_small(impl, rb="1"):
     return {"wav": o}
 
 
+HIFIGAN_UNTUNED = dict(W.HIFIGAN_V1, upsample_initial_channel=64, resblock_kernel_sizes=[5, 9, 3],
+                       resblock_dilation_sizes=[[1, 2, 4], [2, 6, 3], [3, 12, 1]], upsample_factors=[3, 2, 4, 2], upsample_kernel_sizes=[7, 4, 4, 6])
+
+
+def hifigan_untuned(impl):
+    """A generator outside every released config (hifigan_generator.py:199-233 accepts any): ResBlock kernels 5 / 9 / 3 at the dilations
+    (1,2,4) (2,6,3) (3,12,1) (ResBlock1 takes exactly three: hifigan_generator.py:36-66), upsampling (stride, kernel) = (3,7) (2,4) (4,4) (2,6) — the padding rules `(k - u) // 2` / `get_padding` at
+    sizes the default configs never reach.  The GPU path runs this config on the generic conv / polyphase fallback
+    (tests/test_hifigan_gpu.py) against the oracle; this case pins the oracle itself to the reference module."""
+    cfg = dict(HIFIGAN_UNTUNED)
+    sd = O.make_hifigan_state(cfg, 80, seed=29)
+    x = torch.randn(2, 80, 33, generator=_g(2))
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        with torch.no_grad():
+            o = RM.hifigan(sd, cfg, 80).inference(x)
+    else:
+        o = O.hifigan_inference(sd, "", x, cfg)
+    return {"wav": o}
+
+
 VITS_SMALL = dict(upsample_initial_channel_decoder=64)
 
 
@@ -176,6 +198,7 @@ def glow_small_speaker(impl, mode):
 CASES = {
     "hifigan_small_rb1": lambda impl: hifigan_small(impl, "1"),
     "hifigan_small_rb2": lambda impl: hifigan_small(impl, "2"),
+    "hifigan_untuned": hifigan_untuned,
     "vits_small_sdp": lambda impl: vits_small(impl, True),
     "vits_small_dp": lambda impl: vits_small(impl, False),
     "vits_small_spk_emb": lambda impl: vits_small_speaker(impl, "emb"),

@@ -203,12 +203,13 @@ def test_single_item_inference_graph_equals_eager(gpu):
 
 
 def test_hifigan_with_untuned_kernel_sizes_dilations_and_upsamplers(gpu):
-    """A generator no default config describes — ResBlock kernels 5 / 9 / 3 at dilations (1,2) (2,6) (3,12), upsampling
+    """A generator no default config describes — ResBlock kernels 5 / 9 / 3 at dilations (1,2,4) (2,6,3) (3,12,1), upsampling
     (stride, kernel) = (3,7) (2,4) (4,4) (2,6) — takes the generic conv / polyphase ConvTranspose fallback wherever there is no
     tuned instantiation (ResBlock pairs stay unfused there) and matches the oracle (hifigan_generator.py:199-233 accepts any)."""
     torch.set_num_threads(8)
     cfg = dict(W.HIFIGAN_V1, upsample_initial_channel=64, resblock_kernel_sizes=[5, 9, 3],
-               resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]], upsample_factors=[3, 2, 4, 2], upsample_kernel_sizes=[7, 4, 4, 6])
+               resblock_dilation_sizes=[[1, 2, 4], [2, 6, 3], [3, 12, 1]], upsample_factors=[3, 2, 4, 2], upsample_kernel_sizes=[7, 4, 4, 6])
+    # (the same config as tests/golden/cases.py: hifigan_untuned, where the oracle is pinned to the reference module)
     sd = O.make_hifigan_state(cfg, 80, seed=29)
     x = torch.randn(2, 80, 33, generator=torch.Generator().manual_seed(2))
     want = O.hifigan_inference(sd, "", x, cfg)
@@ -216,6 +217,14 @@ def test_hifigan_with_untuned_kernel_sizes_dilations_and_upsamplers(gpu):
     got = m.inference(x.to(gpu))
     assert got.shape == want.shape == (2, 1, (33 + 10) * 48)
     rms, rel = _errs(got, want)
+    assert rms < 1e-4 and rel < 1e-5, (rms, rel)
+    # ... and the REFERENCE module's own output for this config (tests/golden/hifigan_untuned.npz, made by make_golden.py)
+    import os
+
+    import numpy as np
+
+    ref = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", "hifigan_untuned.npz"))["wav"])
+    rms, rel = _errs(got, ref)
     assert rms < 1e-4 and rel < 1e-5, (rms, rel)
     # ragged-exact rows of a batch equal their own single runs here too (k - stride is even for every stage)
     lens = torch.tensor([33, 21])
