@@ -280,3 +280,59 @@ def test_text_bucket_outputs_are_cut_back_to_the_callers_token_count():
     assert out["alignments"].shape == (2, F, T0) and out["durations"].shape == (2, 1, T0)
     assert out["durations_log"].shape == (2, T0, 1) and out["total_durations_log"].shape == (2, T0, 1)
     assert out["model_outputs"].shape == (2, F, 80)
+
+
+def test_polyphase_transposed_conv_weights_reproduce_conv_transpose1d():
+    """`ops.convt_polyphase_weight` (the load-time transform behind every ConvTranspose1d of the vocoder): for ANY (kernel,
+    stride) the J = ceil(k / stride)-tap Conv1d over the packed rows m = co*stride + r, followed by the SHUFFLE epilogue's
+    index map n = q*stride + r - pad, is torch's conv_transpose1d (hifigan_generator.py:209-219: padding (k - u) // 2) —
+    emulated here with plain CPU ops, sample for sample, including odd k - u (output one sample longer than T*u)."""
+    import torch
+    import torch.nn.functional as F
+
+    from tts_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    for k, u, cin, cout, T in ((16, 8, 6, 4, 11), (4, 2, 5, 3, 9), (7, 3, 4, 2, 10), (4, 4, 3, 2, 7), (6, 4, 2, 3, 8), (5, 2, 3, 2, 6),
+                               (11, 4, 2, 1, 9), (5, 5, 2, 2, 5)):
+        wt = torch.randn(cin, cout, k, generator=g, dtype=torch.float64)
+        b = torch.randn(cout, generator=g, dtype=torch.float64)
+        x = torch.randn(2, cin, T, generator=g, dtype=torch.float64)
+        pad = (k - u) // 2
+        want = F.conv_transpose1d(x, wt, b, stride=u, padding=pad)
+        wp, bp = ops.convt_polyphase_weight(wt, b, u)
+        J = wp.shape[2]
+        assert wp.shape == (cout * u, cin, J) and J == -(-k // u)
+        # the Conv1d the kernel runs: pad_left = J - 1, t_out = T + J - 1 columns q
+        y = F.conv1d(F.pad(x, (J - 1, J - 1)), wp, bp)                        # [B, cout*u, T + J - 1]
+        t_up = (T - 1) * u - 2 * pad + k
+        out = torch.zeros(2, cout, t_up, dtype=torch.float64)
+        hit = torch.zeros(t_up, dtype=torch.int64)
+        for q in range(T + J - 1):
+            for r in range(u):
+                n = q * u + r - pad                                           # the SHUFFLE epilogue's sample index
+                if 0 <= n < t_up:
+                    out[:, :, n] = y[:, [co * u + r for co in range(cout)], q]
+                    hit[n] += 1
+        assert int(hit.min()) == 1 and int(hit.max()) == 1, (k, u)            # every output sample written exactly once
+        assert torch.allclose(out, want, rtol=0, atol=1e-12), (k, u)
+
+
+def test_paired_row_order_of_abi_v2():
+    """`ops.pair_index` / `pair_permute` / `gate_permute`: packed 32-row tile m = first halves of output channels [16m, 16m+16)
+    then their second halves (include/tts_amd.h, ABI v2), zero rows padding a partial last tile."""
+    import torch
+
+    from tts_amd import ops
+
+    assert ops.PAIR_ROWS == 16
+    idx = ops.pair_index(40, 40)
+    assert len(idx) == 96 and idx[:16] == list(range(16)) and idx[16:32] == list(range(40, 56))
+    assert idx[64:72] == list(range(32, 40)) and idx[72:80] == [-1] * 8 and idx[80:88] == list(range(72, 80)) and idx[88:] == [-1] * 8
+    w = torch.arange(80 * 3 * 2, dtype=torch.float32).reshape(80, 3, 2)
+    b = torch.arange(80, dtype=torch.float32)
+    wp, bp = ops.gate_permute(w, b, 40)
+    assert wp.shape == (96, 3, 2) and torch.equal(wp[16], w[40]) and torch.equal(wp[79], torch.zeros(3, 2)) and float(bp[80]) == 72.0
+    # an affine coupling whose second operand does not start at n (Glow: t rows [0, half), s rows [half, 2*half))
+    wq, _ = ops.pair_permute(w, None, 24, 24)
+    assert wq.shape == (64, 3, 2) and torch.equal(wq[39], w[23]) and torch.equal(wq[40], torch.zeros(3, 2)) and torch.equal(wq[48], w[40])
