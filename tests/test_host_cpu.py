@@ -336,3 +336,63 @@ def test_paired_row_order_of_abi_v2():
     # an affine coupling whose second operand does not start at n (Glow: t rows [0, half), s rows [half, 2*half))
     wq, _ = ops.pair_permute(w, None, 24, 24)
     assert wq.shape == (64, 3, 2) and torch.equal(wq[39], w[23]) and torch.equal(wq[40], torch.zeros(3, 2)) and torch.equal(wq[48], w[40])
+
+
+def test_graph_cache_policy_without_a_gpu(monkeypatch):
+    """tts_amd.graphs.GraphCache's bookkeeping with the capture itself mocked out: a shape runs eagerly until it has been seen
+    `capture_after` times (hits are counted per SHAPE, not per input address), entries are keyed by stream + shape + the
+    addresses of the in-place (`stable`) inputs, the least recently used entry is released and evicted, a failed capture turns
+    the shape eager for good, purge_stream drops one lane's graphs only, and the collector is off inside a capture."""
+    import gc
+    import types
+
+    import torch
+
+    from tts_amd import graphs, parallel
+
+    cur = types.SimpleNamespace(cuda_stream=1234)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: cur)
+    monkeypatch.setattr(parallel, "active_lanes", lambda: 1)
+    log = []
+
+    class FakeSegment:
+        def __init__(self, fn, inputs, stable=()):
+            if inputs[0].shape[-1] == 13:
+                raise RuntimeError("capture failed")
+            self.fn, self.stable = fn, stable
+            log.append(("capture", tuple(inputs[0].shape)))
+
+        def __call__(self, *inputs):
+            return ("replay",) + tuple(self.fn(*inputs))
+
+        def release(self):
+            log.append(("release",))
+
+    monkeypatch.setattr(graphs, "GraphedSegment", FakeSegment)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    c = graphs.GraphCache(lambda *xs: ("eager", xs[0].shape[-1]), max_entries=2, capture_after=2)
+    a, b = torch.zeros(1, 5), torch.zeros(1, 5)                       # same shape, different addresses
+    assert c(a) == ("eager", 5) and not c.last_static                  # first sighting: eager
+    assert c(b, stable=(0,))[0] == "replay" and c.last_static          # second sighting of the SHAPE: captured (for b's address)
+    assert c(a, stable=(0,))[0] == "replay" and len(c.entries) == 2    # another address of a hot shape: its own capture at once
+    assert c.stats["captures"] == 2 and c.stats["eager"] == 1
+    x7 = torch.zeros(1, 7)
+    c(x7)
+    c(x7)                                                              # third entry: the least recently used one goes
+    assert ("release",) in log and len(c.entries) == 2 and c.stats["evictions"] == 1
+    x13 = torch.zeros(1, 13)
+    c(x13)
+    assert c(x13) == ("eager", 13) and c.stats["capture_failures"] == 1
+    assert c(x13) == ("eager", 13) and c.stats["capture_failures"] == 1   # not tried again
+    cur.cuda_stream = 99                                                # another lane
+    y = torch.zeros(1, 7)
+    c(y)
+    c(y)
+    assert sum(1 for k in c.entries if k[1] == 99) == 1
+    c.purge_stream(99)
+    assert all(k[1] != 99 for k in c.entries) and len(c.entries) == 1
+    c.enabled = False
+    assert c(x7) == ("eager", 7)
+    c.clear()
+    assert not c.entries and not c.hits and not c.failed
+    assert gc.isenabled()
