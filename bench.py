@@ -47,18 +47,28 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
 PEAK_HBM_GBPS = 8000.0          # same guide: HBM3E spec peak (a float4 copy reaches 6.29 TB/s)
 X3_PRODUCTS = 6                 # bf16 MFMA products issued per fp32 product by the split-bf16 kernels (conv_kernel_x3.h)
-DTYPE = {"x3": "f32 (conv products: fp32 operands split 3-way into bf16, 6 bf16-MFMA products each, fp32 accumulate)",
+H2_PRODUCTS = 3                 # fp16 MFMA products per fp32 product of the two-part fp16 kernels (conv_kernel_h2.h); same dense peak
+DTYPE = {"h2": "f32 (conv products of the large-grid launches: fp32 operands split 2-way into fp16 with exact power-of-two "
+               "pre-scales, 3 fp16-MFMA products each in two fp32 accumulators; small-grid launches: the 3-way bf16 / 6-product split)",
+         "x3": "f32 (conv products: fp32 operands split 3-way into bf16, 6 bf16-MFMA products each, fp32 accumulate)",
          "f32": "f32"}
+PRODUCTS = {"h2": H2_PRODUCTS, "x3": X3_PRODUCTS}
 
 
 def conv_peak(precision):
-    """Peak the conv kernels are priced against, in ALGORITHMIC (fp32-equivalent) TFLOP/s: the split-bf16 kernels issue
-    six bf16 MFMA products per fp32 product, so their ceiling is the bf16 dense peak / 6."""
-    return PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if precision == "x3" else PEAK_FP32_MFMA_TFLOPS
+    """Peak the conv kernels are priced against, in ALGORITHMIC (fp32-equivalent) TFLOP/s: the split kernels issue three
+    (two-part fp16) or six (three-part bf16) 16-bit MFMA products per fp32 product, so their ceiling is the 16-bit dense peak
+    divided by that."""
+    return PEAK_BF16_MFMA_TFLOPS / PRODUCTS[precision] if precision in PRODUCTS else PEAK_FP32_MFMA_TFLOPS
 
 
 def conv_kernel_name(precision, tmpl):
-    return ("ttsamd::conv1d_x3_kernel<%s>" if precision == "x3" else "ttsamd::conv1d_mfma_kernel<%s>") % tmpl
+    return {"h2": "ttsamd::conv1d_h2_kernel<%s>", "x3": "ttsamd::conv1d_x3_kernel<%s>"}.get(precision, "ttsamd::conv1d_mfma_kernel<%s>") % tmpl
+
+
+# dominant kernel instantiation of the headline step per precision: template arguments and the substring its dispatches carry
+DOMINANT_TMPL = {"h2": "11,1,1,4,4,1,0", "x3": "11,1,1,4,4,1,0", "f32": "11,1,2,2,2,2,0"}
+DOMINANT_SUB = {"h2": "conv1d_h2_kernel<11,1,1,4,4,1,0>", "x3": "conv1d_x3_kernel<11,1,1,4,4,1,0,", "f32": "conv1d_mfma_kernel<11,1,2,2,2,2,0>"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -456,14 +466,12 @@ def wl_vits_e2e(args, ctx):
     line["rtf_x"] = value / SAMPLE_RATE
     line["rtf_x_per_gpu"] = value / SAMPLE_RATE / ctx.world
     pmc = "pmc_dominant_%s.json" % args.precision
-    kern_tmpl = "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0"
     live_traffic, live_note = (None, "skipped (--no-live-pmc)")
     if ctx.world == 1 and not args.no_live_pmc:
-        live_traffic, live_note = pmc_traffic_live(args.precision, ("conv1d_x3_kernel<%s," if args.precision == "x3" else
-                                                                    "conv1d_mfma_kernel<%s,") % kern_tmpl)
+        live_traffic, live_note = pmc_traffic_live(args.precision, DOMINANT_SUB[args.precision])
     line["roofline"] = {
         "bound": "mfma",
-        "kernel": conv_kernel_name(args.precision, "11,1,1,4,4,1,0" if args.precision == "x3" else "11,1,2,2,2,2,0")
+        "kernel": conv_kernel_name(args.precision, DOMINANT_TMPL[args.precision])
                   + " (ResBlock1 k=11 d=1 convs, 256->256 and 128->128)",
         "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
         "frac": ach / conv_peak(args.precision),
@@ -475,9 +483,9 @@ def wl_vits_e2e(args, ctx):
         "traffic_source": live_note if live_traffic is not None else (pmc_state(pmc) + "; live pass: " + live_note),
         # from the same PMC passes: fraction of kernel cycles the matrix pipe is busy and the kernel's cycle count
         "pmc_mfma_busy_frac": load_pmc(pmc, "mfma_busy_frac"), "pmc_kernel_cycles": load_pmc(pmc, "kernel_cycles"),
-        "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B) / HIP-event launch time; peak = bf16 dense MFMA "
-                      "2500 TF / 6 bf16 products per fp32 product; on the pipe: %.0f of 2500 bf16 TF" % (ach * X3_PRODUCTS))
-                     if args.precision == "x3" else "fp32-input MFMA peak (= fp32 vector peak); exact fp32 arithmetic",
+        "peak_note": ("algorithmic fp32 FLOP (2*c_out*c_in*k*t_out*B) / HIP-event launch time; peak = 16-bit dense MFMA "
+                      "2500 TF / %d products per fp32 product; on the pipe: %.0f of 2500 TF" % (PRODUCTS[args.precision], ach * PRODUCTS[args.precision]))
+                     if args.precision in PRODUCTS else "fp32-input MFMA peak (= fp32 vector peak); exact fp32 arithmetic",
         "launches_timed": dom["launches"], "avg_launch_us": dom["ms"] * 1e3 / max(dom["launches"], 1),
         "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
         "all_conv_launches": {"launches": allc["launches"],
@@ -934,9 +942,10 @@ def main():
                     help="run the MRF resblock branches on one stream (for rocprof: per-kernel durations are then not "
                          "inflated by co-running kernels; the roofline pass always runs this way; with two or more lanes the "
                          "generator does so by itself)")
-    ap.add_argument("--precision", default=None, choices=["x3", "f32"],
-                    help="conv arithmetic: x3 = split-bf16 kernels (default, fp32-class accuracy on the bf16 MFMA), "
-                         "f32 = fp32-input MFMA kernels (bitwise fmaf chain)")
+    ap.add_argument("--precision", default=None, choices=["h2", "x3", "f32"],
+                    help="conv arithmetic: h2 = two-part fp16 split, three MFMA products per fp32 product on the large-grid launches "
+                         "(default), x3 = split-bf16 kernels everywhere (six products), f32 = fp32-input MFMA kernels (bitwise "
+                         "fmaf chain); all fp32-class, same parity tolerances")
     ap.add_argument("--lanes", type=int, default=2,
                     help="vits_e2e: request lanes (HIP streams) per GPU used round-robin by the steps, so that the "
                          "latency-bound text front end of one batch overlaps the waveform decoder of the previous one "

@@ -158,6 +158,14 @@ typedef struct ttsamd_conv1d_args {
                             * both fp32 operands are split three ways into bf16 and the six leading products are
                             * accumulated in fp32 on the bf16 matrix pipe (every product is more accurate than one
                             * fp32 rounding of it); NULL = fp32-input MFMA kernels reading w_packed. */
+    const void *w_h2;      /* ABI v3: from ttsamd_conv1d_pack_weights_h2, or NULL.  Non-NULL (together with w_split) lets the
+                            * LARGE-GRID launches of the tuned (kernel, dilation) pairs run the three-product arithmetic: both fp32
+                            * operands split into two fp16 parts (hi + lo * 2^-11, 22 significand bits + sign), hi*hi in one fp32
+                            * accumulator, the two cross products in a second one that is scaled once in the epilogue; weights
+                            * carry one power-of-two exponent per packed row (in the image), activations one per staged tile
+                            * (derived in the kernel), both undone exactly.  fp32-class like the six-product scheme (error against
+                            * fp64 1-2e-7 of sum|w x| on adversarial operands) at half its matrix-pipe work.  Small-grid launches
+                            * (single requests) and the generic kernel keep the six-product split-bf16 arithmetic of w_split. */
 } ttsamd_conv1d_args;
 
 /* Dispatch notes: c_out == 1, kernel 7, dilation 1, NORMAL mode without residual / accumulate / masks on the output
@@ -175,6 +183,12 @@ int ttsamd_conv1d_pack_weights(float *dst, const float *w, int c_out, int c_in, 
  * groups of prefetch slack); part q of a weight = round-to-nearest bf16 of what parts < q left of it. */
 size_t ttsamd_conv1d_packed_split_bytes(int c_out, int c_in, int kernel);
 int ttsamd_conv1d_pack_weights_split(void *dst, const float *w, int c_out, int c_in, int kernel);
+/* Two-part fp16 weight image (see ttsamd_conv1d_args.w_h2): bytes, and the HOST-side repack
+ * w [c_out, c_in, kernel] fp32 -> [ceil(c_out/32)][ceil(c_in/16)][kernel][2 parts][64 lanes][8 fp16] (+ two zero groups of
+ * prefetch slack), then the row table: {int max_row_exp, 3 pad} and per packed row {float 2^e, float 2^-e}.  Row r is
+ * multiplied by 2^e_r (its largest magnitude lands in [2^13, 2^14)) before the split: hi = fp16(w 2^e), lo = fp16((w 2^e - hi) 2^11). */
+size_t ttsamd_conv1d_packed_h2_bytes(int c_out, int c_in, int kernel);
+int ttsamd_conv1d_pack_weights_h2(void *dst, const float *w, int c_out, int c_in, int kernel);
 /* 1 if ttsamd_conv1d takes this (kernel, dilation): any kernel <= 31 at any dilation <= 27.  ttsamd_conv1d_tuned: 1 for the pairs
  * with tuned template instantiations (k in {1,2,5} at d = 1; k in {3,7,11} at d in {1,3,5}; k = 3, d = 9); every other pair — and a
  * tuned pair in a mode it has no instantiation for — runs on a generic split-bf16 kernel (conv_generic.hip: one wave per 32x32
@@ -221,10 +235,18 @@ typedef struct ttsamd_resblock_args {
     int32_t variant;        /* 0 = default tile; other values select alternative tiles (measurement only) */
     int64_t w1_bytes, w2_bytes; /* ABI v2: size of each split image; must equal ttsamd_resblock_weight_bytes(c, kernel) — the
                                    kernel walks whole 32-channel tiles (c = 8 / 16: the image of the [32, 32, k] padded weight) */
+    const void *w1_h2, *w2_h2;  /* ABI v3: the two-part fp16 images of the same weights (ttsamd_conv1d_pack_weights_h2 of the [c, c, k]
+                                   — c < 32: zero-padded [32, 32, k] — weight), or NULL.  Both non-NULL: launches on the default tiles
+                                   run the three-product arithmetic of ttsamd_conv1d_args.w_h2 (one power-of-two exponent per block
+                                   for the x tile and one for the intermediate tile, derived in the kernel); results then agree with
+                                   the unfused pair to fp32 rounding level instead of bitwise.  The narrow small-grid tiles (single
+                                   sentences) and ttsamd_resblock_group keep the six-product images. */
+    int64_t w1_h2_bytes, w2_h2_bytes; /* must equal ttsamd_resblock_weight_h2_bytes(c, kernel) when the images are given */
 } ttsamd_resblock_args;
 /* bytes of the split-bf16 weight image ttsamd_resblock_pair reads for a c-channel pair (= ttsamd_conv1d_packed_split_bytes of
  * the [max(c,32), max(c,32), kernel] weight) */
 size_t ttsamd_resblock_weight_bytes(int c, int kernel);
+size_t ttsamd_resblock_weight_h2_bytes(int c, int kernel);   /* = ttsamd_conv1d_packed_h2_bytes of the [max(c,32), max(c,32), kernel] weight */
 int ttsamd_resblock_pair(const ttsamd_resblock_args *args /* host */, void *stream);
 int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
 /* The three branches of one MRF stage at one dilation — kernel sizes 3, 7, 11 in slots 0, 1, 2 of args3 (a slot with x == NULL is

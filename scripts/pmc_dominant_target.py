@@ -1,6 +1,6 @@
 """rocprofv3 --pmc target of bench.py's in-run traffic measurement: the dominant conv instantiation (ResBlock1 k = 11, d = 1:
 128 -> 128 at T = 49 280 and 256 -> 256 at T = 6 160, B = 32, leaky-ReLU in, residual in — the headline step's launches), one
-warm-up and two counted launches of each.   rocprofv3 --pmc FETCH_SIZE -- python scripts/pmc_dominant_target.py [x3|f32]"""
+warm-up and two counted launches of each.   rocprofv3 --pmc FETCH_SIZE -- python scripts/pmc_dominant_target.py [h2|x3|f32]"""
 import sys
 
 import torch

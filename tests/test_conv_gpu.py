@@ -11,13 +11,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-@pytest.fixture(params=["x3", "f32"], autouse=True)
+@pytest.fixture(params=["h2", "x3", "f32"], autouse=True)
 def conv_precision(request):
-    """Every conv test runs on both arithmetic paths: the split-bf16 kernels (default) and the fp32-input MFMA kernels,
-    at the SAME tolerance."""
+    """Every conv test runs on all three arithmetic paths at the SAME tolerance: the three-product two-part-fp16 kernels (default
+    for large grids; forced onto the small test shapes here by switching the small-grid tiles off — tests that sweep the small-grid
+    modes set them themselves), the six-product split-bf16 kernels, and the fp32-input MFMA kernels."""
     before = ops.conv_precision()
     ops.set_conv_precision(request.param)
+    was = ops.set_conv_small_grid(0) if request.param == "h2" else None
     yield request.param
+    if was is not None:
+        ops.set_conv_small_grid(was)
     ops.set_conv_precision(before)
 
 
@@ -258,6 +262,72 @@ def test_split_bf16_tiny_activations_flush_bound(gpu, conv_precision):
     xm[:, ::3] = x[:, ::3]                                       # a third of the channels tiny, the rest ordinary
     ops.conv1d(ops.PackedConv(w, None, gpu), xm.to(gpu), y)
     assert _rel(y, _conv64(xm, w, None, K, 1)) < TOL
+
+
+def test_h2_running_exponent_rescales_and_wide_range(gpu):
+    """Three-product kernels: (i) channel magnitudes growing by 2^20 over the reduction force the block's running activation
+    exponent to be renewed (accumulators rescaled) several times; (ii) a tile mixing magnitudes 1e-5 .. 1e2; (iii) weight rows
+    spanning 1e-2 .. 1e1 (weight-norm gains of a trained model) — all against an fp64 conv, relative to sum|w x| per output."""
+    was_p, was_g = ops.conv_precision(), ops.set_conv_small_grid(0)
+    ops.set_conv_precision("h2")
+    try:
+        rng = np.random.default_rng(5)
+        for name, C, K, T in (("growing", 256, 7, 300), ("shrinking", 256, 11, 200), ("wide", 128, 11, 300), ("gains", 128, 3, 500)):
+            x = torch.randn(2, C, T, generator=torch.Generator().manual_seed(C + K))
+            w = torch.randn(C, C, K, generator=torch.Generator().manual_seed(K)) / np.sqrt(C * K)
+            if name == "growing":
+                x = x * (2.0 ** (torch.arange(C).float() / C * 20.0 - 10.0))[None, :, None]
+            elif name == "shrinking":
+                x = x * (2.0 ** (10.0 - torch.arange(C).float() / C * 30.0))[None, :, None]
+            elif name == "wide":
+                x = torch.from_numpy((10.0 ** rng.uniform(-5, 2, (2, C, T)) * rng.choice([-1.0, 1.0], (2, C, T))).astype(np.float32))
+            else:
+                w = w * torch.from_numpy(10.0 ** rng.uniform(-2, 1, (C, 1, 1))).float()
+            res = torch.randn(2, C, T, generator=torch.Generator().manual_seed(3))
+            want = _conv64(x, w, None, K, 1) + res.double()
+            scale = _conv64(x.abs(), w.abs(), None, K, 1) + res.abs().double()
+            y = torch.empty(2, C, T, device=gpu)
+            ops.conv1d(ops.PackedConv(w, None, gpu), x.to(gpu), y, res=res.to(gpu))
+            err = float(((y.cpu().double() - want).abs() / scale).max())
+            print("%s: max |err| / (sum|wx| + |res|) = %.3e" % (name, err))
+            assert err < 2.0 ** -20, (name, err)
+    finally:
+        ops.set_conv_precision(was_p)
+        ops.set_conv_small_grid(was_g)
+
+
+def test_h2_residual_fold_guard_and_zero_chunks(gpu):
+    """Three-product kernels, corners of the scaling: tiny activations x tiny weights next to an ORDINARY residual (the residual
+    cannot be folded into accumulators whose unit is 2^-(activation + row exponent): the epilogue adds it instead); all-zero
+    leading chunks (masked / padded channels: exponent set by the first chunk with data); an all-zero input."""
+    was_p, was_g = ops.conv_precision(), ops.set_conv_small_grid(0)
+    ops.set_conv_precision("h2")
+    try:
+        C, K, T = 128, 7, 300
+        g = torch.Generator().manual_seed(9)
+        w = torch.randn(C, C, K, generator=g) / np.sqrt(C * K)
+        res = torch.randn(1, C, T, generator=g)
+        x = torch.randn(1, C, T, generator=g)
+        for name, xs, ws in (("tiny x tiny + ordinary residual", 1e-25, 1e-12), ("zero leading chunks", 1.0, 1.0), ("all zero", 0.0, 1.0)):
+            xx = x * xs
+            if name.startswith("zero"):
+                xx = xx.clone()
+                xx[:, :48] = 0.0
+            ww = w * ws
+            want = _conv64(xx, ww, None, K, 1) + res.double()
+            y = torch.empty(1, C, T, device=gpu)
+            ops.conv1d(ops.PackedConv(ww, None, gpu), xx.to(gpu), y, res=res.to(gpu))
+            assert torch.isfinite(y).all(), name
+            assert _rel(y, want) < TOL, name
+            y2 = torch.empty(1, C, T, device=gpu)            # the conv part alone keeps its own relative accuracy
+            ops.conv1d(ops.PackedConv(ww, None, gpu), xx.to(gpu), y2)
+            if xs:
+                assert _rel(y2, _conv64(xx, ww, None, K, 1)) < TOL, name
+            else:
+                assert float(y2.abs().max()) == 0.0
+    finally:
+        ops.set_conv_precision(was_p)
+        ops.set_conv_small_grid(was_g)
 
 
 @pytest.mark.parametrize("case", [(2, 32, 5001, True, True), (3, 8, 250, False, True), (1, 32, 3, True, False), (2, 64, 247, True, True),

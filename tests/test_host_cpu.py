@@ -342,7 +342,8 @@ def test_graph_cache_policy_without_a_gpu(monkeypatch):
     """tts_amd.graphs.GraphCache's bookkeeping with the capture itself mocked out: a shape runs eagerly until it has been seen
     `capture_after` times (hits are counted per SHAPE, not per input address), entries are keyed by stream + shape + the
     addresses of the in-place (`stable`) inputs, the least recently used entry is released and evicted, a failed capture turns
-    the shape eager for good, purge_stream drops one lane's graphs only, and the collector is off inside a capture."""
+    the shape eager for good, purge_stream drops one lane's graphs only, purge_addresses the graphs over an evicted scratch set,
+    a capture resets the shape's hit count, and the collector is off inside a capture."""
     import gc
     import types
 
@@ -374,12 +375,19 @@ def test_graph_cache_policy_without_a_gpu(monkeypatch):
     a, b = torch.zeros(1, 5), torch.zeros(1, 5)                       # same shape, different addresses
     assert c(a) == ("eager", 5) and not c.last_static                  # first sighting: eager
     assert c(b, stable=(0,))[0] == "replay" and c.last_static          # second sighting of the SHAPE: captured (for b's address)
-    assert c(a, stable=(0,))[0] == "replay" and len(c.entries) == 2    # another address of a hot shape: its own capture at once
-    assert c.stats["captures"] == 2 and c.stats["eager"] == 1
+    # another address of the shape (an evicted scratch set, a re-captured producer): the hit count was reset by the capture, so it
+    # has to be seen `capture_after` times again — no capture storm when addresses churn
+    assert c(a, stable=(0,)) == ("eager", 5) and len(c.entries) == 1
+    assert c(a, stable=(0,))[0] == "replay" and len(c.entries) == 2
+    assert c.stats["captures"] == 2 and c.stats["eager"] == 2
+    c.purge_addresses([b.data_ptr()])                                  # b's scratch set evicted: the graph over it goes with it
+    assert len(c.entries) == 1 and c.stats["evictions"] == 1 and ("release",) in log
+    assert c(b, stable=(0,)) == ("eager", 5)                           # ... and b's shape starts counting again
+    assert c(b, stable=(0,))[0] == "replay" and len(c.entries) == 2
     x7 = torch.zeros(1, 7)
     c(x7)
     c(x7)                                                              # third entry: the least recently used one goes
-    assert ("release",) in log and len(c.entries) == 2 and c.stats["evictions"] == 1
+    assert len(c.entries) == 2 and c.stats["evictions"] == 2
     x13 = torch.zeros(1, 13)
     c(x13)
     assert c(x13) == ("eager", 13) and c.stats["capture_failures"] == 1
@@ -396,3 +404,40 @@ def test_graph_cache_policy_without_a_gpu(monkeypatch):
     c.clear()
     assert not c.entries and not c.hits and not c.failed
     assert gc.isenabled()
+
+
+def test_stream_scratch_eviction_drops_dependent_graphs(monkeypatch):
+    """StreamScratch: LRU-bounded per-(stream, key) buffer sets; evicting a set (or purging a lane's stream) tells the dependent
+    GraphCaches to drop the graphs that read its addresses in place (they stayed as dead entries pinning their pools)."""
+    import types
+
+    import torch
+
+    from tts_amd import graphs
+
+    cur = types.SimpleNamespace(cuda_stream=7)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: cur)
+
+    class Cache:
+        def __init__(self):
+            self.purged = []
+
+        def purge_addresses(self, ptrs):
+            self.purged.append(frozenset(ptrs))
+
+    dep = Cache()
+    sc = graphs.StreamScratch(max_entries=2, dependents=[dep])
+    a = sc.get((1, 5), lambda: {"m": torch.zeros(3), "pair": (torch.zeros(2), torch.zeros(1))})
+    assert sc.get((1, 5), lambda: None) is a
+    b = sc.get((1, 6), lambda: torch.zeros(4))
+    sc.get((1, 5), lambda: None)                                      # a is the most recently used
+    sc.get((1, 7), lambda: torch.zeros(5))                            # third set: b goes
+    assert dep.purged == [frozenset([b.data_ptr()])]
+    cur.cuda_stream = 8
+    sc.get((1, 5), lambda: torch.zeros(6))                            # another stream: its own set; a (stream 7) is evicted
+    assert dep.purged[-1] == frozenset([a["m"].data_ptr(), a["pair"][0].data_ptr(), a["pair"][1].data_ptr()])
+    n = len(dep.purged)
+    sc.purge_stream(7)                                                # the (1, 7) set of stream 7
+    assert len(dep.purged) == n + 1 and all(k[0] == 8 for k in sc.sets)
+    sc.clear()
+    assert not sc.sets

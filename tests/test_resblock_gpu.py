@@ -22,9 +22,11 @@ SLOPE = 0.1
 def same_summation_order():
     """The bitwise comparisons below need the two-launch baseline to sum in the fused kernel's order: small test tensors
     would otherwise take the K-split small-grid kernels (a different, equally valid, fp32 summation order)."""
-    was = ops.set_conv_small_grid(1)
+    was, was_p = ops.set_conv_small_grid(1), ops.conv_precision()
+    ops.set_conv_precision("x3")          # the bitwise claims are the six-product kernels'; the three-product ones: *_h2 tests below
     yield
     ops.set_conv_small_grid(was)
+    ops.set_conv_precision(was_p)
 
 
 def _pair(C, K, D, seed, gpu):
@@ -97,6 +99,90 @@ def test_fused_pair_mask_accum_div_and_edges(gpu, case):
     want = _unfused(pc1, pc2, dev(x), dev(mask), dev(acc), div)
     assert torch.equal(y, want), float((y - want).abs().max())
     assert _rel(y, _torch_ref(w, x, mask, acc, div, K, D)) < 1e-5
+
+
+class _H2:
+    """three-product arithmetic (precision "h2") with the large-grid kernels forced onto the test shapes: small-grid tiles off
+    for the convs, variant 1 (the default-width tiles) for the fused pair"""
+
+    def __enter__(self):
+        self.was, self.was_p = ops.set_conv_small_grid(0), ops.conv_precision()
+        ops.set_conv_precision("h2")
+
+    def __exit__(self, *exc):
+        ops.set_conv_small_grid(self.was)
+        ops.set_conv_precision(self.was_p)
+
+
+@pytest.mark.parametrize("ckd", ALL, ids=lambda c: "c%d_k%d_d%d" % c)
+def test_fused_pair_h2_equals_two_convs_to_rounding(gpu, ckd):
+    """The three-product fused kernel (resblock_kernel_h2.h: one activation exponent per block tile) against the two three-product
+    conv launches (one exponent per 16-channel chunk tile) — fp32 rounding level, not bitwise —, against torch at the conv
+    tolerance, and different in its bits from the six-product kernel (i.e. it is the kernel that ran)."""
+    C, K, D = ckd
+    B, T = 2, 700 + 13 * K + D
+    w, pc1, pc2, g = _pair(C, K, D, C + K + D, gpu)
+    x = torch.randn(B, C, T, generator=g).to(gpu)
+    y6 = torch.empty_like(x)
+    ops.resblock_pair(pc1, pc2, x, y6, slope=SLOPE, variant=1)
+    with _H2():
+        assert ops.resblock_pair_supported(pc1, pc2)
+        y = torch.full((B, C, T), float("nan"), device=gpu)
+        ops.resblock_pair(pc1, pc2, x, y, slope=SLOPE, variant=1)
+        want = _unfused(pc1, pc2, x, None, None, 0.0)
+    assert _rel(y, want) < 2e-6, _rel(y, want)
+    assert _rel(y, _torch_ref(w, x.cpu(), None, None, 0.0, K, D)) < 1e-5
+    assert not torch.equal(y, y6) and _rel(y, y6) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(32, 11, 5, 3, 1000, True, True, 3.0), (32, 3, 1, 2, 256, True, False, 0.0),
+                                  (64, 7, 3, 3, 517, True, True, 3.0), (64, 11, 1, 1, 247, False, True, 0.0),
+                                  (128, 3, 5, 2, 300, True, True, 3.0), (32, 7, 1, 4, 5, True, True, 3.0),
+                                  (64, 3, 1, 1, 1, False, False, 0.0), (32, 11, 3, 1, 246, False, False, 0.0),
+                                  (32, 11, 3, 1, 247, False, True, 3.0), (16, 7, 5, 3, 700, True, True, 3.0),
+                                  (8, 11, 1, 2, 1000, True, True, 3.0)])
+def test_fused_pair_h2_mask_accum_div_and_edges(gpu, case):
+    """The edge cases of test_fused_pair_mask_accum_div_and_edges on the three-product kernel, plus a wide-range input (item
+    magnitudes 1e-3 .. 1e2: every block takes its own exponent) against an fp64 evaluation."""
+    C, K, D, B, T, has_mask, has_acc, div = case
+    w, pc1, pc2, g = _pair(C, K, D, sum(case[:5]), gpu)
+    x = torch.randn(B, C, T, generator=g) * (10.0 ** torch.linspace(-3, 2, B))[:, None, None]
+    lens = torch.tensor([max(1, T - 97 * i) for i in range(B)])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float() if has_mask else None
+    acc = torch.randn(B, C, T, generator=g) if has_acc else None
+    dev = lambda t: None if t is None else t.to(gpu)  # noqa: E731
+    with _H2():
+        y = torch.full((B, C, T), float("nan"), device=gpu)
+        ops.resblock_pair(pc1, pc2, dev(x), y, slope=SLOPE, mask=dev(mask), accum=dev(acc), out_div=div, variant=1)
+        want = _unfused(pc1, pc2, dev(x), dev(mask), dev(acc), div)
+    assert torch.isfinite(y).all()
+    assert _rel(y, want) < 2e-6, _rel(y, want)
+    w64 = tuple(t.double() for t in w)
+    ref = _torch_ref(w64, x.double(), None if mask is None else mask.double(), None if acc is None else acc.double(), div, K, D)
+    for i in range(B):                                  # per item: the small-magnitude items keep their own relative accuracy
+        assert _rel(y[i], ref[i]) < 1e-5, (i, _rel(y[i], ref[i]))
+
+
+@pytest.mark.parametrize("case", [(32, 11, 5, 3, 60000), (64, 3, 1, 2, 120000), (64, 7, 3, 5, 30011), (128, 3, 3, 4, 20000)])
+def test_fused_pair_h2_many_tiles_default_dispatch(gpu, case):
+    """Large tensors take the three-product kernel by default (no variant): many more (item, tile) pairs than resident blocks,
+    ragged masks + accumulate + division, both tiles of the 64-channel pair."""
+    C, K, D, B, T = case
+    w, pc1, pc2, g = _pair(C, K, D, sum(case), gpu)
+    x = torch.randn(B, C, T, generator=g).to(gpu)
+    lens = torch.tensor([T - 1234 * i for i in range(B)])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(gpu)
+    acc = torch.randn(B, C, T, generator=g).to(gpu)
+    y6 = torch.empty_like(x)
+    ops.resblock_pair(pc1, pc2, x, y6, slope=SLOPE, mask=mask, accum=acc, out_div=3.0)
+    with _H2():
+        y = torch.full((B, C, T), float("nan"), device=gpu)
+        ops.resblock_pair(pc1, pc2, x, y, slope=SLOPE, mask=mask, accum=acc, out_div=3.0)
+        y2 = torch.full((B, C, T), float("nan"), device=gpu)
+        ops.resblock_pair(pc1, pc2, x, y2, slope=SLOPE, mask=mask, accum=acc, out_div=3.0, variant=1)
+    assert not torch.equal(y, y6) and _rel(y, y6) < 2e-6
+    assert _rel(y2, y6) < 2e-6
+    assert _rel(y, _torch_ref(w, x.cpu(), mask.cpu(), acc.cpu(), 3.0, K, D)) < 1e-5
 
 
 @pytest.mark.parametrize("case", [(32, 11, 5, 3, 60000), (64, 3, 1, 2, 120000), (64, 7, 3, 5, 30011), (128, 11, 1, 4, 20000)])

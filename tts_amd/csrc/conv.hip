@@ -2,7 +2,9 @@
 #include <cstdlib>
 #include "conv_dispatch.h"
 
+#include <cmath>
 #include <cstring>
+#include <vector>
 
 using namespace ttsamd;
 
@@ -132,6 +134,68 @@ extern "C" int ttsamd_conv1d_pack_weights_split(void *dst_, const float *w, int 
                         grp[(0 * 64 + l) * 8 + i] = p1;
                         grp[(1 * 64 + l) * 8 + i] = p2;
                         grp[(2 * 64 + l) * 8 + i] = p3;
+                    }
+                }
+            }
+    return TTSAMD_OK;
+}
+
+// ---- two-part fp16 image (conv_kernel_h2.h) -----------------------------------------------------------------------------
+extern "C" size_t ttsamd_conv1d_packed_h2_bytes(int c_out, int c_in, int kernel)
+{
+    if (c_out <= 0 || c_in <= 0 || kernel <= 0) return 0;
+    const size_t mtiles = (size_t)(c_out + 31) / 32;
+    return conv_h2_table_offset(c_out, c_in, kernel) + sizeof(H2RowTable) + mtiles * 32 * 2 * sizeof(float);
+}
+
+extern "C" int ttsamd_conv1d_pack_weights_h2(void *dst_, const float *w, int c_out, int c_in, int kernel)
+{
+    TTSAMD_CHECK_ARG(dst_ && w && c_out > 0 && c_in > 0 && kernel > 0, "conv1d_pack_weights_h2: bad args");
+    unsigned char *const base = static_cast<unsigned char *>(dst_);
+    memset(base, 0, ttsamd_conv1d_packed_h2_bytes(c_out, c_in, kernel));
+    const int mtiles = (c_out + 31) / 32;
+    const int nchunks = (c_in + kConvCK - 1) / kConvCK;
+    H2RowTable *const hdr = reinterpret_cast<H2RowTable *>(base + conv_h2_table_offset(c_out, c_in, kernel));
+    float *const tab = reinterpret_cast<float *>(hdr + 1);
+    // row exponents: the row's largest magnitude lands in [2^13, 2^14); an all-zero (or padding) row keeps exponent 0
+    std::vector<int> rexp((size_t)mtiles * 32, 0);
+    int emax = -1000;
+    for (int row = 0; row < mtiles * 32; ++row) {
+        float mx = 0.f;
+        if (row < c_out)
+            for (long i = 0; i < (long)c_in * kernel; ++i) {
+                const float v = fabsf(w[(long)row * c_in * kernel + i]);
+                if (v > mx && v <= 3.4e38f) mx = v;
+            }
+        int e = 0;
+        if (mx > 0.f) {
+            int ex;
+            frexpf(mx, &ex);              // mx = f * 2^ex, f in [0.5, 1)  ->  mx in [2^(ex-1), 2^ex)
+            e = 14 - ex;
+            e = e > 126 ? 126 : (e < -126 ? -126 : e);
+        }
+        rexp[row] = e;
+        tab[2 * row] = ldexpf(1.f, e);
+        tab[2 * row + 1] = ldexpf(1.f, -e);
+        if (row < c_out && e > emax) emax = e;
+    }
+    hdr->max_row_exp = emax == -1000 ? 0 : emax;
+    _Float16 *const dst = reinterpret_cast<_Float16 *>(base);
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int c = 0; c < nchunks; ++c)
+            for (int tap = 0; tap < kernel; ++tap) {
+                _Float16 *grp = dst + (((size_t)mt * nchunks + c) * kernel + tap) * (2 * 64 * 8);
+                for (int l = 0; l < 64; ++l) {
+                    const int row = mt * 32 + (l & 31);
+                    if (row >= c_out) continue;
+                    for (int i = 0; i < 8; ++i) {
+                        const int ci = c * kConvCK + 8 * (l >> 5) + i;
+                        if (ci >= c_in) continue;
+                        const float v = ldexpf(w[((long)row * c_in + ci) * kernel + tap], rexp[row]);     // exact
+                        const _Float16 hi = (_Float16)v;                                                 // round to nearest even
+                        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);                        // residual exact
+                        grp[(0 * 64 + l) * 8 + i] = hi;
+                        grp[(1 * 64 + l) * 8 + i] = lo;
                     }
                 }
             }

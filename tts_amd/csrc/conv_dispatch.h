@@ -4,6 +4,7 @@
 #include "conv_kernel_x3.h"
 #include "conv_kernel_x3s.h"
 #include "conv_kernel_x3o.h"
+#include "conv_kernel_h2.h"
 
 namespace ttsamd {
 

@@ -411,6 +411,8 @@ template <int K, int D, int MI, int MODE>
 bool conv1d_x3s_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc);   // conv_kernel_x3s.h
 template <int K, int D, int MODE>
 bool conv1d_x3o_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc);   // conv_kernel_x3o.h
+template <int K, int D, int MODE>
+int conv1d_h2_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st);        // conv_kernel_h2.h
 
 template <int K, int D, int MODE>
 int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
@@ -471,6 +473,8 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     // (<2,4,2,1>, half the L1 bytes per MFMA, 20 spilled VGPRs) 79.5 -> 81.7 ms/step; 256-row blocks of 8 waves (<1,4,8,1>,
     // the 256-channel layers stage their tile once instead of twice) 77.5 -> 77.9; the conflict-free planar LDS image
     // (TTSAMD_X3_PLANAR) +-0 on the 128/256-row layers (SQ_LDS_BANK_CONFLICT 0, but LDS was not the limiter).
+    // large grids with the two-part fp16 image present: three products per fp32 product instead of six (conv_kernel_h2.h)
+    if (a.w_h2) return conv1d_h2_launch_tiles<K, D, MODE>(a, st);
     if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
     // same bench, same box: <2,2,1,4> 90.6 ms/step, <1,4,2,2> 89.7; (<1,8,4,1> on the 128-row blocks: 93.4)
     if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);

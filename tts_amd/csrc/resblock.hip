@@ -15,6 +15,12 @@ extern "C" size_t ttsamd_resblock_weight_bytes(int c, int kernel)
     return ttsamd_conv1d_packed_split_bytes(cc, cc, kernel);
 }
 
+extern "C" size_t ttsamd_resblock_weight_h2_bytes(int c, int kernel)
+{
+    const int cc = c < 32 ? 32 : c;
+    return ttsamd_conv1d_packed_h2_bytes(cc, cc, kernel);
+}
+
 extern "C" int ttsamd_resblock_pair(const ttsamd_resblock_args *args, void *stream)
 {
     TTSAMD_CHECK_ARG(args, "resblock_pair: NULL args");
@@ -33,6 +39,12 @@ extern "C" int ttsamd_resblock_pair(const ttsamd_resblock_args *args, void *stre
                          "resblock_pair: weight images of %lld / %lld bytes, the c=%d k=%d tile reads %lld (c < 32: pack the "
                          "weight zero-padded to [32, 32, k])", (long long)a.w1_bytes, (long long)a.w2_bytes, a.c, a.kernel,
                          (long long)need);
+    }
+    if (a.w1_h2 || a.w2_h2) {
+        const int64_t need = (int64_t)ttsamd_resblock_weight_h2_bytes(a.c, a.kernel);
+        TTSAMD_CHECK_ARG(a.w1_h2 && a.w2_h2 && a.w1_h2_bytes == need && a.w2_h2_bytes == need,
+                         "resblock_pair: two-part fp16 images of %lld / %lld bytes, the c=%d k=%d tile reads %lld (both or neither)",
+                         (long long)a.w1_h2_bytes, (long long)a.w2_h2_bytes, a.c, a.kernel, (long long)need);
     }
     if (a.batch == 0 || a.t == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(a.batch <= 65535, "resblock_pair: batch > 65535");

@@ -1,4 +1,4 @@
-#include "resblock_kernel_x3.h"
+#include "resblock_kernel_h2.h"
 namespace ttsamd {
 int resblock_pair_launch_k11(const ttsamd_resblock_args &a, hipStream_t st) { return resblock_pair_launch_k<11>(a, st); }
 }  // namespace ttsamd

@@ -1,0 +1,379 @@
+// The fused ResBlock1 iteration of resblock_kernel_x3.h on the three-product arithmetic of conv_kernel_h2.h (two fp16 parts per
+// fp32 operand, hi*hi in a main fp32 accumulator, the two cross products in a second one scaled by 2^-11 once):
+//
+//     mid = conv1(lrelu(x * mask), kernel K, dilation D) + bias1
+//     y   = conv2(lrelu(mid * mask), kernel K, dilation 1) + bias2 + x   [+ accum] [/ div]
+//
+// Same block shape, LDS image order ([part 2][chunk][half][column][8 ch] fp16: two thirds of the split-bf16 image's bytes) and
+// weight streams as the six-product kernel.  What the fp16 range adds: a block stages its WHOLE x tile at once and writes its
+// whole mid tile at once, so each gets ONE power-of-two exponent per block, taken from the tile's largest magnitude:
+//   * x tile: loads -> mask / leaky ReLU in registers -> wave maxima -> LDS slots -> barrier -> scale, split, write;
+//   * mid tile: conv1's accumulators leave their units (activation exponent, row exponent), + bias, mask, leaky ReLU in
+//     registers -> wave maxima -> slots -> the barrier that separates conv1's LDS reads from the mid writes anyway -> scale,
+//     split, write.
+// One barrier more than the six-product kernel (the x tile's).  The residual x is requested before conv1 as before, but kept in
+// registers of its own and added in the output epilogue (the accumulators live in scaled units here).
+// Results agree with two ttsamd_conv1d launches to fp32 rounding level, not bitwise: the unfused kernel scales per 16-channel
+// chunk, this one per tile.
+#pragma once
+#include "conv_kernel_h2.h"
+#include "resblock_kernel_x3.h"
+
+namespace ttsamd {
+
+template <int K, int D, int C, int WM, int WN, int NI>
+struct ResGeomH2 : ResGeom<K, D, C, WM, WN, NI> {
+    using B = ResGeom<K, D, C, WM, WN, NI>;
+    static constexpr size_t kImageBytes = (size_t)2 * B::kNCh * 2 * B::kPlaneX;
+    static constexpr size_t kLdsBytes = kImageBytes + 2 * 8 * 4;        // + [x tile / mid tile][wave] maximum slots
+    static constexpr int kOcc = (2 * kLdsBytes <= 160 * 1024 && B::kThreads <= 256) ? 2 : (B::kThreads >= 512 && 2 * kLdsBytes <= 160 * 1024 ? 2 : 1);
+    static_assert(WM * WN == 4 || WM * WN == 8, "the maximum slots are read four at a time");
+};
+
+// acc{m,x}[mi][ni] += sum over (chunk, tap) of the three products; weight fragments requested two taps ahead (a_cur: this tap,
+// a_n1: the next), as in res_conv_mainloop
+template <int KK, int DD, int MI, int NI, int NCH, int PLANE>
+__device__ __forceinline__ void res_conv_mainloop_h2(f32x16 (&accm)[MI][NI], f32x16 (&accx)[MI][NI], const u32x4 *const (&wp)[MI],
+                                                     u32x4 (&a_cur)[MI][2], u32x4 (&a_n1)[MI][2], const unsigned char *bbase)
+{
+    u32x4 a_n2[MI][2];
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const unsigned char *cb = bbase + c * (2 * PLANE);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const long g = ((long)c * KK + tap + 2) * (2 * 64);   // the packed image ends with two groups of slack
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) a_n2[mi][q] = wp[mi][g + q * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                u32x4 bq[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bq[q] = *reinterpret_cast<const u32x4 *>(cb + q * (NCH * 2 * PLANE) + (ni * 32 + tap * DD) * 16);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][1]), __builtin_bit_cast(f16x8, bq[0]), accx[mi][ni], 0, 0, 0);
+                    accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[1]), accx[mi][ni], 0, 0, 0);
+                    accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[0]), accm[mi][ni], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    a_cur[mi][q] = a_n1[mi][q];
+                    a_n1[mi][q] = a_n2[mi][q];
+                }
+        }
+    }
+}
+
+template <int K, int D, int C, int WM, int WN, int NI>
+__global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc)) void resblock_pair_h2_kernel(const ttsamd_resblock_args a)
+{
+    using G = ResGeomH2<K, D, C, WM, WN, NI>;
+    constexpr int MI = G::kMI;
+    constexpr int NCH = G::kNCh;
+    constexpr int NW = WM * WN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rh2[];
+    unsigned *const slots = reinterpret_cast<unsigned *>(rh2 + G::kImageBytes);
+
+    const ConvTile tile = conv_tile_of_block();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int b = tile.b;
+    const int t0 = tile.nb * G::kBN;
+    const int T = a.t;
+    constexpr int kOob = kConvOob;
+
+    const int creal = a.c;                    // may be smaller than C (8 / 16 channels on the padded tile): real rows only
+    const long slab = (long)creal * T * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * creal * T, slab);
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(a.mask ? a.mask + (long)b * T : nullptr, a.mask ? (long)T * 4 : 0);
+    const bool has_mask = a.mask != nullptr;
+    constexpr int CC = C < 32 ? 32 : C;       // channel count of the (padded) weight images
+    const float *const tab1 = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.w1_h2) + conv_h2_table_offset(CC, CC, K) + sizeof(H2RowTable));
+    const float *const tab2 = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.w2_h2) + conv_h2_table_offset(CC, CC, K) + sizeof(H2RowTable));
+
+    auto block_max = [&](int which) -> unsigned {      // after a barrier
+        const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slots + which * 8);
+        unsigned m = max(max(s0.x, s0.y), max(s0.z, s0.w));
+        if constexpr (NW > 4) {
+            const u32x4 s1 = *reinterpret_cast<const u32x4 *>(slots + which * 8 + 4);
+            m = max(m, max(max(s1.x, s1.y), max(s1.z, s1.w)));
+        }
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    };
+
+    // ---- stage the x tile: columns [t0 - H2 - H1, +kXW) of all C channels: mask, leaky ReLU, block exponent, split, LDS ------
+    int e_x;
+    {
+        const int tx0 = t0 - G::kH2 - G::kH1;
+        const int row_bytes = T * 4;
+        float st[G::kRounds][8];
+#pragma unroll
+        for (int rr = 0; rr < G::kRounds; ++rr) {
+            const int e = tid + rr * G::kThreads;
+            const int pl = e / G::kXW;                 // chunk * 2 + half
+            const int col = e - pl * G::kXW;
+            const int gt = tx0 + col;
+            const bool ok = (e < G::kItems) && (gt >= 0) && (gt < T);
+            const int off = ok ? (pl * 8 * row_bytes + gt * 4) : kOob;
+            float sm;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off == kOob ? kOob : off + i * row_bytes, 0);
+            sm = has_mask ? ld_buf(rmask, ok ? gt * 4 : kOob, 0) : 1.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st[rr][i] *= sm;
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < G::kRounds; ++rr)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                st[rr][i] = conv_lrelu(st[rr][i], a.slope);
+                m = __builtin_fmaxf(m, __builtin_fabsf(st[rr][i]));
+            }
+        slots[wave] = wave_max_u32(__builtin_bit_cast(unsigned, m));
+        __syncthreads();
+        e_x = h2_exp_for(block_max(0));
+        const float sx = pow2f(e_x);
+#pragma unroll
+        for (int rr = 0; rr < G::kRounds; ++rr) {
+            const int e = tid + rr * G::kThreads;
+            const int pl = e / G::kXW;
+            const int col = e - pl * G::kXW;
+            if (e < G::kItems) {
+                unsigned pw[2][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) conv_split2x2(st[rr][2 * i] * sx, st[rr][2 * i + 1] * sx, pw[0][i], pw[1][i]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u32x4 w;
+                    w.x = pw[q][0];
+                    w.y = pw[q][1];
+                    w.z = pw[q][2];
+                    w.w = pw[q][3];
+                    *reinterpret_cast<u32x4 *>(rh2 + (q * (NCH * 2) + pl) * G::kPlaneX + col * 16) = w;
+                }
+            }
+        }
+    }
+
+    // ---- conv1 ------------------------------------------------------------------------------------------------------
+    const u32x4 *wp1[MI], *wp2[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long mtile = (long)wm * MI + mi;
+        wp1[mi] = reinterpret_cast<const u32x4 *>(a.w1_h2) + mtile * ((long)NCH * K * 2 * 64) + lane;
+        wp2[mi] = reinterpret_cast<const u32x4 *>(a.w2_h2) + mtile * ((long)NCH * K * 2 * 64) + lane;
+    }
+    u32x4 a_cur[MI][2], a_n1[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a_cur[mi][q] = wp1[mi][q * 64];
+            a_n1[mi][q] = wp1[mi][(2 + q) * 64];
+        }
+    // the residual x — the tile's own columns, requested now (L2 hits right after the staging pass), added in the output epilogue
+    f32x16 resv[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row0 = (wm * MI + mi) * 32;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int o = (wn * NI + ni) * 32 + j;
+            const int t = t0 + o;
+            const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) resv[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+        }
+    }
+    float mk[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int t = t0 - G::kH2 + (wn * NI + ni) * 32 + j;      // time of this lane's mid column
+        const bool ok = (t >= 0) && (t < T);                      // outside the tensor conv2 sees its zero padding
+        mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
+    }
+    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(a.bias1, a.bias1 ? creal * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(a.bias2, a.bias2 ? creal * 4 : 0);
+    float bia[MI][16], ru[MI][16];     // bias and row unscale factor (2^-e_row) of this lane's rows
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2);
+            bia[mi][r] = ld_buf(rb1, 16 * h, row * 4);
+            ru[mi][r] = tab1[2 * (row + 4 * h) + 1];
+        }
+    f32x16 accm[MI][NI], accx[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[mi][ni][r] = 0.f;
+                accx[mi][ni][r] = 0.f;
+            }
+    __syncthreads();
+    res_conv_mainloop_h2<K, D, MI, NI, NCH, G::kPlaneX>(accm, accx, wp1, a_cur, a_n1, rh2 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
+
+    // conv2's first weight fragments: requested before the mid epilogue so that their latency hides behind it
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a_cur[mi][q] = wp2[mi][q * 64];
+            a_n1[mi][q] = wp2[mi][(2 + q) * 64];
+        }
+
+    // ---- mid epilogue: leave the scaled units, + bias1, mask, leaky ReLU (in registers), tile exponent, split -> LDS -------------
+    int e_m;
+    {
+        const float usx = pow2f(-e_x);
+        float m = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usx) * ru[mi][r];
+                    v = conv_lrelu((v + bia[mi][r]) * mk[ni], a.slope);
+                    accm[mi][ni][r] = v;
+                    m = __builtin_fmaxf(m, __builtin_fabsf(v));
+                }
+        slots[8 + wave] = wave_max_u32(__builtin_bit_cast(unsigned, m));
+        __syncthreads();                                               // every wave is done reading the x tile; the maxima are in
+        e_m = h2_exp_for(block_max(1));
+        const float sm = pow2f(e_m);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = (wn * NI + ni) * 32 + j;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    unsigned pw[2][2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        conv_split2x2(accm[mi][ni][rg * 4 + 2 * i] * sm, accm[mi][ni][rg * 4 + 2 * i + 1] * sm, pw[0][i], pw[1][i]);
+                    // rows 8*rg + 4*h + i of m-tile (wm*MI + mi): chunk 2*mtile + rg/2, 8-channel half rg%2, channels 4h..4h+3
+                    const int pl = (2 * (wm * MI + mi) + (rg >> 1)) * 2 + (rg & 1);
+                    if (2 * (wm * MI + mi) + (rg >> 1) >= NCH) continue;     // C = 16: rows 16..31 of the tile are padding
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        u32x2 w;
+                        w.x = pw[q][0];
+                        w.y = pw[q][1];
+                        *reinterpret_cast<u32x2 *>(rh2 + (q * (NCH * 2) + pl) * G::kPlaneM + col * 16 + h * 8) = w;
+                    }
+                }
+            }
+    }
+
+    // ---- conv2 ----------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2);
+            bia[mi][r] = ld_buf(rb2, 16 * h, row * 4);
+            ru[mi][r] = tab2[2 * (row + 4 * h) + 1];
+        }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[mi][ni][r] = 0.f;
+                accx[mi][ni][r] = 0.f;
+            }
+    __syncthreads();                                                   // the mid tile is complete
+    res_conv_mainloop_h2<K, 1, MI, NI, NCH, G::kPlaneM>(accm, accx, wp2, a_cur, a_n1, rh2 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
+
+    // ---- output epilogue: leave the scaled units, + bias2, + x (+ accum) (/ div) ---------------------------------------------
+    {
+        ResArgsKernargPtr ep = (ResArgsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ep) : : "memory");
+        const float out_div = ep->out_div;
+        const bool has_accum = ep->accum != nullptr;
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(ep->y + (long)b * creal * T, slab);
+        const __amdgpu_buffer_rsrc_t racc = make_rsrc(has_accum ? ep->accum + (long)b * creal * T : nullptr, has_accum ? slab : 0);
+        const float usm = pow2f(-e_m);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row0 = (wm * MI + mi) * 32;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int o = (wn * NI + ni) * 32 + j;
+                const int t = t0 + o;
+                const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+                float vout[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    vout[r] = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usm) * ru[mi][r] + bia[mi][r];
+                    vout[r] += resv[mi][ni][r];
+                }
+                if (has_accum) {
+                    float e2[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vout[r] = e2[r] + vout[r];
+                }
+                if (out_div != 0.f) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) vout[r] = vout[r] / out_div;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st_buf(ry, vout[r], vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+            }
+        }
+    }
+}
+
+template <int K, int D, int C, int WM, int WN, int NI>
+int resblock_pair_h2_launch_cfg(const ttsamd_resblock_args &a, hipStream_t st)
+{
+    using G = ResGeomH2<K, D, C, WM, WN, NI>;
+    auto kern = resblock_pair_h2_kernel<K, D, C, WM, WN, NI>;
+    static std::atomic<unsigned long long> lds_attr_done{0};
+    TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (int)G::kLdsBytes, lds_attr_done));
+    const int nblocks = (a.t + G::kBN - 1) / G::kBN;
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, a.batch), dim3(G::kThreads), G::kLdsBytes, st, a);
+    TTSAMD_LAUNCH_CHECK();
+    return TTSAMD_OK;
+}
+
+// the default (large-grid) tiles of resblock_pair_launch_kd; the narrow small-grid tiles keep the six-product kernel
+template <int K, int D>
+int resblock_pair_h2_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
+{
+    switch (a.c) {
+        case 8:
+        case 16: return resblock_pair_h2_launch_cfg<K, D, 16, 1, 4, 2>(a, st);
+        case 32: return resblock_pair_h2_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
+        case 64:
+            if ((a.variant == 1) != (K == 11)) return resblock_pair_h2_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
+            return resblock_pair_h2_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
+        case 128: return resblock_pair_h2_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
+    }
+    set_error("resblock_pair: c = %d has no instantiation (8, 16, 32, 64, 128)", a.c);
+    return TTSAMD_ERR_UNSUPPORTED;
+}
+
+}  // namespace ttsamd

@@ -175,9 +175,17 @@ int resblock_pair_launch_cfg(const ttsamd_resblock_args &a, hipStream_t st)
 //            (measured at the benchmark shape, us per pair, 4-wave / 8-wave: k=3 988 / 1088, k=7 1760 / 1773, k=11 2686 / 2605:
 //            k = 11 takes the 8-wave tile by default, variant 1 flips the choice)
 //   C = 128: 8 waves as 4x2, NI = 2 -> 128 mid columns, 137 KB (1 block / CU)
+inline bool resblock_group_small(int c, long cols);
+template <int K, int D>
+int resblock_pair_h2_launch_kd(const ttsamd_resblock_args &a, hipStream_t st);    // resblock_kernel_h2.h
+
 template <int K, int D>
 int resblock_pair_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
 {
+    // the default tiles with the two-part fp16 images present: three products per fp32 product (resblock_kernel_h2.h); the narrow
+    // small-grid tiles below (a single sentence) keep the six-product kernel
+    if (a.w1_h2 && a.w2_h2 && a.variant != 2 && !(a.variant == 0 && resblock_group_small(a.c, (long)a.t * a.batch)))
+        return resblock_pair_h2_launch_kd<K, D>(a, st);
     if constexpr (K == 3) {
         // variant 2 (A/B): half-width tiles — 4 waves x 32 columns at C = 32, 2x2 waves x 32 columns at C = 64: a quarter /
         // half of the LDS, <= 128 VGPRs, 4 blocks per CU instead of 3 / 2 (more blocks in different phases per SIMD)

@@ -64,7 +64,9 @@ class GlowTTS:
         self._front = graphs.GraphCache(self._front_eager)
         self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
         self._tail_cfg = None
-        self._scratch = graphs.StreamScratch()  # per-stream fixed buffers the graphs read in place (see tts_amd.Vits.inference)
+        # per-stream fixed buffers the graphs read in place (see tts_amd.Vits.inference); evicting a set drops the graphs over it
+        self._scratch = graphs.StreamScratch(dependents=[self._front, self._tail])
+        self.weights_version = 0               # bumped by every re-pack: dependants (SentencePipeline) key their graphs on it
         self.graph_tail_max_frames = 4096      # B * padded frames up to which the tail is captured
         self.text_bucket = 16                  # token-axis padding of graphed requests (1 = off)
 
@@ -106,6 +108,7 @@ class GlowTTS:
         a, sd, dev = self.args, self._sd, self.device
         self._front.clear()          # captured graphs hold raw pointers to the weight tensors replaced below
         self._tail.clear()
+        self.weights_version += 1
         self.encoder = layers.GlowEncoder(sd, "encoder.", dev, a.hidden_channels_enc, a.out_channels, a.encoder_params,
                                           a.mean_only, a.use_encoder_prenet)
         self.decoder = layers.GlowDecoder(sd, "decoder.", dev, a.out_channels, a.hidden_channels_dec, a.kernel_size_dec,
@@ -247,7 +250,9 @@ class GlowTTS:
         "ragged_exact": padded tokens own no frames (the reference gives each PADDED token one frame via clamp_min,
         which only matters in batches) so that row b equals a B=1 run on sentence b (up to the conv launcher's batch-dependent
         tile choice: fp32 reassociation, ~1e-6 relative)."""
-        ctx = self.request_front(x, aux_input)
+        # "_front_ctx": the context of a request_front() the caller has already run for this very request (a Synthesizer whose
+        # fused pipeline declined a large batch): the front end — and the request's host wait — is not repeated
+        ctx = (aux_input or {}).get("_front_ctx") or self.request_front(x, aux_input)
         a = self.args
         B, T, T0, dev, t_dec, ragged = ctx["B"], ctx["T"], ctx["T0"], ctx["dev"], ctx["t_dec"], ctx["ragged"]
         o_mean, o_logs, logw, w_ceil, cum, y_lengths, x_mask, g = (ctx[k] for k in (

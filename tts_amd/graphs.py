@@ -91,6 +91,7 @@ class GraphCache:
     def __init__(self, fn, max_entries=16, capture_after=2):
         self.fn, self.max_entries, self.capture_after = fn, max_entries, capture_after
         self.entries = collections.OrderedDict()    # key -> GraphedSegment, least recently used first
+        self.stable_ptrs = {}                       # key -> addresses of the in-place inputs the capture reads (purge_addresses)
         self.hits = collections.OrderedDict()       # key -> times seen (not captured yet)
         self.failed = set()                         # keys whose capture raised: eager from then on
         self.enabled = True
@@ -103,13 +104,26 @@ class GraphCache:
         for seg in self.entries.values():
             seg.release()
         self.entries.clear()
+        self.stable_ptrs.clear()
         self.hits.clear()
         self.failed.clear()
+
+    def _drop(self, key):
+        self.stable_ptrs.pop(key, None)
+        self.entries.pop(key).release()
+
+    def purge_addresses(self, ptrs):
+        """Drop the graphs that read one of these device addresses in place (a StreamScratch set that is being evicted: the
+        graph would otherwise sit in the cache as a dead entry — its key can never match again — pinning its private pool)."""
+        ptrs = frozenset(ptrs)
+        for k in [k for k, p in self.stable_ptrs.items() if p & ptrs]:
+            self._drop(k)
+            self.stats["evictions"] += 1
 
     def purge_stream(self, handle):
         """Drop the graphs captured for one stream (a request lane that is being torn down)."""
         for k in [k for k in self.entries if k[1] == handle]:
-            self.entries.pop(k).release()
+            self._drop(k)
         for k in [k for k in self.hits if k[1] == handle]:
             self.hits.pop(k)
 
@@ -146,8 +160,7 @@ class GraphCache:
             self.stats["eager"] += 1
             return self.fn(*inputs)
         while len(self.entries) >= self.max_entries:
-            _, old = self.entries.popitem(last=False)
-            old.release()
+            self._drop(next(iter(self.entries)))
             self.stats["evictions"] += 1
         try:
             seg = GraphedSegment(self.fn, inputs, stable)
@@ -158,6 +171,11 @@ class GraphCache:
             self.stats["eager"] += 1
             return self.fn(*inputs)
         self.entries[key] = seg
+        self.stable_ptrs[key] = frozenset(inputs[i].data_ptr() for i in stable)
+        # the shape has to earn its next capture again: after an LRU eviction (or a change of an in-place input's address) it is
+        # captured on its `capture_after`-th fresh sighting, not on the very next one — a capture costs a collection, two warm-up
+        # runs and a device synchronise, and diverse traffic would otherwise thrash on them
+        self.hits.pop(base, None)
         self.stats["captures"] += 1
         self.last_static = True
         return seg(*inputs)
@@ -168,20 +186,48 @@ class StreamScratch:
     (masks, durations, noise) lands at the same address every time, so the graph reads it in place (`stable` inputs of
     GraphCache) instead of through a staging copy.  Per stream because request lanes run concurrently.  LRU-bounded."""
 
-    def __init__(self, max_entries=24):
+    def __init__(self, max_entries=64, dependents=()):
+        # sized above the graph caches that key on these buffers (2 x 16 + the sentence pipeline's 12): a live graph's scratch
+        # set is not the first thing to go; `dependents`: GraphCaches told to drop their graphs over a set that is evicted
         self.max_entries = max_entries
+        self.dependents = list(dependents)
         self.sets = collections.OrderedDict()
+
+    @staticmethod
+    def _addresses(obj):
+        if torch.is_tensor(obj):
+            return [obj.data_ptr()]
+        if isinstance(obj, dict):
+            obj = obj.values()
+        if isinstance(obj, (list, tuple)) or hasattr(obj, "__iter__"):
+            out = []
+            for v in obj:
+                out += StreamScratch._addresses(v)
+            return out
+        return []
+
+    def _evict(self, k):
+        old = self.sets.pop(k)
+        ptrs = self._addresses(old)
+        for cache in self.dependents:
+            cache.purge_addresses(ptrs)
 
     def get(self, key, make):
         k = (torch.cuda.current_stream().cuda_stream,) + tuple(key)
         s = self.sets.get(k)
         if s is None:
             while len(self.sets) >= self.max_entries:
-                self.sets.popitem(last=False)      # (graphs captured on an evicted set keep their own references to it)
+                self._evict(next(iter(self.sets)))
             s = self.sets[k] = make()
         else:
             self.sets.move_to_end(k)
         return s
 
+    def purge_stream(self, handle):
+        """Drop the sets of one stream (a request lane that is being torn down), and the graphs reading them."""
+        for k in [k for k in self.sets if k[0] == handle]:
+            self._evict(k)
+
     def clear(self):
-        self.sets.clear()
+        for k in list(self.sets):
+            self._evict(k)

@@ -83,6 +83,7 @@ class HifiganGenerator:
         self.use_graphs = True
         self.graph_max_frames = 2048
         self._graph = graphs.GraphCache(self._inference_ragged, max_entries=12)
+        self.weights_version = 0    # bumped by every re-pack: dependants (SentencePipeline) key their graphs on it
 
     def hop_length(self):
         return _cumprod(self.upsample_factors)[-1]
@@ -158,6 +159,7 @@ class HifiganGenerator:
                                                             sd.get(rp + "convs.%d.bias" % m), dev, dilation=d)
         P["conv_post"] = PackedConv(ops.fold_weight_norm(sd, "conv_post"), sd.get("conv_post.bias"), dev)
         self._graph.clear()          # captured graphs hold raw pointers to the previous weight tensors
+        self.weights_version += 1
         self._packed = P
 
     def _group_stage(self, i, ch, B, T, P):

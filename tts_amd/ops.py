@@ -37,7 +37,7 @@ class Conv1dArgs(ctypes.Structure):
         ("out_mask", ctypes.c_void_p), ("out_div", ctypes.c_float),
         ("shuffle_u", ctypes.c_int32), ("shuffle_pad", ctypes.c_int32), ("shuffle_t_out", ctypes.c_int32),
         ("y2", ctypes.c_void_p), ("y2_bstride", ctypes.c_int64), ("y2_rstride", ctypes.c_int64),
-        ("split_row", ctypes.c_int32), ("row_bias", ctypes.c_void_p), ("w_split", ctypes.c_void_p),
+        ("split_row", ctypes.c_int32), ("row_bias", ctypes.c_void_p), ("w_split", ctypes.c_void_p), ("w_h2", ctypes.c_void_p),
     ]
 
 
@@ -74,15 +74,22 @@ def set_conv_timer(timer):
     _TIMER = timer
 
 
-# Conv arithmetic: "x3" = split-bf16 kernels (3-way bf16 split of both fp32 operands, six products, fp32 accumulate:
-# fp32-class accuracy on the bf16 matrix pipe), "f32" = fp32-input MFMA kernels.  TTSAMD_CONV_PRECISION overrides.
-_PRECISION = os.environ.get("TTSAMD_CONV_PRECISION", "x3")
+# Conv arithmetic (TTSAMD_CONV_PRECISION overrides the default):
+#   "h2"  (default) large-grid launches split both fp32 operands into two fp16 parts and accumulate three products in fp32
+#         (csrc/conv_kernel_h2.h); small-grid launches (single requests) and untuned shapes run the "x3" kernels
+#   "x3"  split-bf16 kernels everywhere: three bf16 parts per operand, six products, fp32 accumulate
+#   "f32" fp32-input MFMA kernels (bitwise an fmaf chain)
+# All three are fp32-class (same parity tolerances; tests/test_conv_gpu.py runs every conv test on each).
+PRECISIONS = ("h2", "x3", "f32")
+_PRECISION = os.environ.get("TTSAMD_CONV_PRECISION", "h2")
+if _PRECISION not in PRECISIONS:
+    raise ValueError("TTSAMD_CONV_PRECISION must be one of %s" % (PRECISIONS,))
 
 
 def set_conv_precision(p):
     global _PRECISION
-    if p not in ("x3", "f32"):
-        raise ValueError("conv precision must be 'x3' or 'f32'")
+    if p not in PRECISIONS:
+        raise ValueError("conv precision must be one of %s" % (PRECISIONS,))
     _PRECISION = p
 
 
@@ -93,6 +100,17 @@ def conv_precision():
 def set_conv_small_grid(mode):
     """0 .. 3, see ttsamd_conv1d_set_small_grid (include/tts_amd.h); returns the previous mode."""
     return int(lib().ttsamd_conv1d_set_small_grid(int(mode)))
+
+
+def _pack_h2(w, c_out, c_in, kernel):
+    """Host image of ttsamd_conv1d_pack_weights_h2 for a contiguous fp32 [c_out, c_in, kernel] weight."""
+    L = lib()
+    L.ttsamd_conv1d_packed_h2_bytes.restype = ctypes.c_size_t
+    nb = L.ttsamd_conv1d_packed_h2_bytes(c_out, c_in, kernel)
+    img = torch.empty(nb, dtype=torch.uint8)
+    check(L.ttsamd_conv1d_pack_weights_h2(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()), c_out, c_in, kernel),
+          "conv1d_pack_weights_h2")
+    return img
 
 
 class PackedConv:
@@ -121,10 +139,14 @@ class PackedConv:
         check(L.ttsamd_conv1d_pack_weights_split(ctypes.c_void_p(split.data_ptr()), ctypes.c_void_p(w.data_ptr()),
                                                  self.c_out, self.c_in, self.kernel), "conv1d_pack_weights_split")
         self.w_split = split.to(device)
+        # the two-part fp16 image of the three-product kernels (tuned shapes only: what the large-grid dispatch can reach)
+        self.w_h2 = None
+        if self.tuned:
+            self.w_h2 = _pack_h2(w, self.c_out, self.c_in, self.kernel).to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
         # square convs of fewer than 32 channels also keep the split image of the weight zero-padded to [32, 32, k]: what the
         # fused ResBlock kernel's 32-channel tile reads (ttsamd_resblock_pair, c = 8 / 16)
-        self.w_split_pad32 = None
+        self.w_split_pad32 = self.w_h2_pad32 = None
         if self.c_out == self.c_in and self.c_out in (8, 16):
             wp = torch.zeros(32, 32, self.kernel, dtype=torch.float32)
             wp[: self.c_out, : self.c_in] = w
@@ -133,6 +155,7 @@ class PackedConv:
             check(L.ttsamd_conv1d_pack_weights_split(ctypes.c_void_p(sp.data_ptr()), ctypes.c_void_p(wp.data_ptr()), 32, 32,
                                                      self.kernel), "conv1d_pack_weights_split")
             self.w_split_pad32 = sp.to(device)
+            self.w_h2_pad32 = _pack_h2(wp, 32, 32, self.kernel).to(device)
 
     def nbytes(self):
         return self.w.numel() * 4 + (0 if self.bias is None else self.bias.numel() * 4)
@@ -173,7 +196,12 @@ def conv1d(pc: PackedConv, x, y, *, t_out=None, c_in_offset=0, in_act=ACT_NONE, 
         a.y2 = y2.data_ptr()
     a.split_row, a.row_bias = split_row, _dp(row_bias)
     # (shapes without a tuned instantiation run on the generic kernel, which is split-bf16 whatever the precision switch says)
-    a.w_split = pc.w_split.data_ptr() if (_PRECISION == "x3" or not pc.tuned or mode == CONV_SHUFFLE and pc.kernel != 2) else None
+    # ... and so does a tuned (k, d) pair in a mode that has no tuned instantiation (a gate conv at k = 3, d = 3 under
+    # precision "f32" reached the generic kernel without its image)
+    untuned_mode = (mode == CONV_SHUFFLE and pc.kernel != 2) or (mode == CONV_GATE and not (pc.kernel in (3, 5) and pc.dilation == 1)) or \
+        (mode not in (CONV_NORMAL, CONV_GATE, CONV_SHUFFLE) and pc.kernel != 1)
+    a.w_split = pc.w_split.data_ptr() if (_PRECISION != "f32" or not pc.tuned or untuned_mode) else None
+    a.w_h2 = pc.w_h2.data_ptr() if (_PRECISION == "h2" and pc.w_h2 is not None and not untuned_mode) else None
     if _TIMER is not None and not torch.cuda.is_current_stream_capturing():
         key = _TIMER.select(pc, a)
         if key is not None:
@@ -202,12 +230,13 @@ class ResblockArgs(ctypes.Structure):
         ("kernel", ctypes.c_int32), ("dilation", ctypes.c_int32),
         ("slope", ctypes.c_float), ("out_div", ctypes.c_float), ("variant", ctypes.c_int32),
         ("w1_bytes", ctypes.c_int64), ("w2_bytes", ctypes.c_int64),
+        ("w1_h2", ctypes.c_void_p), ("w2_h2", ctypes.c_void_p), ("w1_h2_bytes", ctypes.c_int64), ("w2_h2_bytes", ctypes.c_int64),
     ]
 
 
 def resblock_pair_supported(pc1: PackedConv, pc2: PackedConv):
     """True when the fused ResBlock1-iteration kernel covers this conv pair (split-bf16 arithmetic only)."""
-    return (_PRECISION == "x3" and pc1.c_in == pc1.c_out == pc2.c_in == pc2.c_out and pc1.kernel == pc2.kernel
+    return (_PRECISION in ("x3", "h2") and pc1.c_in == pc1.c_out == pc2.c_in == pc2.c_out and pc1.kernel == pc2.kernel
             and pc2.dilation == 1 and bool(lib().ttsamd_resblock_pair_supported(pc1.c_out, pc1.kernel, pc1.dilation)))
 
 
@@ -223,6 +252,9 @@ def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, a
     ws1, ws2 = (pc1.w_split, pc2.w_split) if C >= 32 else (pc1.w_split_pad32, pc2.w_split_pad32)
     a.w1_split, a.bias1, a.w2_split, a.bias2 = ws1.data_ptr(), _dp(pc1.bias), ws2.data_ptr(), _dp(pc2.bias)
     a.w1_bytes, a.w2_bytes = ws1.numel(), ws2.numel()
+    if _PRECISION == "h2":
+        wh1, wh2 = (pc1.w_h2, pc2.w_h2) if C >= 32 else (pc1.w_h2_pad32, pc2.w_h2_pad32)
+        a.w1_h2, a.w2_h2, a.w1_h2_bytes, a.w2_h2_bytes = wh1.data_ptr(), wh2.data_ptr(), wh1.numel(), wh2.numel()
     a.c, a.t, a.batch, a.kernel, a.dilation = C, T, B, pc1.kernel, pc1.dilation
     a.slope, a.out_div, a.variant = slope, out_div, variant
     if _TIMER is not None and not torch.cuda.is_current_stream_capturing():
@@ -401,6 +433,9 @@ def copy_into(dsts, srcs):
     _copy_launch(segs)
 
 
+MASK_MAX_STAGES = 8       # TTSAMD_MASK_MAX_STAGES (include/tts_amd.h)
+
+
 def stage_masks(lengths, scales, t_stage, quantum=1, add=0):
     """One launch for every length mask of a ragged vocoder call -> ([mask_s float [B, t_stage[s]]], len_eff int64 [B]);
     len_eff = lengths // quantum * quantum + add, mask_s[b, t] = t < len_eff[b] * scales[s]   (ttsamd_stage_masks)."""
@@ -408,14 +443,20 @@ def stage_masks(lengths, scales, t_stage, quantum=1, add=0):
     B, n = lengths.shape[0], len(scales)
     flat = torch.empty(B * sum(int(t) for t in t_stage), dtype=torch.float32, device=lengths.device)
     len_eff = torch.empty(B, dtype=torch.int64, device=lengths.device)
-    sc = (ctypes.c_int32 * n)(*[int(v) for v in scales])
-    ts = (ctypes.c_int32 * n)(*[int(v) for v in t_stage])
-    check(lib().ttsamd_stage_masks(P(flat), P(len_eff), P(lengths), B, int(quantum), int(add), sc, ts, n, stream_ptr()),
-          "stage_masks")
-    out, off = [], 0
-    for t in t_stage:
-        out.append(flat[off: off + B * int(t)].view(B, int(t)))
-        off += B * int(t)
+    # the kernel takes up to MASK_MAX_STAGES stages per launch (a generator with more than 7 upsample layers — the reference
+    # accepts any list, hifigan_generator.py:199-233 — needs more): chunks of 8 stages, each recomputing the same len_eff
+    off = 0
+    out = []
+    for s0 in range(0, max(n, 1), MASK_MAX_STAGES):
+        sc_l, ts_l = [int(v) for v in scales[s0:s0 + MASK_MAX_STAGES]], [int(v) for v in t_stage[s0:s0 + MASK_MAX_STAGES]]
+        m = len(sc_l)
+        sc, ts = (ctypes.c_int32 * max(m, 1))(*sc_l), (ctypes.c_int32 * max(m, 1))(*ts_l)
+        part = flat[off:]
+        check(lib().ttsamd_stage_masks(P(part), P(len_eff), P(lengths), B, int(quantum), int(add), sc, ts, m, stream_ptr()),
+              "stage_masks")
+        for t in ts_l:
+            out.append(flat[off: off + B * t].view(B, t))
+            off += B * t
     return out, len_eff
 
 
@@ -543,6 +584,7 @@ class _HostLengths:
     instead of `y_lengths.max().item()` (a reduce kernel + device-to-host copy + a blocking stream synchronise)."""
 
     _tls = threading.local()
+    quarantine = []          # mirrors a stalled kernel may still write (durations() timed out): referenced for the process lifetime
 
     @classmethod
     def take(cls, n):
@@ -573,6 +615,8 @@ def durations(logw, mask, length_scale, glow=False, durations_in=None, t_valid=N
         ylen = torch.empty((B,), dtype=torch.int64, device=dev)
     host = None
     if want_max:
+        if torch.cuda.is_current_stream_capturing():      # the host wait below would poll for ever: nothing runs during a capture
+            raise _lib.TtsAmdError("durations(want_max=True) waits for the device: not valid under stream capture")
         host = _HostLengths.take(B)
         host[1][:] = -1
     # glow: 0 VITS, 1 Glow, 2 Glow ragged-exact
@@ -586,11 +630,16 @@ def durations(logw, mask, length_scale, glow=False, durations_in=None, t_valid=N
     spins = 0
     while int(arr.min()) < 0:
         spins += 1
+        if spins & 0x3F == 0:
+            time.sleep(0)                   # give the GIL away: other request lanes' host threads issue their launches meanwhile
         if spins & 0xFFF == 0:              # a stalled stream must not hang the host for ever: ~ every millisecond look at the clock
             now = time.monotonic()
             if deadline is None:
                 deadline = now + 30.0
             elif now > deadline:
+                # the stalled kernel may still write the mirror later: keep it referenced (never back to the pool, never freed
+                # to the pinned-memory allocator) instead of letting another tensor take its place
+                _HostLengths.quarantine.append(host)
                 raise _lib.TtsAmdError("durations: the device did not publish y_lengths within 30 s (stalled stream?)")
     t_max = int(arr.max())
     if host_out is not None:

@@ -139,10 +139,14 @@ class Lanes:
             st.synchronize()
         for o in self._owned:
             for m in models:
-                for holder in (m, getattr(m, "waveform_decoder", None), getattr(m, "model_g", None)):
+                # a Synthesizer brings its models and its SentencePipeline (whose captured tail is keyed by the lane's stream too)
+                holders = [m, getattr(m, "waveform_decoder", None), getattr(m, "model_g", None), getattr(m, "pipeline", None)]
+                for sub in (getattr(m, "tts_model", None), getattr(m, "vocoder_model", None)):
+                    holders += [sub, getattr(sub, "waveform_decoder", None), getattr(sub, "model_g", None)]
+                for holder in holders:
                     if holder is None:
                         continue
-                    for name in ("_front", "_tail", "_graph"):
+                    for name in ("_front", "_tail", "_graph", "_scratch"):      # graphs first, then the scratch sets they read
                         cache = getattr(holder, name, None)
                         if cache is not None and hasattr(cache, "purge_stream"):
                             cache.purge_stream(o.handle)

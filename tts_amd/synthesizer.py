@@ -81,15 +81,34 @@ class SentencePipeline:
 
         self.tts, self.voc, self.ap_t, self.ap_v = tts_model, vocoder_g, tts_ap, vocoder_ap
         self._graph = graphs.GraphCache(self._tail_eager, max_entries=12)
+        # the captured tail holds raw pointers to BOTH models' weight tensors and reads the acoustic model's per-stream scratch in
+        # place: it is keyed on the models' weight versions (a re-pack — .cuda(), load_checkpoint, a hot swap — drops it) and
+        # registered with the scratch so that evicting a scratch set drops the graphs over it
+        self._weights = None
+        if hasattr(tts_model, "_scratch"):
+            tts_model._scratch.dependents.append(self._graph)
         self._cfg = None
         self.max_frames = 4096
         self.launches = None       # kernel launches of the last captured tail (reported by bench.py)
+        self.last_ctx = None       # request_front's context of a request that did not fit the fused path (handed to inference)
 
     def supported(self):
         return isinstance(self.tts, GlowTTS) and self.tts.use_graphs and self.voc is not None
 
     def clear(self):
         self._graph.clear()
+
+    def purge_stream(self, handle):
+        """Lanes.close: drop the graphs captured for a request lane that is being torn down."""
+        self._graph.purge_stream(handle)
+
+    def _check_weights(self):
+        v = (getattr(self.tts, "weights_version", 0), getattr(self.voc, "weights_version", 0))
+        if v != self._weights:
+            if self._weights is not None:
+                self._graph.clear()
+            self._weights = v
+        return v
 
     def _tail_eager(self, o_mean, o_logs, cum, x_mask, y_lengths, noise, g):
         from . import ops
@@ -110,15 +129,19 @@ class SentencePipeline:
         from . import ops
 
         tts = self.tts
+        wv = self._check_weights()
         ctx = tts.request_front(x, dict(aux_input or {}, no_graph=True) if eager else aux_input)
         B, t_dec = ctx["B"], ctx["t_dec"]
         t_pad = -(-t_dec // 32) * 32
         if not ((ctx["graphing"] or eager) and (B == 1 or ctx["ragged"]) and B * t_pad <= self.max_frames):
+            # too large for the fused path: the caller continues from the front end that has already run (no second encoder /
+            # duration-predictor pass, no second host wait)
+            self.last_ctx = ctx
             return None
         t_pad, inputs, stable = tts.tail_inputs(ctx, aux_input)
         self._cfg = (t_pad, float(tts.inference_noise_scale))
         self._graph.enabled = not eager
-        wav = self._graph(*inputs, key=self._cfg, stable=stable)
+        wav = self._graph(*inputs, key=self._cfg + wv, stable=stable)
         nsq, pad = tts.num_squeeze, self.voc.inference_padding
         hop = wav.shape[-1] // (t_pad + 2 * pad)
         lens = [((n // nsq) * nsq + 2 * pad) * hop for n in ctx["y_lengths_host"]]
@@ -270,12 +293,16 @@ class Synthesizer:
         sr_v = _get(_get(self.vocoder_config, "audio", {}), "sample_rate", 22050) if self.vocoder_config is not None else sr_t
         do_trim = trim and bool(_get(_get(self.tts_config, "audio", {}), "do_trim_silence", False))
         if self.pipeline is not None and self.pipeline.supported() and sr_t == sr_v:
+            self.pipeline.last_ctx = None
             fused = self.pipeline(x.to(dev), aux)           # acoustic model -> seam -> vocoder without leaving the device
             if fused is not None:
                 wav, lens = fused
                 wav = wav.float().cpu().numpy().reshape(len(ids), -1)
                 res = [wav[r, : int(lens[r])] for r in range(len(ids))]
                 return [w[: self.tts_model.ap.find_endpoint(w)] for w in res] if do_trim else res
+            if self.pipeline.last_ctx is not None:          # a large batch: the front end has run, inference continues from it
+                aux = dict(aux, _front_ctx=self.pipeline.last_ctx)
+                self.pipeline.last_ctx = None
         out = self.tts_model.inference(x.to(dev), aux)
         frames = out["y_lengths"]
         if self.vocoder_model is None:

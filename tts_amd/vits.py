@@ -110,6 +110,8 @@ class Vits:
         # the unpadded run bit for bit (as long as padding does not move a launch across the small-grid threshold of
         # ttsamd_conv1d_set_small_grid, where the fp32 summation order changes).
         self._tail = graphs.GraphCache(self._tail_eager, max_entries=12)
+        self._scratch.dependents += [self._front, self._tail]      # evicting a scratch set drops the graphs that read it in place
+        self.weights_version = 0                                   # bumped by every re-pack
         self._tail_cfg = None
         self.graph_tail_max_frames = 2048      # B * padded frames up to which the tail is captured
         self.text_bucket = 16                  # token-axis padding of graphed requests (1 = off): 16 lengths share a capture
@@ -161,6 +163,7 @@ class Vits:
         # captured graphs hold raw pointers to the weight tensors replaced below: drop them first
         self._front.clear()
         self._tail.clear()
+        self.weights_version += 1
         self.text_encoder = layers.TextEncoder(sd, "text_encoder.", dev, a.hidden_channels, a.num_layers_text_encoder,
                                                a.num_heads_text_encoder, a.kernel_size_text_encoder)
         spk = self.embedded_speaker_dim
