@@ -215,12 +215,12 @@ def pmc_state(name):
             else "null: committed PMC file is stale (recorded with stamp %s, running %s)" % (d.get("code_stamp"), code_stamp()))
 
 
-def pmc_traffic_live(precision, kernel_sub, timeout_s=150):
-    """HBM bytes per launch of the dominant kernel instantiation measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE,
-    then WRITE_SIZE — one counter set per pass, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a child process
-    that launches the kernel at its two headline shapes (scripts/pmc_dominant_target.py).  Corrections of the same guide:
-    both counters are KiB; FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (x2).
-    -> (bytes per launch or None, description)."""
+def pmc_passes(target_argv, match, timeout_s=200):
+    """Two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE — one counter set per pass, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a child process `python target_argv...`; per counter the sum over the
+    dispatches whose kernel name contains one of `match` (spaces stripped) and their count.  Corrections of the same guide are
+    applied by the callers: both counters are KiB; FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (x2).
+    -> ({counter: (sum, dispatches)}, None) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -235,24 +235,34 @@ def pmc_traffic_live(precision, kernel_sub, timeout_s=150):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
-            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
-                                os.path.join(ROOT, "scripts", "pmc_dominant_target.py"), precision],
+            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable] + list(target_argv),
                                capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, env=env)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc=%d)" % (ctr, r.returncode)
             per = {}
             for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == ctr and kernel_sub in row["Kernel_Name"].replace(" ", ""):
+                name = row["Kernel_Name"].replace(" ", "")
+                if row["Counter_Name"] == ctr and any(m in name for m in match):
                     per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
             if not per:
-                return None, "no dispatch of %s in the counter file" % kernel_sub
-            vals[ctr] = (sum(per.values()) / len(per), len(per))
+                return None, "no dispatch of %s in the counter file" % (match,)
+            vals[ctr] = (sum(per.values()), len(per))
     except Exception as e:          # the measurement is an extra: never cost the bench line
         return None, "%s: %s" % (type(e).__name__, e)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return vals, None
+
+
+def pmc_traffic_live(precision, kernel_sub, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel instantiation measured IN THIS RUN (pmc_passes over
+    scripts/pmc_dominant_target.py: the kernel at its two headline shapes).  -> (bytes per launch or None, description)."""
+    vals, why = pmc_passes([os.path.join(ROOT, "scripts", "pmc_dominant_target.py"), precision], [kernel_sub], timeout_s)
+    if vals is None:
+        return None, why
+    fetch = vals["FETCH_SIZE"][0] / vals["FETCH_SIZE"][1] * 1024 * 2
+    write = vals["WRITE_SIZE"][0] / vals["WRITE_SIZE"][1] * 1024
     return fetch + write, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over %d launches of the kernel at "
                            "its two headline shapes; fetch %.4g B (KiB x1024 x2, gfx950 correction) + write %.4g B per launch"
                            % (vals["FETCH_SIZE"][1], fetch, write))
@@ -594,6 +604,19 @@ def wl_glow_hifigan_v2(args, ctx):
         t1_ = time.perf_counter()
         step().cpu()
         lat.append((time.perf_counter() - t1_) * 1e3)
+    # GPU time of a sentence (first kernel start to last kernel end on the request's stream), LAST: timing events put the queue
+    # into profiling mode for the rest of the process (see _run).  step time ~ GPU time: the loop is bound by the sentence's
+    # kernel chain; step time >> GPU time: by the host / dispatch path — the two readings of a "slow mode" on another box.
+    gpu_ms = []
+    for _ in range(min(args.steps, 30)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        step()
+        e1.record()
+        torch.cuda.synchronize()
+        gpu_ms.append(e0.elapsed_time(e1))
+    gpu_ms.sort()
     samples = wav.shape[-1]
     elapsed_max, total = ctx.max(elapsed), ctx.sum(samples)
     if ctx.rank != 0:
@@ -608,6 +631,14 @@ def wl_glow_hifigan_v2(args, ctx):
                      warmup_steps_run=nw, step_ms_p50=deltas[len(deltas) // 2], step_ms_max=deltas[-1],
                      frames=int(wav.shape[-1] // 256 - 10))
     line["rtf_x"] = value / SAMPLE_RATE
+    p50 = deltas[len(deltas) // 2]
+    g50 = gpu_ms[len(gpu_ms) // 2]
+    line["observed"] = {"step_ms_p50": p50, "step_ms_p90": deltas[int(len(deltas) * 0.9)], "step_ms_max": deltas[-1],
+                        "sentence_latency_ms_p50": float(sorted(lat)[len(lat) // 2]), "gpu_ms_per_sentence_p50": g50,
+                        "warmup_steps_run": nw,
+                        # which regime this process ran in (1.47 ms in some processes / boxes, 1.85 in others)
+                        "mode": ("kernel-chain-bound" if p50 <= 1.12 * g50 else "host/dispatch-bound") +
+                                (", fast" if p50 < 1.6 else ", SLOW")}
     # 20.4 GFLOP per sentence (FlopCounter on the reference modules); a B=1 sentence is launch/latency-bound
     # on this chip, the fraction is reported for completeness
     ach = 20.4e9 * args.steps * ctx.world / elapsed_max / 1e12
@@ -716,12 +747,30 @@ def wl_hifigan_v1(args, ctx):
     # the MRF branches run on three HIP streams here, so per-launch event times overlap; the aggregate is priced
     # on the wall clock of the timed region instead (a lower bound on the conv kernels' own rate)
     ach = r["flops"] / elapsed_max / 1e12
+    # HBM traffic of one step, measured in this run: the PMC passes run the generator on ONE 4-item slab in a child process
+    # (scripts/pmc_hifigan_target.py: every conv / fused-pair / conv_post dispatch counted) and the bytes per output sample
+    # are scaled to the step; next to it the layer-by-layer algorithmic figure of SURVEY §8(d) (21 237 B per sample)
+    traffic, traffic_note, per_sample = None, "skipped (--no-live-pmc)", None
+    if ctx.world == 1 and not args.no_live_pmc:
+        pm_items, pm_frames = 4, args.frames
+        vals, why = pmc_passes([os.path.join(ROOT, "scripts", "pmc_hifigan_target.py"), args.precision, str(pm_items), str(pm_frames)],
+                               ["conv1d_", "resblock_pair_", "conv_post_kernel", "replicate_pad"], timeout_s=300)
+        if vals is None:
+            traffic_note = why
+        else:
+            runs = 2                                           # the target runs the slab twice (both runs counted)
+            slab_samples = float(pm_items * (pm_frames + 10) * 256)
+            per_sample = (vals["FETCH_SIZE"][0] * 1024 * 2 + vals["WRITE_SIZE"][0] * 1024) / runs / slab_samples
+            traffic = per_sample * samples / ctx.world
+            traffic_note = ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over every conv / "
+                            "fused-pair / conv_post dispatch (%d per slab) of a %d-item x %d-frame slab, %.0f B per output sample, scaled "
+                            "to the step's samples" % (vals["FETCH_SIZE"][1] // runs, pm_items, pm_frames, per_sample))
     line["roofline"] = {"bound": "mfma", "kernel": "all conv launches of the generator (%s)" % conv_kernel_name(args.precision, "..."),
                         "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
                         "frac": ach / conv_peak(args.precision),
-                        "traffic": load_pmc("pmc_hifigan_v1_%s_resblock.json" % args.precision),
-                        "traffic_source": pmc_state("pmc_hifigan_v1_%s_resblock.json" % args.precision) +
-                                          "; HBM bytes per launch of the fused ResBlock kernels, 16-item slab",
+                        "traffic": traffic, "traffic_source": traffic_note,
+                        "traffic_bytes_per_sample": per_sample, "algorithmic_bytes_per_sample": r["bytes"] / (samples / ctx.world * steps),
+                        "algorithmic_bytes_per_sample_layer_by_layer": 21237.0,
                         "algorithmic_gbps": r["bytes"] / elapsed_max / 1e9, "launches_timed": r["launches"],
                         "measured": "algorithmic conv FLOP of the timed steps / wall time of the timed region",
                         "hbm_subset_best_frac_of_8TBps": max([v["frac_of_8TBps"] for v in sub.values()] or [0.0])}
@@ -801,6 +850,82 @@ def wl_mas(args, ctx):
         line["cpu_baseline"] = {"value": c32 / dt, "unit": "cells/s", "cores": 1, "kind": "port",
                                 "sample": "first %d items of the same problem, C restatement of core.pyx (single thread, as "
                                           "the reference ships it)" % nb}
+    return line
+
+
+def wl_vits_b1(args, ctx):
+    """One VITS request at a time — the reference's real call pattern (TTS/utils/synthesizer.py:384: one sentence per
+    `synthesis()` call): 257 ids -> 770 frames -> 197 120 samples (8.94 s of audio), VitsArgs defaults, SDP run.  A step is one
+    request; `value` = p50 wall time of a request with the waveform left on the device (host returns when the GPU is done);
+    also reported: with the waveform copied to the host, and requests/s with two requests in flight (tts_amd.parallel.Lanes)."""
+    from tts_amd import _lib, parallel
+    from tts_amd import synthetic as W
+    from tts_amd.vits import Vits
+    import ctypes
+
+    dev = ctx.dev
+    sd, _, _ = ctx.broadcast_weights(lambda: W.make_vits_state({}, seed=1234))
+    model = Vits({"model_args": {}})
+    model.load_state_dict(sd)
+    model.to(dev)
+    x, xl, dur = synthetic_batch(1, args.chars, seed=ctx.rank, device=dev)
+    aux = {"x_lengths": xl, "durations": dur, "run_duration_predictor": True}
+    _lib.lib().ttsamd_launch_count.restype = ctypes.c_uint64
+    eager = dict(aux, no_graph=True)
+    model.inference(x, eager)
+    torch.cuda.synchronize()
+    n0 = int(_lib.lib().ttsamd_launch_count())
+    model.inference(x, eager)
+    torch.cuda.synchronize()
+    launches = int(_lib.lib().ttsamd_launch_count()) - n0
+    tw, nw = time.perf_counter(), 0
+    while nw < max(args.warmup, 4) or time.perf_counter() - tw < 0.5:
+        model.inference(x, aux)
+        nw += 1
+    ctx.fence()
+    dev_ms, host_ms = [], []
+    t_all = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        out = model.inference(x, aux)
+        torch.cuda.synchronize()
+        dev_ms.append((time.perf_counter() - t0) * 1e3)
+    ctx.fence()
+    elapsed = time.perf_counter() - t_all
+    for _ in range(min(args.steps, 30)):
+        t0 = time.perf_counter()
+        model.inference(x, aux)["model_outputs"].cpu()
+        host_ms.append((time.perf_counter() - t0) * 1e3)
+    lanes = parallel.Lanes(2, device=dev, priority=-1)
+    for _ in range(6):
+        lanes.run(model.inference, x, aux)
+    lanes.sync()
+    n = max(args.steps, 40)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        lanes.run(model.inference, x, aux)
+    lanes.sync(timeout_s=60.0)
+    lane_ms = (time.perf_counter() - t0) / n * 1e3
+    lanes.close([model])
+    samples = int(out["y_mask"].sum().item()) * 256
+    dev_ms.sort()
+    host_ms.sort()
+    if ctx.rank != 0:
+        return None
+    p50 = dev_ms[len(dev_ms) // 2]
+    line = base_line(args, ctx, "VITS single request latency, p50 ms (257 ids -> 197 120 samples, waveform on the device)", p50, "ms",
+                     ctx.max(elapsed), "VITS B=1 request (the reference's call pattern, synthesizer.py:384): 128 chars = 257 ids, "
+                     "770 frames, %d samples" % samples, DTYPE[args.precision], higher=False)
+    line["rtf_x"] = samples / SAMPLE_RATE / (p50 * 1e-3)
+    line["observed"] = {"request_ms_p50": p50, "request_ms_p90": dev_ms[int(len(dev_ms) * 0.9)], "request_ms_min": dev_ms[0],
+                        "request_ms_max": dev_ms[-1], "request_ms_p50_waveform_on_host": host_ms[len(host_ms) // 2],
+                        "two_lanes_ms_per_request": lane_ms, "two_lanes_requests_per_s": 1e3 / lane_ms,
+                        "launches_per_request": launches, "warmup_steps_run": nw}
+    ach = 488.8e9 / (p50 * 1e-3) / 1e12            # SURVEY §8(d): 488.8 GFLOP per utterance
+    line["roofline"] = {"bound": "mfma", "kernel": "whole request at B=1 (%d kernel launches): latency-bound on the small-grid kernels" % launches,
+                        "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s", "frac": ach / conv_peak(args.precision),
+                        "traffic": None, "launches_per_request": launches}
+    del model
     return line
 
 
@@ -923,7 +1048,7 @@ def wl_launch_check(args, ctx):
 
 
 WORKLOADS = {"vits_e2e": wl_vits_e2e, "glow_hifigan_v2": wl_glow_hifigan_v2, "hifigan_v1": wl_hifigan_v1, "mas": wl_mas,
-             "xtts_stream": wl_xtts_stream, "launch_check": wl_launch_check}
+             "xtts_stream": wl_xtts_stream, "vits_b1": wl_vits_b1, "launch_check": wl_launch_check}
 
 
 def main():
@@ -1017,7 +1142,10 @@ def _run(args):
         for name, extra_args in (("configs[0] glow_hifigan_v2", ["--workload", "glow_hifigan_v2", "--steps", "200", "--warmup", "5"]),
                                  ("configs[2] hifigan_v1", ["--workload", "hifigan_v1", "--steps", str(args.hifigan_steps or 1),
                                                             "--warmup", str(1 if args.hifigan_warmup is None else args.hifigan_warmup),
-                                                            "--items", str(args.items), "--frames", str(args.frames)])):
+                                                            "--items", str(args.items), "--frames", str(args.frames)] +
+                                  (["--no-live-pmc"] if args.no_live_pmc else [])),
+                                 ("vits_b1 single request", ["--workload", "vits_b1", "--steps", "100", "--warmup", "5", "--no-cpu-baseline"]),
+                                 ("configs[4] xtts_stream (vocoder half)", ["--workload", "xtts_stream", "--steps", "5", "--warmup", "2"])):
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra_args + common, capture_output=True, text=True,
                                    timeout=600, cwd=ROOT)
@@ -1038,7 +1166,7 @@ def _run(args):
             print(json.dumps({"extra_workload": name, "line": compact_line(extra)}), flush=True)
         if extras:
             line["other_configs"] = {name.split()[0]: {k: (float("%.5g" % v) if isinstance(v, float) else v) for k, v in (
-                ("ms_per_step", e.get("ms_per_step")), ("value", e.get("value")), ("unit", e.get("unit")),
+                ("ms_per_step", e.get("ms_per_step") if e.get("unit") != "ms" else None), ("value", e.get("value")), ("unit", e.get("unit")),
                 ("roofline_frac", (e.get("roofline") or {}).get("frac")),
                 ("cpu_baseline_value", (e.get("cpu_baseline") or {}).get("value")), ("error", e.get("error"))) if v is not None}
                 for name, e in extras}
@@ -1054,8 +1182,9 @@ def emit_details(ctx):
 
 
 HEADLINE_MAX_BYTES = 2300
-EXTRA_MAX_BYTES = 800
-_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_8TBps", "frac_of_157TF", "traffic",
+EXTRA_MAX_BYTES = 900
+_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_8TBps", "frac_of_157TF", "traffic", "traffic_bytes_per_sample",
+              "algorithmic_bytes_per_sample",
               "pmc_mfma_busy_frac", "pmc_kernel_cycles", "launches_timed", "avg_launch_us", "algorithmic_bytes_per_launch",
               "all_conv_launches", "hbm_subset_best_frac_of_8TBps", "traffic_source", "launches_per_request")
 _CPU_KEEP = ("value", "unit", "cores", "kind", "host_cores", "reps", "value_min", "value_max", "batched_x_lengths_mode", "sample")
@@ -1079,6 +1208,8 @@ def compact_line(line, limit=EXTRA_MAX_BYTES):
     cfg = dict(line.get("config", {}))
     cfg.pop("weights", None)
     out["config"] = cfg
+    if "observed" in line:                  # step / request percentiles and the regime the process ran in: numbers, always kept
+        out["observed"] = line["observed"]
     if "roofline" in line:
         out["roofline"] = {k: line["roofline"][k] for k in _ROOF_KEEP if k in line["roofline"]}
     if "cpu_baseline" in line:
@@ -1089,6 +1220,9 @@ def compact_line(line, limit=EXTRA_MAX_BYTES):
     out["dtype"] = str(out.get("dtype", ""))[:4].strip()
     out["metric"] = str(out["metric"])[:80]
     out["config"] = {"workload": str(cfg.get("workload", ""))[:60]}
+    for k in ("p50_later_chunk_ms", "reference_schedule_p50_first_ms"):       # the streaming line's second numbers
+        if k in cfg:
+            out.setdefault("observed", {})[k] = _round(cfg[k])
     for path in (("cpu_baseline", "sample"), ("roofline", "traffic_source"), ("roofline", "kernel"), ("roofline", "all_conv_launches"),
                  ("cpu_baseline", "batched_x_lengths_mode"), ("roofline", "algorithmic_bytes_per_launch"), ("cpu_baseline", "host_cores"),
                  ("data",), ("scaling",), ("vs_baseline",), ("higher_is_better",)):

@@ -441,3 +441,67 @@ def test_stream_scratch_eviction_drops_dependent_graphs(monkeypatch):
     assert len(dep.purged) == n + 1 and all(k[0] == 8 for k in sc.sets)
     sc.clear()
     assert not sc.sets
+
+
+def test_host_pack_code_and_mas_oracle_under_sanitizers(tmp_path):
+    """SURVEY.md §5's sanitizer pass: the host-side pack / policy translation unit of libtts_amd (tts_amd/csrc/pack_host.cpp: plain
+    C++, the same source the library links) and the C restatement of maximum_path_c (oracle/mas_oracle.c), built with
+    -fsanitize=address,undefined (no recovery) around tests/native/sanitize_driver.cpp and run here: exactly-sized heap buffers for
+    every image, awkward shapes, zero / denormal / huge rows, the policy queries over their whole argument range, ragged MAS
+    problems.  (The dispatchers' argument checks live in HIP translation units together with device code and are exercised by
+    the GPU suite instead.)"""
+    import shutil
+    import subprocess
+
+    cxx = next((c for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("g++") or "", shutil.which("c++") or "") if c and os.path.exists(c)), None)
+    cc = next((c for c in ("/opt/rocm/lib/llvm/bin/clang", shutil.which("gcc") or "", shutil.which("cc") or "") if c and os.path.exists(c)), None)
+    if cxx is None or cc is None:
+        pytest.skip("no host compiler")
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+    obj = str(tmp_path / "mas_oracle.o")
+    r = subprocess.run([cc] + san + ["-c", os.path.join(ROOT, "oracle", "mas_oracle.c"), "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exe = str(tmp_path / "sanitize_driver")
+    r = subprocess.run([cxx, "-std=c++17"] + san + [os.path.join(ROOT, "tests", "native", "sanitize_driver.cpp"),
+                                                    os.path.join(ROOT, "tts_amd", "csrc", "pack_host.cpp"), obj, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "sanitize_driver: ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_h2_weight_image_matches_a_numpy_restatement():
+    """ttsamd_conv1d_pack_weights_h2 against numpy: per-row power-of-two scale (row maximum in [2^13, 2^14)), hi = float16(w s),
+    lo = float16((w s - hi) 2^11) with numpy's round-to-nearest-even conversions (denormal halves included), fragment order
+    [m-tile][chunk][tap][part][lane][8], row table {2^e, 2^-e}, max_row_exp."""
+    import numpy as np
+    import torch
+
+    from tts_amd import ops
+
+    rng = np.random.default_rng(3)
+    for co, ci, k in ((64, 32, 3), (40, 20, 7), (32, 16, 1)):
+        w = (rng.standard_normal((co, ci, k)) * 10.0 ** rng.uniform(-6, 1, (co, 1, 1))).astype(np.float32)
+        w[1] = 0.0
+        w[2, 1:, :] *= 1e-5                                        # next to the row maximum: high and low parts in fp16's denormal range
+        img = ops._pack_h2(torch.from_numpy(w).contiguous(), co, ci, k).numpy()
+        mt, nch = (co + 31) // 32, (ci + 15) // 16
+        mx = np.abs(w).reshape(co, -1).max(1)
+        e = np.where(mx > 0, 13 - np.floor(np.log2(np.maximum(mx, 1e-45))), 0.0).astype(np.int64)
+        ws = np.ldexp(w.astype(np.float64), e[:, None, None]).astype(np.float32)
+        hi = ws.astype(np.float16)
+        lo = ((ws - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        want = np.zeros((mt * nch * k + 2, 2, 64, 8), np.float16)
+        for part, p in enumerate((hi, lo)):
+            pad = np.zeros((mt * 32, nch * 16, k), np.float16)
+            pad[:co, :ci] = p
+            a = pad.reshape(mt, 32, nch, 2, 8, k).transpose(0, 2, 5, 3, 1, 4)          # (mt, c, tap, h, r, i)
+            want[: mt * nch * k, part] = a.reshape(mt * nch * k, 64, 8)
+        nfrag = want.size * 2
+        assert np.array_equal(img[:nfrag].view(np.uint16), want.reshape(-1).view(np.uint16))
+        hdr = img[nfrag:nfrag + 16].view(np.int32)
+        tab = img[nfrag + 16:].view(np.float32).reshape(-1, 2)
+        assert hdr[0] == int(e.max()) and tab.shape[0] == mt * 32
+        assert np.array_equal(tab[:co, 0], np.ldexp(1.0, e).astype(np.float32)) and np.array_equal(tab[:co, 1], np.ldexp(1.0, -e).astype(np.float32))
+        assert np.all(tab[co:] == 1.0)

@@ -31,11 +31,11 @@ def _newer(target, deps):
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     objs, jobs = [], []
     for s in srcs:
-        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
             jobs.append((s, o))

@@ -22,6 +22,7 @@
 // class as the reference's fp32 CPU conv; only the summation order differs.
 #pragma once
 #include "common.h"
+#include "pack_layout.h"
 
 namespace ttsamd {
 
@@ -29,7 +30,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4s = __attribute__((ext_vector_type(4))) float;
 using f32x2u = __attribute__((ext_vector_type(2), aligned(4))) float;   // 8-byte vector at 4-byte alignment
 
-constexpr int kConvCK = 16;  // input channels per LDS chunk (8 channel pairs)
+// kConvCK = 16 input channels per LDS chunk (8 channel pairs): pack_layout.h
 constexpr int kConvOob = kBufOob;
 
 struct ConvTileCfg {

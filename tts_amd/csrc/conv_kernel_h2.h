@@ -37,24 +37,9 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2v = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2v = __attribute__((ext_vector_type(2))) float;
 
-constexpr int kH2GroupBytes = 2 * 64 * 16;      // one (chunk, tap) group of the weight image: 2 parts x 64 lanes x 16 bytes
 constexpr int kH2TargetExp = 12;                // a chunk maximum is scaled into [2^12, 2^13) when the running exponent is set
 constexpr int kH2LimitExp = 15;                 // ... and the exponent is renewed when a chunk maximum would reach 2^15
 constexpr int kH2FoldMaxExp = 60;               // residual folded into the accumulators only while activation + row exponent <= 60
-
-// header of the row table that follows the fragment groups of an h2 weight image
-struct H2RowTable {
-    int max_row_exp;        // largest row exponent of the image
-    int pad[3];
-    // then per packed row (mtiles * 32): float scale = 2^e_row, float unscale = 2^-e_row
-};
-
-__host__ __device__ inline size_t conv_h2_table_offset(int c_out, int c_in, int kernel)
-{
-    const size_t mtiles = (size_t)(c_out + 31) / 32;
-    const size_t nchunks = (size_t)(c_in + kConvCK - 1) / kConvCK;
-    return (mtiles * nchunks * kernel + 2) * kH2GroupBytes;     // + two zero groups of prefetch slack
-}
 
 template <int K, int D, int MI, int NI, int WM, int WN>
 struct ConvGeomH2 {
@@ -366,6 +351,12 @@ int conv1d_h2_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     if (mtiles % 4 == 0) return conv1d_h2_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
     if (mtiles % 2 == 0) return conv1d_h2_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);
     return conv1d_h2_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
+}
+
+template <int K, int D, int MODE>
+int conv1d_h2_launch_mid(const ttsamd_conv1d_args &a, hipStream_t st)
+{
+    return conv1d_h2_launch_cfg<K, D, 1, 2, 4, 1, MODE>(a, st);
 }
 
 }  // namespace ttsamd

@@ -38,6 +38,8 @@ extern long g_conv_small_grid_blocks;       // conv.hip (default 128): up to thi
 #define kConvSmallGridBlocks g_conv_small_grid_blocks
 constexpr long kConvWaveTileBlocks = 1024;  // up to this many 32x32 tiles those kernels run a wave per tile and K slice
 extern int g_conv_small_grid;               // conv.hip: 0 = off, 1 = small tiles, 2 = + K-split groups, 3 = + conv_kernel_x3s.h kernels, 4 = + conv_kernel_x3o.h (default)
+extern long g_conv_h2_mid_min;              // conv.hip (default 48): from this many 128x128-class blocks up to the small-grid limit a NORMAL conv
+                                            // with the two-part fp16 image takes the three-product kernel on 128 x 64 tiles (TTSAMD_H2_MID_MIN)
 }
 #ifndef TTSAMD_X3_PLANAR
 #define TTSAMD_X3_PLANAR 1
@@ -413,6 +415,8 @@ template <int K, int D, int MODE>
 bool conv1d_x3o_launch(const ttsamd_conv1d_args &a, hipStream_t st, int *rc);   // conv_kernel_x3o.h
 template <int K, int D, int MODE>
 int conv1d_h2_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st);        // conv_kernel_h2.h
+template <int K, int D, int MODE>
+int conv1d_h2_launch_mid(const ttsamd_conv1d_args &a, hipStream_t st);          // conv_kernel_h2.h: 128 rows x 64 columns per block
 
 template <int K, int D, int MODE>
 int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
@@ -441,6 +445,13 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
                   (D == 1 && K <= 7 && (MODE == TTSAMD_CONV_GATE || MODE == TTSAMD_CONV_RES_SKIP || MODE == TTSAMD_CONV_COUPLE))) {
         const long tiles_n = (a.t_out + 127) / 128;
         const long blocks_default = tiles_n * ((mtiles + 3) / 4) * a.batch;      // 128x128-class blocks
+        if constexpr (MODE == TTSAMD_CONV_NORMAL) {
+            // Mid-size grids (one utterance's 256-channel decoder stage: 98 of the 128x128-class blocks): too few blocks for the
+            // large-grid tile, long enough reductions that the K-split small-grid tiles pay six products per output — the
+            // three-product kernel on 128-row x 64-column blocks (twice the blocks, half the serial chain of the 128x128 tile)
+            if (a.w_h2 && g_conv_small_grid && mtiles % 4 == 0 && blocks_default >= g_conv_h2_mid_min && blocks_default <= kConvSmallGridBlocks)
+                return conv1d_h2_launch_mid<K, D, MODE>(a, st);
+        }
         if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks) {
             // mode 4 (default), first choice: the one-shot kernels of conv_kernel_x3o.h (every K slice its own wave, the whole
             // reduction in flight at once, the epilogue spread over four waves)

@@ -3,24 +3,6 @@
 
 using namespace ttsamd;
 
-extern "C" int ttsamd_resblock_pair_supported(int c, int kernel, int dilation)
-{
-    return (c == 8 || c == 16 || c == 32 || c == 64 || c == 128) && (kernel == 3 || kernel == 7 || kernel == 11) &&
-           (dilation == 1 || dilation == 3 || dilation == 5);
-}
-
-extern "C" size_t ttsamd_resblock_weight_bytes(int c, int kernel)
-{
-    const int cc = c < 32 ? 32 : c;
-    return ttsamd_conv1d_packed_split_bytes(cc, cc, kernel);
-}
-
-extern "C" size_t ttsamd_resblock_weight_h2_bytes(int c, int kernel)
-{
-    const int cc = c < 32 ? 32 : c;
-    return ttsamd_conv1d_packed_h2_bytes(cc, cc, kernel);
-}
-
 extern "C" int ttsamd_resblock_pair(const ttsamd_resblock_args *args, void *stream)
 {
     TTSAMD_CHECK_ARG(args, "resblock_pair: NULL args");
