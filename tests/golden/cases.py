@@ -49,6 +49,56 @@ def hifigan_untuned(impl):
     return {"wav": o}
 
 
+HIFIGAN_TRAINED_LIKE = dict(W.HIFIGAN_V1, upsample_initial_channel=256)
+
+
+def trained_like_hifigan_state(cfg, seed):
+    """Stand-in for a released checkpoint (unreachable offline): seeded weights re-scaled the way training leaves them — weight-norm
+    gains `g` spread over 1e-2 .. 1e1 per output channel in every ResBlock's first conv, the following conv's input columns carrying
+    the inverse factor (leaky ReLU is positively homogeneous, so the network function is unchanged while the intermediate tensors
+    span three decades per tile and the second conv's weight rows mix magnitudes 1e-1 .. 1e2), and mel channels spanning
+    1e-5 .. 1e2 with conv_pre's columns compensating.  Returns (state_dict, per-mel-channel input scale)."""
+    sd = O.make_hifigan_state(cfg, 80, seed=seed)
+    gen = _g(seed + 1)
+    g0, v1 = "parametrizations.weight.original0", "parametrizations.weight.original1"
+    nk = len(cfg["resblock_kernel_sizes"])
+    for blk in range(len(cfg["upsample_factors"]) * nk):
+        for m in range(3):
+            a, b = "resblocks.%d.convs1.%d." % (blk, m), "resblocks.%d.convs2.%d." % (blk, m)
+            c = sd[a + g0].shape[0]
+            s = 10.0 ** (torch.rand(c, generator=gen) * 3.0 - 2.0)                 # 1e-2 .. 1e1 per channel
+            sd[a + g0] = sd[a + g0] * s.view(c, 1, 1)
+            sd[a + "bias"] = sd[a + "bias"] * s
+            v = sd[b + v1]
+            ratio = sd[b + g0] / v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)
+            v = v / s.view(1, c, 1)
+            sd[b + v1] = v
+            sd[b + g0] = ratio * v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)  # same effective weight, columns / s
+    sx = 10.0 ** (torch.rand(80, generator=gen) * 7.0 - 5.0)                        # mel channels: 1e-5 .. 1e2
+    v = sd["conv_pre." + v1]
+    ratio = sd["conv_pre." + g0] / v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)
+    v = v / sx.view(1, 80, 1)
+    sd["conv_pre." + v1] = v
+    sd["conv_pre." + g0] = ratio * v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)
+    return sd, sx
+
+
+def hifigan_trained_like(impl):
+    """See trained_like_hifigan_state; 2 x 130 frames so that the 128-, 64- and 32-channel stages run on the large-grid
+    (three-product) kernels of the GPU path (tests/test_hifigan_gpu.py)."""
+    cfg = dict(HIFIGAN_TRAINED_LIKE)
+    sd, sx = trained_like_hifigan_state(cfg, 77)
+    x = torch.randn(2, 80, 130, generator=_g(5)) * sx.view(1, 80, 1)
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        with torch.no_grad():
+            o = RM.hifigan(sd, cfg, 80).inference(x)
+    else:
+        o = O.hifigan_inference(sd, "", x, cfg)
+    return {"wav": o}
+
+
 VITS_SMALL = dict(upsample_initial_channel_decoder=64)
 
 
@@ -199,6 +249,7 @@ CASES = {
     "hifigan_small_rb1": lambda impl: hifigan_small(impl, "1"),
     "hifigan_small_rb2": lambda impl: hifigan_small(impl, "2"),
     "hifigan_untuned": hifigan_untuned,
+    "hifigan_trained_like": hifigan_trained_like,
     "vits_small_sdp": lambda impl: vits_small(impl, True),
     "vits_small_dp": lambda impl: vits_small(impl, False),
     "vits_small_spk_emb": lambda impl: vits_small_speaker(impl, "emb"),

@@ -231,3 +231,40 @@ def test_hifigan_with_untuned_kernel_sizes_dilations_and_upsamplers(gpu):
     rag = m.inference(x.to(gpu), lengths=lens.to(gpu))
     one = m.inference(x[1:2, :, :21].to(gpu))
     assert _errs(rag[1:2, :, : (21 + 10) * 48], one)[1] < 2e-6
+
+
+@pytest.mark.parametrize("precision", ["h2", "x3", "f32"])
+def test_hifigan_trained_like_weights_match_the_reference_golden(gpu, precision):
+    """Stand-in for the released checkpoints (unreachable offline): weight-norm gains spread over 1e-2 .. 1e1 per
+    channel, intermediate tensors spanning three decades inside a tile, conv weight rows mixing magnitudes 1e-1 .. 1e2, mel channels
+    from 1e-5 to 1e2 (tests/golden/cases.py: trained_like_hifigan_state) — against the REFERENCE module's own output
+    (tests/golden/hifigan_trained_like.npz, made by make_golden.py from TTS/vocoder/models/hifigan_generator.py) on every conv
+    arithmetic: the three-product fp16 kernels (the 128-, 64- and 32-channel stages of this 2 x 130-frame batch run on them), the
+    six-product bf16 kernels, the fp32-input MFMA kernels; and the unscaled twin of the same network (leaky ReLU is positively
+    homogeneous: same function) as a second witness."""
+    import numpy as np
+
+    from tests.golden import cases
+    from tts_amd import ops
+
+    torch.set_num_threads(8)
+    cfg = dict(cases.HIFIGAN_TRAINED_LIKE)
+    sd, sx = cases.trained_like_hifigan_state(cfg, 77)
+    x = torch.randn(2, 80, 130, generator=torch.Generator().manual_seed(5)) * sx.view(1, 80, 1)
+    ref = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", "hifigan_trained_like.npz"))["wav"])
+    was = ops.conv_precision()
+    ops.set_conv_precision(precision)
+    try:
+        m = _make(cfg, 80, gpu, sd)
+        m.use_graphs = False
+        got = m.inference(x.to(gpu))
+        m0 = _make(cfg, 80, gpu, O.make_hifigan_state(cfg, 80, seed=77))
+        m0.use_graphs = False
+        got0 = m0.inference((x / sx.view(1, 80, 1)).to(gpu))
+    finally:
+        ops.set_conv_precision(was)
+    assert torch.isfinite(got).all() and got.shape == ref.shape
+    rms, rel = _errs(got, ref)
+    print("trained-like weights, %s: rms %.3e rel %.3e vs the reference; rel %.3e vs the unscaled network" % (precision, rms, rel, _errs(got, got0)[1]))
+    assert rms < 1e-4 and rel < 1e-5, (precision, rms, rel)
+    assert _errs(got, got0)[1] < 1e-5
