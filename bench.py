@@ -268,6 +268,76 @@ def pmc_traffic_live(precision, kernel_sub, timeout_s=150):
                            % (vals["FETCH_SIZE"][1], fetch, write))
 
 
+class NodeProbe:
+    """sysfs sampler (20 Hz, no subprocess) of the GPU this process runs on — picked by PCI address: the box may hold eight — and of
+    the node's OTHER GPUs' load, over a timed region: the evidence for (or against) the two explanations of a slow single-sentence
+    loop — our clocks, or neighbours sharing the node."""
+
+    def __init__(self):
+        import glob
+        import threading
+
+        self._glob = glob
+        cards = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+        mine = []
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            mine = [c for c in cards if want in os.path.realpath(c)]
+        except Exception:
+            pass
+        if not mine and len(cards) == 1:
+            mine = cards
+        self.card = mine[0] if mine else None
+        self.others = [c for c in cards if c != self.card]
+        self.rows, self._stop = [], False
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _cur(self, path):
+        import re
+
+        try:
+            for ln in open(path).read().splitlines():
+                if "*" in ln:
+                    m = re.search(r"(\d+)Mhz", ln)
+                    if m:
+                        return float(m.group(1))
+        except Exception:
+            pass
+        return float("nan")
+
+    def _num(self, pattern, scale=1.0):
+        try:
+            f = self._glob.glob(pattern)
+            return float(open(f[0]).read()) * scale if f else float("nan")
+        except Exception:
+            return float("nan")
+
+    def _run(self):
+        while not self._stop:
+            busy = [self._num(o + "/gpu_busy_percent") for o in self.others]
+            self.rows.append((self._cur(self.card + "/pp_dpm_sclk"), self._num(self.card + "/hwmon/hwmon*/power1_average", 1e-6),
+                              sum(1 for b in busy if b == b and b > 20)))
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.card:
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self.card:
+            self._t.join(timeout=2)
+
+    def summary(self):
+        if not self.rows:
+            return {"gpus_on_node": len(self.others) + (1 if self.card else 0)}
+        n = len(self.rows)
+        return {"our_sclk_mhz": sum(r[0] for r in self.rows) / n, "our_power_w": sum(r[1] for r in self.rows) / n,
+                "gpus_on_node": len(self.others) + 1, "other_gpus_busy": sum(r[2] for r in self.rows) / n}
+
+
 def timer_table(res):
     return {k: {"launches": r["launches"], "avg_us": r["ms"] * 1e3 / r["launches"],
                 "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12, "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
@@ -591,12 +661,14 @@ def wl_glow_hifigan_v2(args, ctx):
         wav = step()
         nw += 1
     ctx.fence()
-    stamps = [time.perf_counter()]
-    for _ in range(args.steps):
-        wav = step()
-        stamps.append(time.perf_counter())      # the host returns once per sentence (it waits for the sentence's extent)
-    ctx.fence()
-    elapsed = time.perf_counter() - stamps[0]
+    probe = NodeProbe()
+    with probe:
+        stamps = [time.perf_counter()]
+        for _ in range(args.steps):
+            wav = step()
+            stamps.append(time.perf_counter())      # the host returns once per sentence (it waits for the sentence's extent)
+        ctx.fence()
+        elapsed = time.perf_counter() - stamps[0]
     deltas = sorted((b_ - a_) * 1e3 for a_, b_ in zip(stamps, stamps[1:]))
     lat = []
     for _ in range(min(args.steps, 20)):        # per-sentence latency incl. the D2H of the waveform (what a caller waits for)
@@ -635,7 +707,7 @@ def wl_glow_hifigan_v2(args, ctx):
     g50 = gpu_ms[len(gpu_ms) // 2]
     line["observed"] = {"step_ms_p50": p50, "step_ms_p90": deltas[int(len(deltas) * 0.9)], "step_ms_max": deltas[-1],
                         "sentence_latency_ms_p50": float(sorted(lat)[len(lat) // 2]), "gpu_ms_per_sentence_p50": g50,
-                        "warmup_steps_run": nw,
+                        "warmup_steps_run": nw, "node": _round(probe.summary()),
                         # which regime this process ran in (1.47 ms in some processes / boxes, 1.85 in others)
                         "mode": ("kernel-chain-bound" if p50 <= 1.12 * g50 else "host/dispatch-bound") +
                                 (", fast" if p50 < 1.6 else ", SLOW")}

@@ -261,6 +261,53 @@ int ttsamd_resblock_group_supported(int c, int t, int batch);
 int ttsamd_sum_div(float *y, const float *a, const float *b, const float *c, float div, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Model-level handle of the vocoder — replaces, as ONE object a non-Python host can drive:
+ *   TTS/vocoder/models/hifigan_generator.py:162-234  HifiganGenerator.__init__ (layer list from the config)
+ *   :284-301  remove_weight_norm / load_checkpoint   (weight-norm folded at ttsamd_hifigan_finalize)
+ *   :236-265  forward,  :267-282  inference          (replicate padding of `inference_padding` frames, no crop)
+ *   TTS/vocoder/models/gan.py:58-66  GAN.inference   (the wrapper around it)
+ * create(config) -> load(name, tensor) for every state_dict entry in the REFERENCE's key layout ("conv_pre.weight" or
+ * "conv_pre.parametrizations.weight.original0/1" or ".weight_g/.weight_v", "ups.0...", "resblocks.3.convs1.2...", "conv_post...",
+ * ".bias") -> finalize (fold weight norm as torch does — over every dim but 0, i.e. per in_channel for ConvTranspose1d —,
+ * polyphase form of the transposed convs, the three fragment images of every conv, upload) -> forward(mel) any number of times
+ * -> destroy.  forward launches exactly the kernel sequence of the Python host (tts_amd/hifigan.py: same ttsamd_conv1d /
+ * ttsamd_resblock_pair / ttsamd_resblock_group calls, same tile choices — bitwise the same waveform, tests/test_hifigan_gpu.py),
+ * on ONE stream, into a workspace the handle owns; with use_graph != 0 the sequence for a given (mel, lengths, wav, batch, frames,
+ * stream) is captured into a hipGraph on its first call and replayed afterwards (a single sentence is ~100 launches of a few
+ * microseconds: replay removes the host from the loop).  Speaker conditioning (cond_layer / XTTS conds[i]) is not part of the
+ * handle: those models run through the kernel-level ABI.
+ * Caller owns mel [batch, in_channels, frames] / lengths [batch] int64 or NULL (ragged-exact batching: row b is computed as if
+ * it were alone with lengths[b] frames; needs k - stride even in every upsample layer) / wav
+ * [batch, out_channels, ttsamd_hifigan_output_samples(frames)], all on the device.  One caller at a time per handle. */
+#define TTSAMD_HIFIGAN_MAX_KERNELS 8
+#define TTSAMD_HIFIGAN_MAX_DILATIONS 8
+#define TTSAMD_HIFIGAN_MAX_UPSAMPLES 12
+typedef struct ttsamd_hifigan_config {
+    int32_t in_channels, out_channels;       /* HifiganGenerator(in_channels, out_channels, ...), hifigan_generator.py:163-178 */
+    int32_t resblock_type;                   /* 1 = ResBlock1 (:18-105), 2 = ResBlock2 (:108-159) */
+    int32_t num_kernels;
+    int32_t resblock_kernel_sizes[TTSAMD_HIFIGAN_MAX_KERNELS];
+    int32_t num_dilations[TTSAMD_HIFIGAN_MAX_KERNELS];
+    int32_t resblock_dilation_sizes[TTSAMD_HIFIGAN_MAX_KERNELS][TTSAMD_HIFIGAN_MAX_DILATIONS];
+    int32_t num_upsamples;
+    int32_t upsample_factors[TTSAMD_HIFIGAN_MAX_UPSAMPLES];
+    int32_t upsample_kernel_sizes[TTSAMD_HIFIGAN_MAX_UPSAMPLES];
+    int32_t upsample_initial_channel;
+    int32_t inference_padding;               /* frames replicated either side by `inference` (:267-282); 0 = plain forward */
+    int32_t precision;                       /* conv arithmetic: 0 = three fp16 products on large grids (default of the Python host),
+                                              * 1 = six bf16 products, 2 = fp32-input MFMA */
+} ttsamd_hifigan_config;
+int ttsamd_hifigan_create(const ttsamd_hifigan_config *config /* host */, void **handle_out);
+/* one state_dict entry: `data` (host, fp32, row-major) of `shape[ndim]` under the reference's key `name` */
+int ttsamd_hifigan_load(void *handle, const char *name, const float *data, const int64_t *shape, int ndim);
+int ttsamd_hifigan_finalize(void *handle);
+/* output samples per item for `frames` input frames: (frames + 2 * inference_padding) * hop when every k - stride is even */
+int64_t ttsamd_hifigan_output_samples(void *handle, int frames);
+int ttsamd_hifigan_forward(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, float *wav, int use_graph,
+                           void *stream);
+int ttsamd_hifigan_destroy(void *handle);
+
+/* ------------------------------------------------------------------------------------------
  * Channel LayerNorm on [B, C, T] (normalise over C for every (b, t)), with the fusions the text
  * encoder / duration predictors need.
  * replaces: TTS/tts/layers/generic/normalization.py:5-28 (LayerNorm, eps 1e-4) and :31-53

@@ -23,40 +23,59 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 tag = sys.argv[2] if len(sys.argv) > 2 else "-"
 
 
+def our_card():
+    """sysfs directory of the GPU this process runs on (the box may hold eight: pick ours by PCI address), and the others'."""
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        mine = [c for c in cards if want in os.path.realpath(c)]
+    except Exception:
+        mine = []
+    if not mine and len(cards) == 1:
+        mine = cards
+    return (mine[0] if mine else None), [c for c in cards if not mine or c != mine[0]]
+
+
 class Smi(threading.Thread):
-    """sysfs first (no subprocess: does not steal the host core), rocm-smi as the fallback"""
+    """clocks / power / busy of OUR card and the busy percentage + power of the node's other GPUs, from sysfs (no subprocess)"""
 
     def __init__(self):
         super().__init__(daemon=True)
         self.rows, self.stop = [], False
-        self.sclk_f = (glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk") or [None])[0]
-        self.mclk_f = (glob.glob("/sys/class/drm/card*/device/pp_dpm_mclk") or [None])[0]
-        self.pow_f = (glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") or glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input") or [None])[0]
+        self.card, self.others = our_card()
+        self.sclk_f = self.card
 
     @staticmethod
     def cur(path):
-        for ln in open(path).read().splitlines():
-            if "*" in ln:
-                m = re.search(r"(\d+)Mhz", ln)
-                if m:
-                    return float(m.group(1))
+        try:
+            for ln in open(path).read().splitlines():
+                if "*" in ln:
+                    m = re.search(r"(\d+)Mhz", ln)
+                    if m:
+                        return float(m.group(1))
+        except Exception:
+            pass
         return float("nan")
 
+    @staticmethod
+    def num(pattern, scale=1.0):
+        try:
+            f = glob.glob(pattern)
+            return float(open(f[0]).read()) * scale if f else float("nan")
+        except Exception:
+            return float("nan")
+
     def run(self):
-        while not self.stop:
-            try:
-                if self.sclk_f:
-                    p = float(open(self.pow_f).read()) / 1e6 if self.pow_f else float("nan")
-                    self.rows.append((self.cur(self.sclk_f), self.cur(self.mclk_f) if self.mclk_f else float("nan"), p))
-                else:
-                    out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
-                    p = re.search(r"Power \(W\):\s*([\d.]+)", out)
-                    c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
-                    m = re.search(r"mclk clock level: \d+: \((\d+)Mhz\)", out)
-                    self.rows.append((float(c.group(1)) if c else float("nan"), float(m.group(1)) if m else float("nan"), float(p.group(1)) if p else float("nan")))
-            except Exception:
-                pass
-            time.sleep(0.05 if self.sclk_f else 0.4)
+        while not self.stop and self.card:
+            c = self.card
+            busy_o = [self.num(o + "/gpu_busy_percent") for o in self.others]
+            pow_o = [self.num(o + "/hwmon/hwmon*/power1_average", 1e-6) for o in self.others]
+            self.rows.append((self.cur(c + "/pp_dpm_sclk"), self.cur(c + "/pp_dpm_mclk"), self.num(c + "/hwmon/hwmon*/power1_average", 1e-6),
+                              self.cur(c + "/pp_dpm_fclk"), self.num(c + "/gpu_busy_percent"),
+                              sum(1 for b in busy_o if b == b and b > 20), sum(p for p in pow_o if p == p)))
+            time.sleep(0.05)
 
 
 dev = torch.device("cuda:0")
@@ -102,9 +121,9 @@ for _ in range(40):
 lat.sort()
 smi.stop = True
 smi.join(timeout=3)
-rows = smi.rows or [(float("nan"),) * 3]
+rows = smi.rows or [(float("nan"),) * 7]
 mean = lambda k: sum(r[k] for r in rows) / len(rows)  # noqa: E731
-xa = x.data_ptr()
-print("BIMODAL %-22s ms/sentence %.3f %.3f | step p50 %.3f p90 %.3f max %.3f | sync latency p50 %.3f min %.3f | sclk %.0f (min %.0f max %.0f) mclk %.0f power %.0f W (%d samples, %s) | cpu %s | x@%x"
-      % (tag, res[0][0], res[1][0], res[1][1], res[1][2], res[1][3], lat[20], lat[0], mean(0), min(r[0] for r in rows), max(r[0] for r in rows), mean(1), mean(2),
-         len(rows), "sysfs" if smi.sclk_f else "rocm-smi", sorted(os.sched_getaffinity(0))[:4], xa), flush=True)
+print("BIMODAL %-22s ms/sentence %.3f %.3f | step p50 %.3f p90 %.3f max %.3f | sync latency p50 %.3f min %.3f | OUR card %s: sclk %.0f (min %.0f max %.0f) "
+      "mclk %.0f fclk %.0f busy %.0f%% power %.0f W | %d other GPUs on the node: busy(>20%%) %.1f of them, their power %.0f W (%d samples)"
+      % (tag, res[0][0], res[1][0], res[1][1], res[1][2], res[1][3], lat[20], lat[0], os.path.basename(os.path.dirname(smi.card)) if smi.card else "?",
+         mean(0), min(r[0] for r in rows), max(r[0] for r in rows), mean(1), mean(3), mean(4), mean(2), len(smi.others), mean(5), mean(6), len(rows)), flush=True)

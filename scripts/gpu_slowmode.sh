@@ -4,7 +4,7 @@
 # back to auto, one more as found, and a kernel trace (per-kernel medians: compare with the fast-mode table of
 # profiles/r05_bimodal_probe.txt).      bash scripts/gpu_slowmode.sh [outdir]
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/${1:-slowmode}; mkdir -p $OUT; cd $R
-dpm() { for f in /sys/class/drm/card*/device/pp_dpm_sclk /sys/class/drm/card*/device/pp_dpm_mclk /sys/class/drm/card*/device/pp_dpm_fclk /sys/class/drm/card*/device/pp_dpm_socclk /sys/class/drm/card*/device/power_dpm_force_performance_level; do [ -e $f ] && echo "$(basename $f): $(tr '\n' ' ' < $f)"; done; }
+dpm() { for f in /sys/class/drm/card*/device/power_dpm_force_performance_level; do [ -e $f ] && echo "$(dirname $f | xargs dirname | xargs basename): perf level $(cat $f), busy $(cat $(dirname $f)/gpu_busy_percent 2>/dev/null)%, sclk $(grep "\*" $(dirname $f)/pp_dpm_sclk | tr -d "\n")"; done; }
 {
 echo "--- as found"; dpm
 timeout 120 python scripts/bimodal_step.py 300 asfound1 2>&1 | grep BIMODAL

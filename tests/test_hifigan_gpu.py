@@ -268,3 +268,72 @@ def test_hifigan_trained_like_weights_match_the_reference_golden(gpu, precision)
     print("trained-like weights, %s: rms %.3e rel %.3e vs the reference; rel %.3e vs the unscaled network" % (precision, rms, rel, _errs(got, got0)[1]))
     assert rms < 1e-4 and rel < 1e-5, (precision, rms, rel)
     assert _errs(got, got0)[1] < 1e-5
+
+
+@pytest.mark.parametrize("variant", ["v2_sentence", "v1_c256_batch", "rb2_c64", "untuned"])
+def test_native_vocoder_handle_equals_the_python_driven_path(gpu, variant):
+    """The model-level C ABI (include/tts_amd.h: ttsamd_hifigan_{create,load,finalize,forward,destroy}; csrc/hifigan_model.hip)
+    through ctypes: weights handed over in the reference's state_dict layout, folded / re-ordered / packed in C++, the launch
+    sequence issued in C++ — against the oracle at the usual tolerance, and BITWISE equal to the Python-driven generator when both
+    get the same folded weights (same kernels, same tiles), eager and through the handle's own hipGraph replay; ragged batches too.
+    With the raw weight-norm parameters (the handle folds them itself, summing the norm in a different order than torch) the two
+    agree to 1e-6."""
+    from tts_amd import ops
+    from tts_amd.hifigan import NativeHifigan
+
+    torch.set_num_threads(8)
+    cfg = dict(W.HIFIGAN_V1)
+    B, T = 2, 40
+    if variant == "v2_sentence":                 # a single sentence: grouped MRF launches, small-grid kernels
+        cfg, B, T = dict(W.HIFIGAN_V2), 1, 61
+    elif variant == "v1_c256_batch":             # large grids: three-product kernels on the 128- / 64- / 32-channel stages
+        cfg["upsample_initial_channel"] = 256
+        B, T = 3, 130
+    elif variant == "rb2_c64":
+        cfg.update(upsample_initial_channel=64, resblock_type="2", resblock_dilation_sizes=[[1, 3]] * 3)
+    else:                                        # kernel sizes / strides without tuned instantiations: generic kernels
+        cfg = dict(W.HIFIGAN_V1, upsample_initial_channel=64, resblock_kernel_sizes=[5, 9, 3],
+                   resblock_dilation_sizes=[[1, 2, 4], [2, 6, 3], [3, 12, 1]], upsample_factors=[3, 2, 4, 2], upsample_kernel_sizes=[7, 4, 4, 6])
+    sd = O.make_hifigan_state(cfg, 80, seed=21)
+    x = torch.randn(B, 80, T, generator=torch.Generator().manual_seed(22))
+    want = O.hifigan_inference(sd, "", x, cfg)
+    m = _make(cfg, 80, gpu, sd)
+    m.use_graphs, m.concurrent_branches = False, False
+    ref = m.inference(x.to(gpu))
+    # (1) raw reference-layout state_dict: the handle folds the weight norm itself
+    nat = NativeHifigan(m, sd)
+    got = nat.forward(x.to(gpu))
+    assert got.shape == want.shape == ref.shape and nat.output_samples(T) == want.shape[-1]
+    rms, rel = _errs(got, want)
+    assert rms < 1e-4 and rel < 1e-5, (variant, rms, rel)
+    assert _errs(got, ref)[1] < 1e-6
+    nat.close()
+    # (2) the weights torch folded: bit for bit the Python-driven path
+    folded = {}
+    for k in sd:
+        if k.endswith(".parametrizations.weight.original0"):
+            name = k[: -len(".parametrizations.weight.original0")]
+            folded[name + ".weight"] = ops.fold_weight_norm(sd, name)
+        elif not k.endswith(".parametrizations.weight.original1"):
+            folded[k] = sd[k]
+    nat = NativeHifigan(m, folded)
+    got = nat.forward(x.to(gpu))
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    xg = x.to(gpu)
+    out = torch.empty_like(ref)
+    for _ in range(3):                            # first call: eager + capture, then replays into the same buffers
+        out.zero_()
+        nat.forward(xg, use_graph=True, out=out)
+        assert torch.equal(out, ref)
+    if m.exact_hop and B > 1:                     # ragged-exact batching through the handle == through the Python host
+        lens = torch.tensor([T, max(1, T - 13), max(1, T // 2)][:B]).to(gpu)
+        assert torch.equal(nat.forward(xg, lengths=lens), m.inference(xg, lengths=lens))
+    # errors come back as codes + messages, nothing crashes
+    import pytest as _pt
+
+    from tts_amd import _lib
+
+    with _pt.raises(_lib.TtsAmdError):
+        NativeHifigan(m, {k: v for k, v in folded.items() if not k.startswith("conv_post")})
+    nat.close()
+    nat.close()                                   # idempotent

@@ -1,0 +1,672 @@
+// Model-level C ABI of the vocoder ("mi355_hifigan_{create,load,forward,destroy}"): a HifiganGenerator behind ONE
+// handle — weight-norm folding, polyphase re-ordering of the transposed convs, packing into the three fragment images, the
+// length masks, the launch sequence of TTS/vocoder/models/hifigan_generator.py:236-282 and (optionally) its replay as a hipGraph —
+// so that a host that is not Python can run the model, and so that a request pays one C call instead of ~100 ctypes
+// marshalling calls.  Every launch goes through the kernel-level ABI of this same library (ttsamd_conv1d, ttsamd_resblock_pair,
+// ttsamd_resblock_group, ttsamd_sum_div, ttsamd_stage_masks, ttsamd_replicate_pad*): the arithmetic, the tile choices and therefore
+// the bits are those of the Python-driven path (tts_amd/hifigan.py), which tests/test_hifigan_gpu.py checks.
+//
+// Ownership: the caller owns mel / lengths / wav (device pointers); the handle owns its packed weights (device) and a grow-only
+// activation workspace (device).  One caller and one stream at a time per handle (the reference's Synthesizer is not thread-safe
+// either, synthesizer.py:302-304); errors are return codes + ttsamd_last_error(), nothing throws across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace ttsamd;
+
+namespace {
+
+constexpr float kLreluSlope = 0.1f;       // hifigan_generator.py:11
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    int64_t numel() const
+    {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int upload(const void *src, size_t n)
+    {
+        TTSAMD_HIP(hipMalloc(&p, n ? n : 4));
+        bytes = n;
+        if (n) TTSAMD_HIP(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        return TTSAMD_OK;
+    }
+};
+
+// one conv layer on the device: the three fragment images + bias (tts_amd/ops.py: PackedConv)
+struct PackedConv {
+    int c_out = 0, c_in = 0, kernel = 0, dilation = 1, pad_left = 0;
+    bool tuned = false;
+    DevBuf w, w_split, w_h2, bias, w_split_pad32, w_h2_pad32;
+    bool has_bias = false;
+};
+
+struct GraphEntry {
+    const void *mel, *lengths;
+    void *wav;
+    int batch, frames;
+    hipStream_t stream;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct Model {
+    ttsamd_hifigan_config cfg{};
+    std::map<std::string, HostTensor> tensors;
+    std::map<std::string, std::unique_ptr<PackedConv>> convs;
+    bool finalized = false;
+    int hop = 1;
+    DevBuf work;                 // activation workspace, grow-only
+    std::vector<GraphEntry> graphs;
+    int precision = 0;           // 0 = h2 (three fp16 products on large grids), 1 = x3 (six bf16 products), 2 = f32
+};
+
+int fold_weight_norm(const Model &m, const std::string &name, HostTensor &out)
+{
+    auto it = m.tensors.find(name + ".weight");
+    if (it != m.tensors.end()) {
+        out = it->second;
+        return TTSAMD_OK;
+    }
+    auto g = m.tensors.find(name + ".parametrizations.weight.original0");
+    auto v = m.tensors.find(name + ".parametrizations.weight.original1");
+    if (g == m.tensors.end()) g = m.tensors.find(name + ".weight_g");
+    if (v == m.tensors.end()) v = m.tensors.find(name + ".weight_v");
+    if (g == m.tensors.end() || v == m.tensors.end()) {
+        set_error("hifigan: no weight for '%s' (expected .weight, .parametrizations.weight.original0/1 or .weight_g/_v)", name.c_str());
+        return TTSAMD_ERR_INVALID;
+    }
+    // torch weight_norm, dim = 0: w = v * g / ||v|| with the norm over every dim but 0 (for ConvTranspose1d dim 0 is in_channels)
+    out = v->second;
+    const int64_t d0 = out.shape[0], inner = out.numel() / d0;
+    if (g->second.numel() != d0) {
+        set_error("hifigan: weight-norm gain of '%s' has %lld elements, the weight has %lld rows", name.c_str(), (long long)g->second.numel(), (long long)d0);
+        return TTSAMD_ERR_INVALID;
+    }
+    for (int64_t r = 0; r < d0; ++r) {
+        // torch._weight_norm: norm in fp32 (sum of squares, sqrt), then v * (g / norm)
+        float ss = 0.f;
+        for (int64_t i = 0; i < inner; ++i) ss += out.data[r * inner + i] * out.data[r * inner + i];
+        const float scale = g->second.data[r] / std::sqrt(ss);
+        for (int64_t i = 0; i < inner; ++i) out.data[r * inner + i] *= scale;
+    }
+    return TTSAMD_OK;
+}
+
+int pack_conv(PackedConv &pc, const float *w, const float *bias, int c_out, int c_in, int kernel, int dilation, int pad_left)
+{
+    pc.c_out = c_out;
+    pc.c_in = c_in;
+    pc.kernel = kernel;
+    pc.dilation = dilation;
+    pc.pad_left = pad_left < 0 ? (kernel - 1) * dilation / 2 : pad_left;
+    if (!ttsamd_conv1d_supported(kernel, dilation)) {
+        set_error("hifigan: conv kernel=%d dilation=%d is outside the HIP path's range", kernel, dilation);
+        return TTSAMD_ERR_UNSUPPORTED;
+    }
+    pc.tuned = ttsamd_conv1d_tuned(kernel, dilation) != 0;
+    {
+        std::vector<float> img(ttsamd_conv1d_packed_floats(c_out, c_in, kernel));
+        int rc = ttsamd_conv1d_pack_weights(img.data(), w, c_out, c_in, kernel);
+        if (rc) return rc;
+        if ((rc = pc.w.upload(img.data(), img.size() * sizeof(float)))) return rc;
+    }
+    {
+        std::vector<unsigned char> img(ttsamd_conv1d_packed_split_bytes(c_out, c_in, kernel));
+        int rc = ttsamd_conv1d_pack_weights_split(img.data(), w, c_out, c_in, kernel);
+        if (rc) return rc;
+        if ((rc = pc.w_split.upload(img.data(), img.size()))) return rc;
+    }
+    if (pc.tuned) {
+        std::vector<unsigned char> img(ttsamd_conv1d_packed_h2_bytes(c_out, c_in, kernel));
+        int rc = ttsamd_conv1d_pack_weights_h2(img.data(), w, c_out, c_in, kernel);
+        if (rc) return rc;
+        if ((rc = pc.w_h2.upload(img.data(), img.size()))) return rc;
+    }
+    if (c_out == c_in && (c_out == 8 || c_out == 16)) {       // the fused pair's 32-channel tile reads zero-padded images
+        std::vector<float> wp((size_t)32 * 32 * kernel, 0.f);
+        for (int r = 0; r < c_out; ++r)
+            for (int c = 0; c < c_in; ++c)
+                for (int t = 0; t < kernel; ++t) wp[((size_t)r * 32 + c) * kernel + t] = w[((size_t)r * c_in + c) * kernel + t];
+        std::vector<unsigned char> a(ttsamd_conv1d_packed_split_bytes(32, 32, kernel)), b(ttsamd_conv1d_packed_h2_bytes(32, 32, kernel));
+        int rc = ttsamd_conv1d_pack_weights_split(a.data(), wp.data(), 32, 32, kernel);
+        if (rc) return rc;
+        if ((rc = ttsamd_conv1d_pack_weights_h2(b.data(), wp.data(), 32, 32, kernel))) return rc;
+        if ((rc = pc.w_split_pad32.upload(a.data(), a.size()))) return rc;
+        if ((rc = pc.w_h2_pad32.upload(b.data(), b.size()))) return rc;
+    }
+    pc.has_bias = bias != nullptr;
+    if (bias) return pc.bias.upload(bias, (size_t)c_out * sizeof(float));
+    return TTSAMD_OK;
+}
+
+const float *opt_bias(const Model &m, const std::string &name, int64_t n, int *rc)
+{
+    auto it = m.tensors.find(name + ".bias");
+    if (it == m.tensors.end()) return nullptr;
+    if (it->second.numel() != n) {
+        set_error("hifigan: '%s.bias' has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel(), (long long)n);
+        *rc = TTSAMD_ERR_INVALID;
+        return nullptr;
+    }
+    return it->second.data.data();
+}
+
+int add_conv(Model &m, const std::string &name, int c_out, int c_in, int kernel, int dilation)
+{
+    HostTensor w;
+    int rc = fold_weight_norm(m, name, w);
+    if (rc) return rc;
+    if (w.shape.size() != 3 || w.shape[0] != c_out || w.shape[1] != c_in || w.shape[2] != kernel) {
+        set_error("hifigan: '%s' has shape [%lld, %lld, %lld], the config says [%d, %d, %d]", name.c_str(), (long long)(w.shape.size() > 0 ? w.shape[0] : -1),
+                  (long long)(w.shape.size() > 1 ? w.shape[1] : -1), (long long)(w.shape.size() > 2 ? w.shape[2] : -1), c_out, c_in, kernel);
+        return TTSAMD_ERR_INVALID;
+    }
+    const float *b = opt_bias(m, name, c_out, &rc);
+    if (rc) return rc;
+    auto pc = std::make_unique<PackedConv>();
+    if ((rc = pack_conv(*pc, w.data.data(), b, c_out, c_in, kernel, dilation, -1))) return rc;
+    m.convs[name] = std::move(pc);
+    return TTSAMD_OK;
+}
+
+// ConvTranspose1d weight [c_in, c_out, k] (stride u) -> the J-tap Conv1d [c_out * u, c_in, J], J = ceil(k / u), packed row
+// co * u + r = phase r of output channel co: W'[m, ci, j'] = w[ci, co, r + (J - 1 - j') u] (taps >= k are zero); pad_left = J - 1
+// (tts_amd/ops.py: convt_polyphase_weight)
+int add_convt(Model &m, const std::string &name, int c_in, int c_out, int k, int u)
+{
+    HostTensor wt;
+    int rc = fold_weight_norm(m, name, wt);
+    if (rc) return rc;
+    if (wt.shape.size() != 3 || wt.shape[0] != c_in || wt.shape[1] != c_out || wt.shape[2] != k) {
+        set_error("hifigan: '%s' does not have the ConvTranspose1d shape [%d, %d, %d]", name.c_str(), c_in, c_out, k);
+        return TTSAMD_ERR_INVALID;
+    }
+    const int J = (k + u - 1) / u;
+    std::vector<float> w((size_t)c_out * u * c_in * J, 0.f);
+    for (int co = 0; co < c_out; ++co)
+        for (int r = 0; r < u; ++r)
+            for (int ci = 0; ci < c_in; ++ci)
+                for (int jp = 0; jp < J; ++jp) {
+                    const int tap = r + (J - 1 - jp) * u;
+                    if (tap < k) w[(((size_t)co * u + r) * c_in + ci) * J + jp] = wt.data[((size_t)ci * c_out + co) * k + tap];
+                }
+    const float *b = opt_bias(m, name, c_out, &rc);
+    if (rc) return rc;
+    std::vector<float> br;
+    if (b) {
+        br.resize((size_t)c_out * u);
+        for (int co = 0; co < c_out; ++co)
+            for (int r = 0; r < u; ++r) br[(size_t)co * u + r] = b[co];
+    }
+    auto pc = std::make_unique<PackedConv>();
+    if ((rc = pack_conv(*pc, w.data(), b ? br.data() : nullptr, c_out * u, c_in, J, 1, J - 1))) return rc;
+    m.convs[name] = std::move(pc);
+    return TTSAMD_OK;
+}
+
+void fill_conv_args(const Model &m, ttsamd_conv1d_args &a, const PackedConv &pc, const float *x, int c_x, int t_in, float *y, int c_y, int t_y, int batch)
+{
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.x_bstride = (int64_t)c_x * t_in;
+    a.x_rstride = t_in;
+    a.c_in = pc.c_in;
+    a.t_in = t_in;
+    a.w_packed = static_cast<const float *>(pc.w.p);
+    a.bias = pc.has_bias ? static_cast<const float *>(pc.bias.p) : nullptr;
+    a.c_out = pc.c_out;
+    a.kernel = pc.kernel;
+    a.dilation = pc.dilation;
+    a.pad_left = pc.pad_left;
+    a.y = y;
+    a.y_bstride = (int64_t)c_y * t_y;
+    a.y_rstride = t_y;
+    a.t_out = (pc.kernel % 2 == 0) ? t_in + 2 * pc.pad_left - (pc.kernel - 1) * pc.dilation : t_in;
+    a.batch = batch;
+    a.shuffle_t_out = t_y;
+    // the precision switch of tts_amd/ops.py: conv1d
+    a.w_split = (m.precision != 2 || !pc.tuned) ? pc.w_split.p : nullptr;
+    a.w_h2 = (m.precision == 0 && pc.tuned) ? pc.w_h2.p : nullptr;
+}
+
+struct Workspace {
+    unsigned char *base;
+    size_t used = 0, cap;
+    bool dry;              // size pass: nothing is launched
+    float *take(size_t floats)
+    {
+        const size_t bytes = (floats * 4 + 255) & ~size_t(255);
+        float *p = dry ? nullptr : reinterpret_cast<float *>(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+// which (channels, kernel) pairs the generator fuses (tts_amd/hifigan.py: fuse_channels, fuse_max_kernel = {128: 3})
+bool fuse_pair(const Model &m, const PackedConv &c1, const PackedConv &c2)
+{
+    if (m.precision == 2) return false;
+    const int ch = c1.c_out;
+    if (!(c1.c_in == ch && c2.c_in == ch && c2.c_out == ch && c1.kernel == c2.kernel && c2.dilation == 1)) return false;
+    if (ch == 128 && c1.kernel > 3) return false;
+    return ttsamd_resblock_pair_supported(ch, c1.kernel, c1.dilation) != 0;
+}
+
+void fill_pair_args(const Model &m, ttsamd_resblock_args &r, const PackedConv &c1, const PackedConv &c2, const float *x, float *y, const float *accum,
+                    const float *mask, int ch, int t, int batch, float div)
+{
+    memset(&r, 0, sizeof(r));
+    const bool pad = ch < 32;
+    r.x = x;
+    r.y = y;
+    r.accum = accum;
+    r.mask = mask;
+    r.w1_split = pad ? c1.w_split_pad32.p : c1.w_split.p;
+    r.w2_split = pad ? c2.w_split_pad32.p : c2.w_split.p;
+    r.w1_bytes = (int64_t)(pad ? c1.w_split_pad32.bytes : c1.w_split.bytes);
+    r.w2_bytes = (int64_t)(pad ? c2.w_split_pad32.bytes : c2.w_split.bytes);
+    if (m.precision == 0) {
+        r.w1_h2 = pad ? c1.w_h2_pad32.p : c1.w_h2.p;
+        r.w2_h2 = pad ? c2.w_h2_pad32.p : c2.w_h2.p;
+        r.w1_h2_bytes = (int64_t)(pad ? c1.w_h2_pad32.bytes : c1.w_h2.bytes);
+        r.w2_h2_bytes = (int64_t)(pad ? c2.w_h2_pad32.bytes : c2.w_h2.bytes);
+    }
+    r.bias1 = c1.has_bias ? static_cast<const float *>(c1.bias.p) : nullptr;
+    r.bias2 = c2.has_bias ? static_cast<const float *>(c2.bias.p) : nullptr;
+    r.c = ch;
+    r.t = t;
+    r.batch = batch;
+    r.kernel = c1.kernel;
+    r.dilation = c1.dilation;
+    r.slope = kLreluSlope;
+    r.out_div = div;
+}
+
+#define RC(call)               \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_) return rc_;   \
+    } while (0)
+
+// The launch sequence of HifiganGenerator.inference (hifigan_generator.py:267-282 -> forward, :236-265) on `st`; with ws.dry only the
+// workspace size is computed.
+int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t *lengths, float *wav, hipStream_t st)
+{
+    const ttsamd_hifigan_config &c = m.cfg;
+    const int p = c.inference_padding, nk = c.num_kernels, nu = c.num_upsamples;
+    void *s = reinterpret_cast<void *>(st);
+    int T = T0 + 2 * p;
+    // per-stage length masks of a ragged batch (one launch), then the replicate padding of every item's own frames
+    std::vector<const float *> sm(nu + 1, nullptr);
+    int64_t *len_eff = nullptr;
+    if (lengths) {
+        std::vector<int32_t> scales(nu + 1), ts(nu + 1);
+        int sc = 1;
+        size_t total = 0;
+        for (int i = 0; i <= nu; ++i) {
+            scales[i] = sc;
+            ts[i] = T * sc;
+            total += (size_t)B * ts[i];
+            if (i < nu) sc *= c.upsample_factors[i];
+        }
+        float *masks = ws.take(total);
+        len_eff = reinterpret_cast<int64_t *>(ws.take((size_t)B * 2));
+        if (!ws.dry) {
+            for (int s0 = 0; s0 <= nu; s0 += TTSAMD_MASK_MAX_STAGES) {
+                const int n = std::min(TTSAMD_MASK_MAX_STAGES, nu + 1 - s0);
+                size_t off = 0;
+                for (int i = 0; i < s0; ++i) off += (size_t)B * ts[i];
+                RC(ttsamd_stage_masks(masks + off, len_eff, lengths, B, 1, 2 * p, scales.data() + s0, ts.data() + s0, n, s));
+            }
+            size_t off = 0;
+            for (int i = 0; i <= nu; ++i) {
+                sm[i] = masks + off;
+                off += (size_t)B * ts[i];
+            }
+        }
+    }
+    const float *x = mel;
+    if (p > 0) {
+        float *xp = ws.take((size_t)B * c.in_channels * T);
+        if (!ws.dry) {
+            if (lengths) RC(ttsamd_replicate_pad_ragged_ex(xp, mel, len_eff, -2 * p, B, c.in_channels, T0, p, s));
+            else RC(ttsamd_replicate_pad(xp, mel, (int64_t)B * c.in_channels, T0, p, s));
+        }
+        x = xp;
+    }
+    int ch = c.upsample_initial_channel;
+    float *o = ws.take((size_t)B * ch * T);
+    ttsamd_conv1d_args a;
+    if (!ws.dry) {
+        fill_conv_args(m, a, *m.convs["conv_pre"], x, c.in_channels, T, o, ch, T, B);
+        a.in_mask = sm[0];
+        RC(ttsamd_conv1d(&a, s));
+    }
+    for (int i = 0; i < nu; ++i) {
+        const int u = c.upsample_factors[i], k_up = c.upsample_kernel_sizes[i];
+        ch /= 2;
+        const int pad_up = (k_up - u) / 2;
+        const int T_up = (T - 1) * u - 2 * pad_up + k_up;
+        float *up = ws.take((size_t)B * ch * T_up);
+        if (!ws.dry) {
+            const PackedConv &pu = *m.convs["ups." + std::to_string(i)];
+            fill_conv_args(m, a, pu, o, ch * 2, T, up, ch, T_up, B);
+            a.in_act = TTSAMD_ACT_LRELU;
+            a.in_slope = kLreluSlope;
+            a.mode = TTSAMD_CONV_SHUFFLE;
+            a.shuffle_u = u;
+            a.shuffle_pad = pad_up;
+            a.in_mask = sm[i];
+            a.t_out = T + pu.kernel - 1;
+            if (pu.kernel != 2) a.w_h2 = nullptr, a.w_split = pu.w_split.p;     // polyphase forms other than two taps: the generic kernel
+            RC(ttsamd_conv1d(&a, s));
+        }
+        const float *msk = sm[i + 1];
+        T = T_up;
+        float *o_next = ws.take((size_t)B * ch * T);
+        float *zsum = nk > 1 ? ws.take((size_t)B * ch * T) : nullptr;
+        const size_t ws_mark = ws.used;
+        // grouped stage (a single sentence): the branches of one ResBlock iteration as ONE launch, their outputs averaged by one more
+        bool grouped = false;
+        if (c.resblock_type == 1 && nk >= 2 && nk <= 3 && T % 4 == 0 && ttsamd_resblock_group_supported(ch, T, B)) {
+            grouped = true;
+            for (int j = 0; j < nk && grouped; ++j) {
+                for (int d = 0; d < c.num_dilations[j]; ++d) {
+                    if (c.num_dilations[j] != c.num_dilations[0] || c.resblock_dilation_sizes[j][d] != c.resblock_dilation_sizes[0][d]) grouped = false;
+                }
+                const int k = c.resblock_kernel_sizes[j];
+                if (k != 3 && k != 7 && k != 11) grouped = false;
+                for (int j2 = 0; j2 < j; ++j2)
+                    if (c.resblock_kernel_sizes[j2] == k) grouped = false;
+            }
+            if (grouped) {
+                for (int j = 0; j < nk && grouped; ++j)
+                    for (int d = 0; d < c.num_dilations[0]; ++d) {
+                        const std::string rp = "resblocks." + std::to_string(i * nk + j) + ".";
+                        if (!fuse_pair(m, *m.convs[rp + "convs1." + std::to_string(d)], *m.convs[rp + "convs2." + std::to_string(d)])) grouped = false;
+                    }
+            }
+        }
+        if (grouped) {
+            std::vector<float *> buf(2 * nk);
+            for (auto &b : buf) b = ws.take((size_t)B * ch * T);
+            if (!ws.dry) {
+                std::vector<const float *> cur(nk, up);
+                for (int d = 0; d < c.num_dilations[0]; ++d) {
+                    ttsamd_resblock_args arr[3];
+                    memset(arr, 0, sizeof(arr));
+                    for (int j = 0; j < nk; ++j) {
+                        const std::string rp = "resblocks." + std::to_string(i * nk + j) + ".";
+                        const PackedConv &c1 = *m.convs[rp + "convs1." + std::to_string(d)], &c2 = *m.convs[rp + "convs2." + std::to_string(d)];
+                        const int slot = c1.kernel == 3 ? 0 : (c1.kernel == 7 ? 1 : 2);
+                        fill_pair_args(m, arr[slot], c1, c2, cur[j], buf[2 * j + (d & 1)], nullptr, msk, ch, T, B, 0.f);
+                        arr[slot].w1_h2 = arr[slot].w2_h2 = nullptr;      // grouped launches run the six-product kernels
+                        arr[slot].w1_h2_bytes = arr[slot].w2_h2_bytes = 0;
+                    }
+                    RC(ttsamd_resblock_group(arr, s));
+                    for (int j = 0; j < nk; ++j) cur[j] = buf[2 * j + (d & 1)];
+                }
+                RC(ttsamd_sum_div(o_next, cur[0], cur[1], nk > 2 ? cur[2] : nullptr, (float)nk, (int64_t)B * ch * T, s));
+            }
+        } else {
+            float *xa = ws.take((size_t)B * ch * T), *xb = ws.take((size_t)B * ch * T), *tmp = ws.take((size_t)B * ch * T);
+            for (int j = 0; j < nk && !ws.dry; ++j) {
+                const std::string rp = "resblocks." + std::to_string(i * nk + j) + ".";
+                const int nd = c.num_dilations[j];
+                const float *cur = up;
+                for (int d = 0; d < nd; ++d) {
+                    const bool last = d == nd - 1;
+                    float *dst = last ? (j == nk - 1 ? o_next : zsum) : (cur == xa ? xb : xa);
+                    const float *accum = (last && j > 0) ? zsum : nullptr;
+                    const float div = (last && j == nk - 1) ? (float)nk : 0.f;
+                    if (c.resblock_type == 1) {
+                        const PackedConv &c1 = *m.convs[rp + "convs1." + std::to_string(d)], &c2 = *m.convs[rp + "convs2." + std::to_string(d)];
+                        if (fuse_pair(m, c1, c2)) {
+                            ttsamd_resblock_args r;
+                            fill_pair_args(m, r, c1, c2, cur, dst, accum, msk, ch, T, B, div);
+                            RC(ttsamd_resblock_pair(&r, s));
+                        } else {
+                            fill_conv_args(m, a, c1, cur, ch, T, tmp, ch, T, B);
+                            a.in_act = TTSAMD_ACT_LRELU;
+                            a.in_slope = kLreluSlope;
+                            a.in_mask = msk;
+                            RC(ttsamd_conv1d(&a, s));
+                            fill_conv_args(m, a, c2, tmp, ch, T, dst, ch, T, B);
+                            a.in_act = TTSAMD_ACT_LRELU;
+                            a.in_slope = kLreluSlope;
+                            a.in_mask = msk;
+                            a.res = cur;
+                            a.res_bstride = (int64_t)ch * T;
+                            a.res_rstride = T;
+                            a.accum = accum;
+                            a.accum_bstride = (int64_t)ch * T;
+                            a.accum_rstride = T;
+                            a.out_div = div;
+                            RC(ttsamd_conv1d(&a, s));
+                        }
+                    } else {
+                        const PackedConv &cv = *m.convs[rp + "convs." + std::to_string(d)];
+                        fill_conv_args(m, a, cv, cur, ch, T, dst, ch, T, B);
+                        a.in_act = TTSAMD_ACT_LRELU;
+                        a.in_slope = kLreluSlope;
+                        a.in_mask = msk;
+                        a.res = cur;
+                        a.res_bstride = (int64_t)ch * T;
+                        a.res_rstride = T;
+                        a.accum = accum;
+                        a.accum_bstride = (int64_t)ch * T;
+                        a.accum_rstride = T;
+                        a.out_div = div;
+                        RC(ttsamd_conv1d(&a, s));
+                    }
+                    cur = dst;
+                }
+            }
+        }
+        (void)ws_mark;
+        o = o_next;
+    }
+    if (!ws.dry) {
+        // the final F.leaky_relu(o) uses the DEFAULT slope 0.01 (hifigan_generator.py:262), then conv_post and tanh
+        fill_conv_args(m, a, *m.convs["conv_post"], o, ch, T, wav, c.out_channels, T, B);
+        a.in_act = TTSAMD_ACT_LRELU;
+        a.in_slope = 0.01f;
+        a.out_act = TTSAMD_ACT_TANH;
+        a.in_mask = sm[nu];
+        RC(ttsamd_conv1d(&a, s));
+    }
+    return TTSAMD_OK;
+}
+
+void drop_graphs(Model &m)
+{
+    for (auto &g : m.graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    m.graphs.clear();
+}
+
+Model *as_model(void *h) { return static_cast<Model *>(h); }
+
+}  // namespace
+
+extern "C" int ttsamd_hifigan_create(const ttsamd_hifigan_config *cfg, void **handle_out)
+{
+    TTSAMD_CHECK_ARG(cfg && handle_out, "hifigan_create: NULL argument");
+    const ttsamd_hifigan_config &c = *cfg;
+    TTSAMD_CHECK_ARG(c.in_channels > 0 && c.out_channels > 0 && c.upsample_initial_channel > 0, "hifigan_create: bad channel counts");
+    TTSAMD_CHECK_ARG(c.resblock_type == 1 || c.resblock_type == 2, "hifigan_create: resblock_type must be 1 or 2");
+    TTSAMD_CHECK_ARG(c.num_kernels >= 1 && c.num_kernels <= TTSAMD_HIFIGAN_MAX_KERNELS, "hifigan_create: 1..%d resblock kernels", TTSAMD_HIFIGAN_MAX_KERNELS);
+    TTSAMD_CHECK_ARG(c.num_upsamples >= 1 && c.num_upsamples <= TTSAMD_HIFIGAN_MAX_UPSAMPLES, "hifigan_create: 1..%d upsample layers", TTSAMD_HIFIGAN_MAX_UPSAMPLES);
+    TTSAMD_CHECK_ARG(c.inference_padding >= 0 && c.precision >= 0 && c.precision <= 2, "hifigan_create: bad padding / precision");
+    int ch = c.upsample_initial_channel, hop = 1;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        TTSAMD_CHECK_ARG(c.upsample_factors[i] >= 1 && c.upsample_kernel_sizes[i] >= c.upsample_factors[i],
+                         "hifigan_create: upsample layer %d: kernel %d < stride %d leaves samples without a tap", i, c.upsample_kernel_sizes[i], c.upsample_factors[i]);
+        TTSAMD_CHECK_ARG(ch % 2 == 0, "hifigan_create: channel count %d cannot be halved at upsample layer %d", ch, i);
+        ch /= 2;
+        hop *= c.upsample_factors[i];
+    }
+    for (int j = 0; j < c.num_kernels; ++j) {
+        TTSAMD_CHECK_ARG(c.num_dilations[j] >= 1 && c.num_dilations[j] <= TTSAMD_HIFIGAN_MAX_DILATIONS, "hifigan_create: resblock %d: 1..%d dilations", j, TTSAMD_HIFIGAN_MAX_DILATIONS);
+        TTSAMD_CHECK_ARG(c.resblock_kernel_sizes[j] % 2 == 1, "hifigan_create: resblock kernel sizes are odd (get_padding, hifigan_generator.py:14-15)");
+    }
+    Model *m = new (std::nothrow) Model();
+    TTSAMD_CHECK_ARG(m, "hifigan_create: out of memory");
+    m->cfg = c;
+    m->hop = hop;
+    m->precision = c.precision;
+    *handle_out = m;
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_hifigan_load(void *handle, const char *name, const float *data, const int64_t *shape, int ndim)
+{
+    TTSAMD_CHECK_ARG(handle && name && data && shape && ndim >= 1 && ndim <= 4, "hifigan_load: bad arguments");
+    Model &m = *as_model(handle);
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    for (int i = 0; i < ndim; ++i) TTSAMD_CHECK_ARG(shape[i] > 0, "hifigan_load: '%s' has a non-positive dimension", name);
+    t.data.assign(data, data + t.numel());
+    m.tensors[name] = std::move(t);
+    m.finalized = false;
+    return TTSAMD_OK;
+}
+
+extern "C" int ttsamd_hifigan_finalize(void *handle)
+{
+    TTSAMD_CHECK_ARG(handle, "hifigan_finalize: NULL handle");
+    Model &m = *as_model(handle);
+    const ttsamd_hifigan_config &c = m.cfg;
+    // graphs and packed images of a previous weight set go first (a graph holds raw pointers to them)
+    TTSAMD_HIP(hipDeviceSynchronize());
+    drop_graphs(m);
+    m.convs.clear();
+    RC(add_conv(m, "conv_pre", c.upsample_initial_channel, c.in_channels, 7, 1));
+    int ch = c.upsample_initial_channel;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        RC(add_convt(m, "ups." + std::to_string(i), ch, ch / 2, c.upsample_kernel_sizes[i], c.upsample_factors[i]));
+        ch /= 2;
+        for (int j = 0; j < c.num_kernels; ++j) {
+            const std::string rp = "resblocks." + std::to_string(i * c.num_kernels + j) + ".";
+            for (int d = 0; d < c.num_dilations[j]; ++d) {
+                if (c.resblock_type == 1) {
+                    RC(add_conv(m, rp + "convs1." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j][d]));
+                    RC(add_conv(m, rp + "convs2." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], 1));
+                } else {
+                    RC(add_conv(m, rp + "convs." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j][d]));
+                }
+            }
+        }
+    }
+    RC(add_conv(m, "conv_post", c.out_channels, ch, 7, 1));
+    m.tensors.clear();           // the host copies are not needed any more
+    m.finalized = true;
+    return TTSAMD_OK;
+}
+
+extern "C" int64_t ttsamd_hifigan_output_samples(void *handle, int frames)
+{
+    if (!handle || frames < 0) return -1;
+    Model &m = *as_model(handle);
+    int64_t T = frames + 2 * m.cfg.inference_padding;
+    for (int i = 0; i < m.cfg.num_upsamples; ++i)
+        T = (T - 1) * m.cfg.upsample_factors[i] - 2 * ((m.cfg.upsample_kernel_sizes[i] - m.cfg.upsample_factors[i]) / 2) + m.cfg.upsample_kernel_sizes[i];
+    return T;
+}
+
+extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, float *wav, int use_graph,
+                                      void *stream)
+{
+    TTSAMD_CHECK_ARG(handle && mel && wav, "hifigan_forward: NULL argument");
+    Model &m = *as_model(handle);
+    TTSAMD_CHECK_ARG(m.finalized, "hifigan_forward: weights not loaded (ttsamd_hifigan_load ... ttsamd_hifigan_finalize)");
+    TTSAMD_CHECK_ARG(batch >= 0 && frames >= 1 && batch <= 65535, "hifigan_forward: bad shape");
+    if (batch == 0) return TTSAMD_OK;
+    if (lengths) {
+        for (int i = 0; i < m.cfg.num_upsamples; ++i)
+            TTSAMD_CHECK_ARG((m.cfg.upsample_kernel_sizes[i] - m.cfg.upsample_factors[i]) % 2 == 0,
+                             "hifigan_forward: ragged batching needs upsample kernels with k - stride even (output = frames * hop exactly)");
+    }
+    hipStream_t st = as_stream(stream);
+    Workspace dry{nullptr, 0, 0, true};
+    RC(run(m, dry, mel, batch, frames, lengths, wav, st));
+    if (dry.used > m.work.bytes) {
+        // growing the workspace invalidates every captured graph (they hold pointers into it)
+        TTSAMD_HIP(hipDeviceSynchronize());
+        drop_graphs(m);
+        if (m.work.p) TTSAMD_HIP(hipFree(m.work.p));
+        m.work.p = nullptr;
+        m.work.bytes = 0;
+        TTSAMD_HIP(hipMalloc(&m.work.p, dry.used));
+        m.work.bytes = dry.used;
+    }
+    if (use_graph) {
+        for (auto &g : m.graphs)
+            if (g.mel == mel && g.lengths == lengths && g.wav == wav && g.batch == batch && g.frames == frames && g.stream == st) {
+                TTSAMD_HIP(hipGraphLaunch(g.exec, st));
+                return TTSAMD_OK;
+            }
+        // first sighting of this (buffers, shape, stream): run it once eagerly (one-time function attributes are set outside any
+        // capture), then capture the same sequence and replay from the next call on
+        Workspace w0{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
+        RC(run(m, w0, mel, batch, frames, lengths, wav, st));
+        GraphEntry e{mel, lengths, wav, batch, frames, st};
+        TTSAMD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        Workspace w1{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
+        const int rc = run(m, w1, mel, batch, frames, lengths, wav, st);
+        const hipError_t he = hipStreamEndCapture(st, &e.graph);
+        if (rc) {
+            if (e.graph) (void)hipGraphDestroy(e.graph);
+            return rc;
+        }
+        TTSAMD_HIP(he);
+        TTSAMD_HIP(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+        if (m.graphs.size() >= 16) {
+            GraphEntry &old = m.graphs.front();
+            TTSAMD_HIP(hipStreamSynchronize(old.stream));
+            (void)hipGraphExecDestroy(old.exec);
+            (void)hipGraphDestroy(old.graph);
+            m.graphs.erase(m.graphs.begin());
+        }
+        m.graphs.push_back(e);
+        return TTSAMD_OK;       // (the eager run above produced this call's result)
+    }
+    Workspace w{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
+    return run(m, w, mel, batch, frames, lengths, wav, st);
+}
+
+extern "C" int ttsamd_hifigan_destroy(void *handle)
+{
+    if (!handle) return TTSAMD_OK;
+    Model *m = as_model(handle);
+    (void)hipDeviceSynchronize();
+    drop_graphs(*m);
+    delete m;
+    return TTSAMD_OK;
+}

@@ -12,6 +12,7 @@ polyphase 2-tap conv with a pixel-shuffle epilogue; a whole ResBlock1 iteration
 kernel.  v1: 78 conv launches unfused, 54 with fusion.  No elementwise passes over HBM remain.
 """
 import collections
+import ctypes
 import os
 
 import torch
@@ -28,6 +29,86 @@ def _cumprod(xs):
         p *= x
         out.append(p)
     return out
+
+
+class HifiganConfig(ctypes.Structure):
+    """Mirror of `ttsamd_hifigan_config` (include/tts_amd.h)."""
+
+    _fields_ = [("in_channels", ctypes.c_int32), ("out_channels", ctypes.c_int32), ("resblock_type", ctypes.c_int32),
+                ("num_kernels", ctypes.c_int32), ("resblock_kernel_sizes", ctypes.c_int32 * 8), ("num_dilations", ctypes.c_int32 * 8),
+                ("resblock_dilation_sizes", (ctypes.c_int32 * 8) * 8), ("num_upsamples", ctypes.c_int32),
+                ("upsample_factors", ctypes.c_int32 * 12), ("upsample_kernel_sizes", ctypes.c_int32 * 12),
+                ("upsample_initial_channel", ctypes.c_int32), ("inference_padding", ctypes.c_int32), ("precision", ctypes.c_int32)]
+
+
+class NativeHifigan:
+    """The model-level C ABI of the vocoder (include/tts_amd.h: ttsamd_hifigan_{create,load,finalize,forward,destroy}) seen from
+    Python: weight folding / packing, masks, the launch sequence and its hipGraph replay all live behind the handle in C++
+    (csrc/hifigan_model.hip) — the boundary a non-Python host binds; this class only marshals pointers."""
+
+    _PREC = {"h2": 0, "x3": 1, "f32": 2}
+
+    def __init__(self, gen, state_dict=None, precision=None):
+        sd = state_dict if state_dict is not None else gen._sd
+        if sd is None:
+            raise _lib.TtsAmdError("NativeHifigan: no weights")
+        if gen.cond_channels > 0 or gen.cond_in_each_up_layer:
+            raise _lib.TtsAmdError("NativeHifigan: speaker-conditioned generators run through the kernel-level ABI")
+        c = HifiganConfig()
+        c.in_channels, c.out_channels, c.resblock_type = gen.in_channels, gen.out_channels, int(gen.resblock_type)
+        c.num_kernels = gen.num_kernels
+        for j, (k, dil) in enumerate(zip(gen.resblock_kernel_sizes, gen.resblock_dilation_sizes)):
+            c.resblock_kernel_sizes[j], c.num_dilations[j] = k, len(dil)
+            for d, v in enumerate(dil):
+                c.resblock_dilation_sizes[j][d] = v
+        c.num_upsamples = gen.num_upsamples
+        for i, (u, k) in enumerate(zip(gen.upsample_factors, gen.upsample_kernel_sizes)):
+            c.upsample_factors[i], c.upsample_kernel_sizes[i] = u, k
+        c.upsample_initial_channel, c.inference_padding = gen.upsample_initial_channel, gen.inference_padding
+        c.precision = self._PREC[precision or ops.conv_precision()]
+        self.out_channels = gen.out_channels
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        L.ttsamd_hifigan_output_samples.restype = ctypes.c_int64
+        _lib.check(L.ttsamd_hifigan_create(ctypes.byref(c), ctypes.byref(self._h)), "hifigan_create")
+        try:
+            for name, t in sd.items():
+                t = t.detach().to("cpu", torch.float32).contiguous()
+                if t.dim() == 0 or t.numel() == 0:
+                    continue
+                shape = (ctypes.c_int64 * t.dim())(*t.shape)
+                _lib.check(L.ttsamd_hifigan_load(self._h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()), "hifigan_load")
+            _lib.check(L.ttsamd_hifigan_finalize(self._h), "hifigan_finalize")
+        except Exception:
+            self.close()
+            raise
+
+    def output_samples(self, frames):
+        return int(_lib.lib().ttsamd_hifigan_output_samples(self._h, int(frames)))
+
+    @torch.no_grad()
+    def forward(self, mel, lengths=None, use_graph=False, out=None):
+        """mel [B, C, T] fp32 on the GPU (+ lengths [B] int64 on the GPU for ragged-exact batching) -> wav [B, 1, samples]."""
+        _lib.require_gpu(mel, "mel")
+        mel = mel.contiguous().float()
+        B, _, T = mel.shape
+        wav = out if out is not None else torch.empty((B, self.out_channels, self.output_samples(T)), dtype=torch.float32, device=mel.device)
+        ln = None if lengths is None else lengths.to(mel.device, torch.int64).contiguous()
+        _lib.check(_lib.lib().ttsamd_hifigan_forward(self._h, _lib.P(mel), B, T, _lib.P(ln), _lib.P(wav), int(bool(use_graph)), _lib.stream_ptr()),
+                   "hifigan_forward")
+        self._keep = (mel, ln, wav)          # the launches are asynchronous: inputs stay referenced until the next call
+        return wav
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().ttsamd_hifigan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HifiganGenerator:
