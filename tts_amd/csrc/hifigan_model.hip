@@ -81,6 +81,8 @@ struct Model {
     int hop = 1;
     DevBuf work;                 // activation workspace, grow-only
     std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;   // the sequence is RECORDED on this stream (the caller's may be the NULL stream, which cannot
+                                        // capture) and replayed on the caller's
     int precision = 0;           // 0 = h2 (three fp16 products on large grids), 1 = x3 (six bf16 products), 2 = f32
 };
 
@@ -637,10 +639,11 @@ extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch,
         Workspace w0{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
         RC(run(m, w0, mel, batch, frames, lengths, wav, st));
         GraphEntry e{mel, lengths, wav, batch, frames, st};
-        TTSAMD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (!m.cap_stream) TTSAMD_HIP(hipStreamCreateWithFlags(&m.cap_stream, hipStreamNonBlocking));
+        TTSAMD_HIP(hipStreamBeginCapture(m.cap_stream, hipStreamCaptureModeThreadLocal));
         Workspace w1{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
-        const int rc = run(m, w1, mel, batch, frames, lengths, wav, st);
-        const hipError_t he = hipStreamEndCapture(st, &e.graph);
+        const int rc = run(m, w1, mel, batch, frames, lengths, wav, m.cap_stream);
+        const hipError_t he = hipStreamEndCapture(m.cap_stream, &e.graph);
         if (rc) {
             if (e.graph) (void)hipGraphDestroy(e.graph);
             return rc;
@@ -667,6 +670,7 @@ extern "C" int ttsamd_hifigan_destroy(void *handle)
     Model *m = as_model(handle);
     (void)hipDeviceSynchronize();
     drop_graphs(*m);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     delete m;
     return TTSAMD_OK;
 }
