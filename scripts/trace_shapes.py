@@ -13,8 +13,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
 agg = collections.OrderedDict()
 for r in rows:
-    nm = re.sub(r"void ttsamd::conv1d_(mfma|x3)_kernel<(.*?)>.*", r"conv_\1<\2>", r['Kernel_Name'])
-    nm = re.sub(r"void ttsamd::resblock_pair_x3_kernel<(.*?)>.*", r"resblock_x3<\1>", nm)
+    nm = re.sub(r"void ttsamd::conv1d_(mfma|x3|h2)_kernel<(.*?)>.*", r"conv_\1<\2>", r['Kernel_Name'])
+    nm = re.sub(r"void ttsamd::resblock_pair_(x3|h2)_kernel<(.*?)>.*", r"resblock_\1<\2>", nm)
     nm = re.sub(r"^void ", "", re.sub(r"\(.*", "", nm)).replace("ttsamd::", "")[:42]
     key = (nm, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), int(r['Grid_Size_Y']), int(r['Grid_Size_Z']))
     agg.setdefault(key, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
