@@ -505,3 +505,38 @@ def test_h2_weight_image_matches_a_numpy_restatement():
         assert hdr[0] == int(e.max()) and tab.shape[0] == mt * 32
         assert np.array_equal(tab[:co, 0], np.ldexp(1.0, e).astype(np.float32)) and np.array_equal(tab[:co, 1], np.ldexp(1.0, -e).astype(np.float32))
         assert np.all(tab[co:] == 1.0)
+
+
+def test_sentence_pipeline_drops_its_graphs_when_a_model_is_repacked():
+    """the SentencePipeline's captured tail holds raw pointers to both models' weight tensors.  Every re-pack of
+    a model bumps its `weights_version`; the pipeline clears its cache when either version changed, keys new captures on the pair,
+    is registered with the acoustic model's StreamScratch (an evicted scratch set drops the graphs reading it), and
+    `Lanes.close([synthesizer])` reaches the pipeline's per-lane graphs through `purge_stream`."""
+    import types
+
+    from tts_amd import graphs
+    from tts_amd.synthesizer import SentencePipeline
+
+    class FakeCache:
+        def __init__(self):
+            self.cleared, self.purged = 0, []
+
+        def clear(self):
+            self.cleared += 1
+
+        def purge_stream(self, h):
+            self.purged.append(h)
+
+    tts = types.SimpleNamespace(weights_version=1, _scratch=graphs.StreamScratch())
+    voc = types.SimpleNamespace(weights_version=4)
+    pipe = SentencePipeline(tts, voc, None, None)
+    assert pipe._graph in tts._scratch.dependents
+    pipe._graph = FakeCache()
+    assert pipe._check_weights() == (1, 4) and pipe._graph.cleared == 0          # first sighting: nothing to drop
+    assert pipe._check_weights() == (1, 4) and pipe._graph.cleared == 0
+    voc.weights_version += 1                                                     # vocoder re-packed (.cuda(), load_checkpoint, hot swap)
+    assert pipe._check_weights() == (1, 5) and pipe._graph.cleared == 1
+    tts.weights_version += 1
+    assert pipe._check_weights() == (2, 5) and pipe._graph.cleared == 2
+    pipe.purge_stream(77)
+    assert pipe._graph.purged == [77]
