@@ -143,13 +143,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         for (int c = 0; c < 8; ++c) st[i][c] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb + c * row_bytes, 0);
     };
     // mask + activation in place, and this wave's largest magnitude of the chunk -> its slot
+    const bool has_in_mask = a.in_mask != nullptr;
     auto stage_act_max = [&](int parity) {
         float m = 0.f;
+        if (has_in_mask) {                          // block-uniform: an unmasked launch pays no multiply per value
+#pragma unroll
+            for (int i = 0; i < G::kNStage; ++i)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) st[i][c] *= smask[i];
+        }
 #pragma unroll
         for (int i = 0; i < G::kNStage; ++i)
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                st[i][c] = conv_in_act(st[i][c] * smask[i], a.in_act, a.in_slope);
+                st[i][c] = conv_in_act(st[i][c], a.in_act, a.in_slope);
                 m = __builtin_fmaxf(m, __builtin_fabsf(st[i][c]));
             }
         const unsigned wmax = wave_max_u32(__builtin_bit_cast(unsigned, m));

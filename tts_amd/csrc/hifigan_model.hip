@@ -274,7 +274,7 @@ bool fuse_pair(const Model &m, const PackedConv &c1, const PackedConv &c2)
     if (m.precision == 2) return false;
     const int ch = c1.c_out;
     if (!(c1.c_in == ch && c2.c_in == ch && c2.c_out == ch && c1.kernel == c2.kernel && c2.dilation == 1)) return false;
-    if (ch == 128 && c1.kernel > 3) return false;
+    if (ch == 128 && c1.kernel > (m.precision == 0 ? 7 : 3)) return false;     // tts_amd/hifigan.py: _fuse_limit
     return ttsamd_resblock_pair_supported(ch, c1.kernel, c1.dilation) != 0;
 }
 

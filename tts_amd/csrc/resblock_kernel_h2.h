@@ -130,9 +130,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
             float sm;
 #pragma unroll
             for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off == kOob ? kOob : off + i * row_bytes, 0);
-            sm = has_mask ? ld_buf(rmask, ok ? gt * 4 : kOob, 0) : 1.f;
+            if (has_mask) {                         // block-uniform: an unmasked call pays no multiply per value
+                sm = ld_buf(rmask, ok ? gt * 4 : kOob, 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) st[rr][i] *= sm;
+                for (int i = 0; i < 8; ++i) st[rr][i] *= sm;
+            }
         }
         float m = 0.f;
 #pragma unroll
@@ -368,7 +370,10 @@ int resblock_pair_h2_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
         case 16: return resblock_pair_h2_launch_cfg<K, D, 16, 1, 4, 2>(a, st);
         case 32: return resblock_pair_h2_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:
-            if ((a.variant == 1) != (K == 11)) return resblock_pair_h2_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
+            // the 4-wave / 128-column tile for every kernel size (two blocks per CU: one block's staging and epilogue phases run
+            // under the other's MFMAs); on six products k = 11 preferred the 8-wave / 256-column tile (4 % halo work instead of
+            // 8 %), on three it is 1.5-2 % slower (scripts/h2_variants_ab.py); variant 1 selects it for A/B
+            if (a.variant == 1) return resblock_pair_h2_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
             return resblock_pair_h2_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
         case 128: return resblock_pair_h2_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
     }

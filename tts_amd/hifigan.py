@@ -151,7 +151,10 @@ class HifiganGenerator:
         # C=64 0.66-0.92, C=128 0.88 (k=3), 1.00 (k=7), 1.07 (k=11) -> the 128-channel stage fuses its k=3 blocks only.
         self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
         self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "8,16,32,64,128").split(",") if c)
-        self.fuse_max_kernel = {128: 3}     # channel count -> largest kernel size fused (absent = all)
+        # channel count -> largest kernel size fused (absent = all).  128 channels: k = 3 only on six products (round 2: k = 7 1.00,
+        # k = 11 1.07 of the unfused pair); on three products the fused k = 7 pair is 0.90-0.91 of the two launches (its LDS image is
+        # 2/3 the size), k = 11 1.02 (scripts/h2_variants_ab.py) — `None` = pick by the conv precision at call time
+        self.fuse_max_kernel = None
         # small grids (a single sentence): the three MRF branches of a stage as ONE launch per ResBlock iteration instead of nine
         # launches on three branch streams (forward())
         self.group_branches = os.environ.get("TTSAMD_GROUP_BRANCHES", "1") != "0"
@@ -165,6 +168,11 @@ class HifiganGenerator:
         self.graph_max_frames = 2048
         self._graph = graphs.GraphCache(self._inference_ragged, max_entries=12)
         self.weights_version = 0    # bumped by every re-pack: dependants (SentencePipeline) key their graphs on it
+
+    def _fuse_limit(self, ch):
+        """Largest kernel size whose ResBlock pairs run fused at `ch` channels (see fuse_max_kernel)."""
+        table = self.fuse_max_kernel if self.fuse_max_kernel is not None else ({128: 7} if ops.conv_precision() == "h2" else {128: 3})
+        return table.get(ch, 99)
 
     def hop_length(self):
         return _cumprod(self.upsample_factors)[-1]
@@ -252,7 +260,7 @@ class HifiganGenerator:
             return False
         for m in range(len(dils[0])):
             pairs = [(P["resblocks.%d.convs1.%d" % (i * nk + j, m)], P["resblocks.%d.convs2.%d" % (i * nk + j, m)]) for j in range(nk)]
-            if any(pc1.kernel > self.fuse_max_kernel.get(ch, 99) for pc1, _ in pairs) or not ops.resblock_group_supported(pairs, B, ch, T):
+            if any(pc1.kernel > self._fuse_limit(ch) for pc1, _ in pairs) or not ops.resblock_group_supported(pairs, B, ch, T):
                 return False
         return True
 
@@ -398,7 +406,7 @@ class HifiganGenerator:
                             dst, accum, div = (xa if cur is not xa else xb), None, 0.0
                         if self.resblock_type == "1":
                             pc1, pc2 = P[rp + "convs1.%d" % m], P[rp + "convs2.%d" % m]
-                            if (self.fuse_resblocks and ch in self.fuse_channels and pc1.kernel <= self.fuse_max_kernel.get(ch, 99)
+                            if (self.fuse_resblocks and ch in self.fuse_channels and pc1.kernel <= self._fuse_limit(ch)
                                     and ops.resblock_pair_supported(pc1, pc2)):
                                 if last and side and prev_done is not None:
                                     st.wait_event(prev_done)      # zsum holds the previous branches' sum
