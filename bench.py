@@ -334,8 +334,14 @@ class NodeProbe:
         if not self.rows:
             return {"gpus_on_node": len(self.others) + (1 if self.card else 0)}
         n = len(self.rows)
-        return {"our_sclk_mhz": sum(r[0] for r in self.rows) / n, "our_power_w": sum(r[1] for r in self.rows) / n,
-                "gpus_on_node": len(self.others) + 1, "other_gpus_busy": sum(r[2] for r in self.rows) / n}
+        try:
+            vbios = open(self.card + "/vbios_version").read().strip()
+        except Exception:
+            vbios = None
+        # (the VBIOS string: of the boxes of this pool, those on 113-M355-01-1K1-030A ran the sentence loop in the slow regime and
+        # those on ...-020F in the fast one at identical clocks — DESIGN.md §5)
+        return {"our_sclk_mhz": sum(r[0] for r in self.rows) / n, "gpus_on_node": len(self.others) + 1,
+                "other_gpus_busy": sum(r[2] for r in self.rows) / n, "vbios": vbios}
 
 
 def timer_table(res):

@@ -121,9 +121,13 @@ for _ in range(40):
 lat.sort()
 smi.stop = True
 smi.join(timeout=3)
+try:
+    vbios = open(smi.card + "/vbios_version").read().strip()
+except Exception:
+    vbios = "?"
 rows = smi.rows or [(float("nan"),) * 7]
 mean = lambda k: sum(r[k] for r in rows) / len(rows)  # noqa: E731
 print("BIMODAL %-22s ms/sentence %.3f %.3f | step p50 %.3f p90 %.3f max %.3f | sync latency p50 %.3f min %.3f | OUR card %s: sclk %.0f (min %.0f max %.0f) "
-      "mclk %.0f fclk %.0f busy %.0f%% power %.0f W | %d other GPUs on the node: busy(>20%%) %.1f of them, their power %.0f W (%d samples)"
+      "mclk %.0f fclk %.0f busy %.0f%% power %.0f W vbios " + vbios + " | %d other GPUs on the node: busy(>20%%) %.1f of them, their power %.0f W (%d samples)"
       % (tag, res[0][0], res[1][0], res[1][1], res[1][2], res[1][3], lat[20], lat[0], os.path.basename(os.path.dirname(smi.card)) if smi.card else "?",
          mean(0), min(r[0] for r in rows), max(r[0] for r in rows), mean(1), mean(3), mean(4), mean(2), len(smi.others), mean(5), mean(6), len(rows)), flush=True)
