@@ -86,6 +86,8 @@ glow.to(dev)
 voc = HifiganGenerator(80, 1, hcfg["resblock_type"], hcfg["resblock_dilation_sizes"], hcfg["resblock_kernel_sizes"],
                        hcfg["upsample_kernel_sizes"], hcfg["upsample_initial_channel"], hcfg["upsample_factors"],
                        inference_padding=hcfg["inference_padding"])
+if os.environ.get("GLOW_FUSE_MIX") == "0":       # A/B: affine-coupling conv + separate InvConv / ActNorm kernel instead of the MIX epilogue
+    glow.decoder.fuse_mix = False
 voc.load_state_dict(W.make_hifigan_state(hcfg, 80, seed=1234))
 voc.to(dev)
 T = 64
@@ -128,6 +130,6 @@ except Exception:
 rows = smi.rows or [(float("nan"),) * 7]
 mean = lambda k: sum(r[k] for r in rows) / len(rows)  # noqa: E731
 print("BIMODAL %-22s ms/sentence %.3f %.3f | step p50 %.3f p90 %.3f max %.3f | sync latency p50 %.3f min %.3f | OUR card %s: sclk %.0f (min %.0f max %.0f) "
-      "mclk %.0f fclk %.0f busy %.0f%% power %.0f W vbios " + vbios + " | %d other GPUs on the node: busy(>20%%) %.1f of them, their power %.0f W (%d samples)"
+      "mclk %.0f fclk %.0f busy %.0f%% power %.0f W vbios %s | %d other GPUs on the node: busy(>20%%) %.1f of them, their power %.0f W (%d samples)"
       % (tag, res[0][0], res[1][0], res[1][1], res[1][2], res[1][3], lat[20], lat[0], os.path.basename(os.path.dirname(smi.card)) if smi.card else "?",
-         mean(0), min(r[0] for r in rows), max(r[0] for r in rows), mean(1), mean(3), mean(4), mean(2), len(smi.others), mean(5), mean(6), len(rows)), flush=True)
+         mean(0), min(r[0] for r in rows), max(r[0] for r in rows), mean(1), mean(3), mean(4), mean(2), vbios, len(smi.others), mean(5), mean(6), len(rows)), flush=True)

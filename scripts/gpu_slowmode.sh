@@ -20,4 +20,15 @@ PYTHONPATH=$R timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t
 grep BIMODAL $OUT/tr.log >> $OUT/slowmode.txt
 python $R/scripts/bimodal_trace.py $(find $OUT/tr -name '*kernel_trace.csv' | head -1) traced >> $OUT/slowmode.txt 2>&1
 rm -rf $OUT/tr $OUT/tr.log
+MS=$(grep "BIMODAL asfound" $OUT/slowmode.txt | sed -E 's/.*ms\/sentence ([0-9.]+).*/\1/')
+if [ "$(python -c "print(1 if float('${MS:-0}') > 1.65 else 0)")" = "1" ] || [ -n "$FORCE_VARIANTS" ]; then
+  # a slow-regime box: the two sensitive kernels in their alternative forms (attention: the 8-wave v2 kernel forced; flow-block tail:
+  # affine-coupling conv + separate InvConv / ActNorm kernel instead of the fused MIX epilogue), each traced
+  for V in "TTSAMD_ATT_V2=1" "TTSAMD_ATT_V2=0" "GLOW_FUSE_MIX=0"; do
+    env $V PYTHONPATH=$R timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trv -o g -- python $R/scripts/bimodal_step.py 300 "$V" > $OUT/trv.log 2>&1
+    grep BIMODAL $OUT/trv.log | cut -c1-140 >> $OUT/slowmode.txt
+    python $R/scripts/bimodal_trace.py $(find $OUT/trv -name '*kernel_trace.csv' | head -1) "$V" 2>&1 | grep "TRACE\|attention\|1, 1, 7, 4\|1, 1, 5, 4\|invconv" >> $OUT/slowmode.txt
+    rm -rf $OUT/trv $OUT/trv.log
+  done
+fi
 cat $OUT/slowmode.txt
