@@ -461,6 +461,44 @@ def cpu_baseline_vits(sd, n_chars):
     return out
 
 
+def arithmetic_check(dev):
+    """Measured in the run (a second of work, after the timed region): the error of each conv arithmetic against an fp64 conv on
+    the adversarial operands of tests/test_conv_gpu.py (mantissas that maximise the parts a split drops; |x| in [2^-7, 2^4),
+    |w| in [2^-12, 2^-4); C = 128, k = 11, K = 1408 products per output), as max |err| / sum|w x| over all outputs — the number
+    behind the `dtype` string's "fp32-class"."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    from tts_amd import ops
+
+    rng = np.random.default_rng(128 + 11)
+    C, K, T = 128, 11, 260
+
+    def vals(shape, e_lo, e_hi):
+        n = int(np.prod(shape))
+        mant = (rng.integers(0, 128, n) << 16) | (rng.choice([0x7F, 0x80, 0x7E, 0x81, 0x0F, 0x10], n) << 8) | rng.choice([0x7F, 0x80, 0xFF, 0x01], n)
+        bits = (rng.integers(0, 2, n).astype(np.uint32) << 31) | (rng.integers(e_lo, e_hi + 1, n).astype(np.uint32) << 23) | mant.astype(np.uint32)
+        return torch.from_numpy(bits.view(np.float32).copy()).reshape(shape)
+
+    x, w = vals((1, C, T), 120, 130), vals((C, C, K), 115, 122)
+    want = F.conv1d(x.double(), w.double(), None, padding=K // 2)
+    scale = F.conv1d(x.abs().double(), w.abs().double(), None, padding=K // 2)
+    out = {"operands": "maximal-residual mantissas, C=128 k=11 (1408 products per output), against fp64"}
+    was_p, was_g = ops.conv_precision(), ops.set_conv_small_grid(0)       # the large-grid kernels are the ones the step runs
+    try:
+        pc = ops.PackedConv(w, None, dev)
+        for prec, key in (("h2", "three_fp16_products"), ("x3", "six_bf16_products"), ("f32", "fp32_input_mfma")):
+            ops.set_conv_precision(prec)
+            y = torch.empty(1, C, T, device=dev)
+            ops.conv1d(pc, x.to(dev), y)
+            out[key] = float(((y.cpu().double() - want).abs() / scale).max())
+    finally:
+        ops.set_conv_precision(was_p)
+        ops.set_conv_small_grid(was_g)
+    out["torch_fp32_cpu_conv"] = float(((F.conv1d(x, w, None, padding=K // 2).double() - want).abs() / scale).max())
+    return out
+
+
 def wl_vits_e2e(args, ctx):
     from tts_amd import ops, parallel
     from tts_amd import synthetic as W
@@ -582,6 +620,10 @@ def wl_vits_e2e(args, ctx):
     }
     DETAILS.append({"detail": "configs[1] per-kernel table of the roofline pass (HIP events per launch class)",
                     "per_kernel": timer_table(res)})
+    try:
+        line["arithmetic_max_err_over_sum_abs_wx"] = _round(arithmetic_check(dev))
+    except Exception as e:          # an extra: never cost the headline
+        line["arithmetic_max_err_over_sum_abs_wx"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_vits(sd, args.chars)
     del model
@@ -1259,7 +1301,7 @@ def emit_details(ctx):
     del DETAILS[:]
 
 
-HEADLINE_MAX_BYTES = 2300
+HEADLINE_MAX_BYTES = 2500
 EXTRA_MAX_BYTES = 900
 _ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_8TBps", "frac_of_157TF", "traffic", "traffic_bytes_per_sample",
               "algorithmic_bytes_per_sample",
@@ -1282,7 +1324,8 @@ def compact_line(line, limit=EXTRA_MAX_BYTES):
     if "error" in line and "metric" not in line:
         return line
     out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                                "scaling", "vs_baseline", "dtype", "data", "rtf_x", "rtf_x_per_gpu", "other_configs") if k in line}
+                                "scaling", "vs_baseline", "dtype", "data", "rtf_x", "rtf_x_per_gpu", "other_configs",
+                                "arithmetic_max_err_over_sum_abs_wx") if k in line}
     cfg = dict(line.get("config", {}))
     cfg.pop("weights", None)
     out["config"] = cfg
@@ -1318,6 +1361,7 @@ def headline_json(line):
     are dropped first (never a number that the contract names)."""
     out = json.dumps(line)
     for path in (("roofline", "peak_note"), ("roofline", "measured"), ("roofline", "traffic_source"), ("cpu_baseline", "sample"),
+                 ("arithmetic_max_err_over_sum_abs_wx", "operands"),
                  ("cpu_baseline", "threads_sweep_samples_per_s"), ("config", "weights"), ("roofline", "all_conv_launches"),
                  ("cpu_baseline", "batched_x_lengths_mode"), ("roofline", "kernel")):
         if len(out) <= HEADLINE_MAX_BYTES:

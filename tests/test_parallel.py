@@ -110,7 +110,7 @@ def test_bench_forced_process_group_world1_gloo():
 
 def test_bench_compact_lines_fit_the_tail():
     """bench.compact_line: an extra-workload line keeps every number the contract names and fits its byte budget; the three
-    closing lines of a default run (four extra workloads + the headline) stay under 7 KB together; the `observed` block (step
+    closing lines of a default run (four extra workloads + the headline) stay under 7.2 KB together; the `observed` block (step
     percentiles, regime) survives compaction."""
     sys.path.insert(0, ROOT)
     import bench
@@ -132,7 +132,7 @@ def test_bench_compact_lines_fit_the_tail():
     head = bench.headline_json(bench.compact_line(json.loads(json.dumps(full)), limit=None))
     # four extra lines (configs[0], configs[2], the VITS B=1 request, the XTTS streaming vocoder half) + the headline: inside the
     # ~8 KB of stdout the driver's record keeps (BENCH_r04.json: stdout_tail of 8 081 bytes)
-    assert len(head) <= bench.HEADLINE_MAX_BYTES and 4 * (bench.EXTRA_MAX_BYTES + 70) + bench.HEADLINE_MAX_BYTES <= 7000
+    assert len(head) <= bench.HEADLINE_MAX_BYTES and 4 * (bench.EXTRA_MAX_BYTES + 70) + bench.HEADLINE_MAX_BYTES <= 7200
     full["observed"] = {"step_ms_p50": 1.4712345, "step_ms_p90": 1.49, "step_ms_max": 1.71, "sentence_latency_ms_p50": 1.53,
                         "gpu_ms_per_sentence_p50": 1.44, "warmup_steps_run": 340, "mode": "kernel-chain-bound, fast"}
     c = bench.compact_line(json.loads(json.dumps(full)))
