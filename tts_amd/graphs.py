@@ -199,6 +199,8 @@ class StreamScratch:
             return [obj.data_ptr()]
         if isinstance(obj, dict):
             obj = obj.values()
+        if isinstance(obj, (str, bytes)):
+            return []
         if isinstance(obj, (list, tuple)) or hasattr(obj, "__iter__"):
             out = []
             for v in obj:
