@@ -724,6 +724,24 @@ def wl_glow_hifigan_v2(args, ctx):
         t1_ = time.perf_counter()
         step().cpu()
         lat.append((time.perf_counter() - t1_) * 1e3)
+    # the same sentences with TWO in flight (tts_amd.parallel.Lanes: the next sentence's encoder runs under this one's vocoder) —
+    # a throughput figure next to the sequential loop above, which stays the line's `value` (the reference's call pattern)
+    lanes_ms = None
+    try:
+        from tts_amd import parallel
+
+        lanes = parallel.Lanes(2, device=dev, priority=-1)
+        for _ in range(8):
+            lanes.run(step)
+        lanes.sync()
+        t_l = time.perf_counter()
+        for _ in range(args.steps):
+            lanes.run(step)
+        lanes.sync(timeout_s=60.0)
+        lanes_ms = (time.perf_counter() - t_l) / args.steps * 1e3
+        lanes.close([glow, voc, pipe])
+    except Exception as e:          # an extra: never cost the line
+        lanes_ms = "%s: %s" % (type(e).__name__, e)
     # GPU time of a sentence (first kernel start to last kernel end on the request's stream), LAST: timing events put the queue
     # into profiling mode for the rest of the process (see _run).  step time ~ GPU time: the loop is bound by the sentence's
     # kernel chain; step time >> GPU time: by the host / dispatch path — the two readings of a "slow mode" on another box.
@@ -755,7 +773,7 @@ def wl_glow_hifigan_v2(args, ctx):
     g50 = gpu_ms[len(gpu_ms) // 2]
     line["observed"] = {"step_ms_p50": p50, "step_ms_p90": deltas[int(len(deltas) * 0.9)], "step_ms_max": deltas[-1],
                         "sentence_latency_ms_p50": float(sorted(lat)[len(lat) // 2]), "gpu_ms_per_sentence_p50": g50,
-                        "warmup_steps_run": nw, "node": _round(probe.summary()),
+                        "warmup_steps_run": nw, "two_lanes_ms_per_sentence": lanes_ms, "node": _round(probe.summary()),
                         # which regime this process ran in (1.47 ms in some processes / boxes, 1.85 in others)
                         "mode": ("kernel-chain-bound" if p50 <= 1.12 * g50 else "host/dispatch-bound") +
                                 (", fast" if p50 < 1.6 else ", SLOW")}

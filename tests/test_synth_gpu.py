@@ -267,3 +267,55 @@ def test_sentence_pipeline_equals_the_three_calls(gpu):
         assert l1[0] == lens[r]
         a, b = got[r, 0, : lens[r]].double().cpu(), one[0, 0].double().cpu()
         assert float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()) < 2e-6, r
+
+
+def test_sentence_pipeline_on_two_lanes_equals_one_at_a_time(gpu):
+    """Sentences served with two in flight (parallel.Lanes: the next sentence's encoder runs under this one's vocoder — what
+    bench.py's configs[0] line reports as `two_lanes_ms_per_sentence`): every waveform bit for bit the one the same sentence gets on
+    its own, across captures / replays on both lanes, different lengths interleaved; and `Lanes.close` purges the pipeline's
+    per-lane graphs and the acoustic model's per-lane scratch."""
+    from tts_amd import parallel
+    from tts_amd.glow_tts import GlowTTS
+    from tts_amd.hifigan import HifiganGenerator
+    from tts_amd.synthesizer import SentencePipeline
+
+    gargs = dict(num_flow_blocks_dec=3, num_chars=70, inference_noise_scale=0.3)
+    gargs["encoder_params"] = dict(O.GLOW_DEFAULTS["encoder_params"], num_layers=2)
+    hcfg = dict(W.HIFIGAN_V2)
+    glow = GlowTTS(gargs)
+    glow.load_state_dict(W.make_glow_state(gargs, seed=51))
+    glow.to(gpu)
+    voc = HifiganGenerator(80, 1, hcfg["resblock_type"], hcfg["resblock_dilation_sizes"], hcfg["resblock_kernel_sizes"],
+                           hcfg["upsample_kernel_sizes"], hcfg["upsample_initial_channel"], hcfg["upsample_factors"],
+                           inference_padding=hcfg["inference_padding"])
+    voc.load_state_dict(O.make_hifigan_state(hcfg, 80, seed=52))
+    voc.to(gpu)
+    pipe = SentencePipeline(glow, voc, AudioProcessor(), AudioProcessor())
+    g = torch.Generator().manual_seed(5)
+    reqs = []
+    for T in (21, 30, 21, 26):
+        x = torch.randint(0, 70, (1, T), generator=g).to(gpu)
+        dur = (1 + torch.randint(0, 4, (1, T), generator=g)).float().to(gpu)
+        noise = torch.randn(1, 80, int(dur.sum()), generator=g).to(gpu)
+        reqs.append((x, {"x_lengths": torch.tensor([T], device=gpu), "durations": dur, "noise": noise}))
+    want = []
+    for x, aux in reqs:
+        for _ in range(3):                                   # eager, capture, replay on the default stream
+            wav, lens = pipe(x, aux)
+        want.append((wav.clone(), lens))
+    torch.cuda.synchronize()
+    lanes = parallel.Lanes(2, device=gpu, priority=-1)
+    handles = [o.handle for o in lanes._owned]
+    for rnd in range(4):                                     # each request meets both lanes; graphs are captured per lane
+        outs = []
+        for i, (x, aux) in enumerate(reqs):
+            if rnd % 2:
+                i = len(reqs) - 1 - i
+                x, aux = reqs[i]
+            outs.append((i, lanes.run(pipe, x, aux)))
+        lanes.sync(timeout_s=60.0)
+        for i, (wav, lens) in outs:
+            assert lens == want[i][1] and torch.equal(wav, want[i][0]), (rnd, i)
+    assert any(k[1] in handles for k in pipe._graph.entries)
+    lanes.close([glow, voc, pipe])
+    assert not any(k[1] in handles for k in pipe._graph.entries) and not any(k[0] in handles for k in glow._scratch.sets)
