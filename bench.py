@@ -1320,7 +1320,7 @@ def emit_details(ctx):
 
 
 HEADLINE_MAX_BYTES = 2500
-EXTRA_MAX_BYTES = 900
+EXTRA_MAX_BYTES = 1100
 _ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_8TBps", "frac_of_157TF", "traffic", "traffic_bytes_per_sample",
               "algorithmic_bytes_per_sample",
               "pmc_mfma_busy_frac", "pmc_kernel_cycles", "launches_timed", "avg_launch_us", "algorithmic_bytes_per_launch",
