@@ -404,14 +404,15 @@ def test_small_grid_tiles_and_k_split(gpu, case, conv_precision):
 def test_one_shot_kernel_fused_epilogues(gpu, T, conv_precision):
     """The one-shot small-grid kernel (conv_kernel_x3o.h) under every fused 1x1 epilogue of the flows — WaveNet res/skip split,
     mean-only coupling, Glow's affine coupling both ways with a partly filled last pair tile (80 channels) — with per-item
-    row biases and a ragged mask, against torch; and against the looping kernels (small-grid mode 3)."""
+    row biases and a ragged mask, against torch; and against the looping kernels (small-grid mode 3) and the large-grid kernels (mode 0:
+    under precision "h2" the three-product kernel with every paired-row / split epilogue)."""
     g = torch.Generator().manual_seed(T)
     B, H = 2, 192
     dev = gpu
     mask = (torch.arange(T)[None, :] < torch.tensor([T, max(1, T - 7)])[:, None]).float()
     acts = torch.randn(B, H, T, generator=g)
     outs = {}
-    for mode in (3, 4):
+    for mode in (0, 3, 4):           # 0: the large-grid kernels under the same epilogues (the three-product kernel under "h2")
         was = ops.set_conv_small_grid(mode)
         try:
             # res/skip: rows < H: x = (x + v) * mask, rows >= H: out = out + v
@@ -460,6 +461,8 @@ def test_one_shot_kernel_fused_epilogues(gpu, T, conv_precision):
     if conv_precision == "x3":
         for k in (ops.CONV_COUPLE_AFFINE, ops.CONV_COUPLE_AFFINE_FWD, "gate"):
             assert _rel(outs[(4, k)], outs[(3, k)]) < 2e-6, k
+    for k in (ops.CONV_COUPLE_AFFINE, ops.CONV_COUPLE_AFFINE_FWD, "gate"):
+        assert _rel(outs[(0, k)], outs[(3, k)]) < 4e-6, k
 
 
 @pytest.mark.parametrize("case", [(2, 40, 48, 9, 2, 130), (1, 192, 70, 13, 1, 77), (1, 16, 16, 4, 1, 50), (2, 33, 20, 31, 27, 900),
