@@ -62,3 +62,16 @@ for K in (3, 7, 11):
         t1 = time_us(lambda: ops.resblock_pair(pc1, pc2, x, y, slope=0.1, variant=1))
         print("  k=%2d d=%d: default (%s) %7.1f us   alternative %7.1f us   alt/default %.3f" % (K, D, "8-wave" if K == 11 else "4-wave", t0, t1, t1 / t0), flush=True)
         del x, y
+
+print("(c) C = 128 fused pairs: 4 waves / 64 columns (default since this measurement: two blocks per CU) vs the 8-wave / 128-column tile (variant 1), h2")
+T = 49280
+for K in (3, 7):
+    for D in (1, 5):
+        pc1, pc2 = pair(128, K, D, K + D)
+        x = torch.randn(B, 128, T, device=dev)
+        y, y1 = torch.empty_like(x), torch.empty_like(x)
+        t0 = time_us(lambda: ops.resblock_pair(pc1, pc2, x, y, slope=0.1))
+        t1 = time_us(lambda: ops.resblock_pair(pc1, pc2, x, y1, slope=0.1, variant=1))
+        rel = float((y1 - y).double().pow(2).mean().sqrt() / y.double().pow(2).mean().sqrt())
+        print("  k=%2d d=%d: 4-wave/64-col %7.1f us   8-wave/128-col %7.1f us   8-wave / 4-wave %.3f   rel diff %.1e" % (K, D, t0, t1, t1 / t0, rel), flush=True)
+        del x, y, y1

@@ -370,12 +370,18 @@ int resblock_pair_h2_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
         case 16: return resblock_pair_h2_launch_cfg<K, D, 16, 1, 4, 2>(a, st);
         case 32: return resblock_pair_h2_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:
+            // (one n-tile per wave — half the columns, three blocks per CU — measured 1.14-1.22x SLOWER at 64 and 32 channels)
             // the 4-wave / 128-column tile for every kernel size (two blocks per CU: one block's staging and epilogue phases run
             // under the other's MFMAs); on six products k = 11 preferred the 8-wave / 256-column tile (4 % halo work instead of
             // 8 %), on three it is 1.5-2 % slower (scripts/h2_variants_ab.py); variant 1 selects it for A/B
             if (a.variant == 1) return resblock_pair_h2_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
             return resblock_pair_h2_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
-        case 128: return resblock_pair_h2_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
+        case 128:
+            // 4 waves x 64 mid columns: two blocks per CU (one block's staging / epilogue phases run under the other's MFMAs) instead
+            // of one 8-wave / 128-column block — 0.92-0.98 of its time at k = 3 and 7, bitwise the same results
+            // (scripts/h2_variants_ab.py); variant 1 selects the 8-wave tile for A/B
+            if (a.variant == 1) return resblock_pair_h2_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
+            return resblock_pair_h2_launch_cfg<K, D, 128, 4, 1, 2>(a, st);
     }
     set_error("resblock_pair: c = %d has no instantiation (8, 16, 32, 64, 128)", a.c);
     return TTSAMD_ERR_UNSUPPORTED;
