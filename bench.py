@@ -338,10 +338,10 @@ class NodeProbe:
             vbios = open(self.card + "/vbios_version").read().strip()
         except Exception:
             vbios = None
-        # (the VBIOS string: of the boxes of this pool, those on 113-M355-01-1K1-030A ran the sentence loop in the slow regime and
-        # those on ...-020F in the fast one at identical clocks — DESIGN.md §5)
+        # (VBIOS and host kernel: the two slow-regime boxes whose configuration was recorded differ from the thirteen fast ones in
+        # this pairing — one runs VBIOS ...-030A, one host kernel 6.18.50 instead of ...-020F + 6.18.51 — at identical clocks: DESIGN.md §5)
         return {"our_sclk_mhz": sum(r[0] for r in self.rows) / n, "gpus_on_node": len(self.others) + 1,
-                "other_gpus_busy": sum(r[2] for r in self.rows) / n, "vbios": vbios}
+                "other_gpus_busy": sum(r[2] for r in self.rows) / n, "vbios": vbios, "host_kernel": os.uname().release}
 
 
 def timer_table(res):
