@@ -215,6 +215,23 @@ def pmc_state(name):
             else "null: committed PMC file is stale (recorded with stamp %s, running %s)" % (d.get("code_stamp"), code_stamp()))
 
 
+def kernel_family(name):
+    """Kernel name -> the family key the per-family traffic table uses: conv k/d/mode, fused pair k/d/c, conv_post, other."""
+    import re
+
+    name = name.replace(" ", "")
+    m = re.search(r"conv1d_\w+_kernel<(\d+),(\d+),(?:[^>]*,)?(\d+)>", name)
+    if m:
+        return "conv k%s d%s mode%s" % m.groups()
+    m = re.search(r"resblock_pair_\w+_kernel<(\d+),(\d+),(\d+),", name)
+    if m:
+        return "pair k%s d%s c%s" % m.groups()
+    if "conv_post_kernel" in name:
+        return "conv_post"
+    m = re.search(r"(\w+)_kernel", name)
+    return m.group(1) if m else name[:24]
+
+
 def pmc_passes(target_argv, match, timeout_s=200):
     """Two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE — one counter set per pass, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a child process `python target_argv...`; per counter the sum over the
@@ -240,14 +257,17 @@ def pmc_passes(target_argv, match, timeout_s=200):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc=%d)" % (ctr, r.returncode)
-            per = {}
+            per, by_kernel = {}, {}
             for row in csv.DictReader(open(files[0])):
                 name = row["Kernel_Name"].replace(" ", "")
                 if row["Counter_Name"] == ctr and any(m in name for m in match):
                     per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                    fam = kernel_family(name)
+                    by_kernel[fam] = by_kernel.get(fam, 0.0) + float(row["Counter_Value"])
             if not per:
                 return None, "no dispatch of %s in the counter file" % (match,)
             vals[ctr] = (sum(per.values()), len(per))
+            vals[ctr + "_by_family"] = by_kernel
     except Exception as e:          # the measurement is an extra: never cost the bench line
         return None, "%s: %s" % (type(e).__name__, e)
     finally:
@@ -867,7 +887,17 @@ def wl_hifigan_v1(args, ctx):
         torch.cuda.synchronize()
         ops.set_conv_timer(None)
         m.concurrent_branches = was
-        sub = timer_table(st.results())
+        sub_raw = st.results()
+        sub = timer_table(sub_raw)
+        # time-weighted mean over the whole HBM subset (total algorithmic bytes / total event time): the typical launch, next to
+        # the best one
+        # (HBM-priced launches only: algorithmic bytes / 8 TB/s >= algorithmic FLOP / the matrix peak — the timer also sees the
+        # matrix-priced fused pairs)
+        pk = conv_peak(args.precision) * 1e12
+        hb = [v for v in sub_raw.values() if v["launches"] and v["bytes"] / (PEAK_HBM_GBPS * 1e9) >= v["flops"] / pk]
+        sb = sum(v["bytes"] for v in hb)
+        sms = sum(v["ms"] for v in hb)
+        sub_mean = (sb / (sms * 1e-3) / 1e9 / PEAK_HBM_GBPS) if sms > 0 else 0.0
     if ctx.rank != 0:
         return None
     r = dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)          # plain convs ("conv") + fused ResBlock pairs
@@ -889,7 +919,7 @@ def wl_hifigan_v1(args, ctx):
     # HBM traffic of one step, measured in this run: the PMC passes run the generator on ONE 4-item slab in a child process
     # (scripts/pmc_hifigan_target.py: every conv / fused-pair / conv_post dispatch counted) and the bytes per output sample
     # are scaled to the step; next to it the layer-by-layer algorithmic figure of SURVEY §8(d) (21 237 B per sample)
-    traffic, traffic_note, per_sample = None, "skipped (--no-live-pmc)", None
+    traffic, traffic_note, per_sample, traffic_excess = None, "skipped (--no-live-pmc)", None, None
     if ctx.world == 1 and not args.no_live_pmc:
         pm_items, pm_frames = 4, args.frames
         vals, why = pmc_passes([os.path.join(ROOT, "scripts", "pmc_hifigan_target.py"), args.precision, str(pm_items), str(pm_frames)],
@@ -901,18 +931,48 @@ def wl_hifigan_v1(args, ctx):
             slab_samples = float(pm_items * (pm_frames + 10) * 256)
             per_sample = (vals["FETCH_SIZE"][0] * 1024 * 2 + vals["WRITE_SIZE"][0] * 1024) / runs / slab_samples
             traffic = per_sample * samples / ctx.world
+            # where the bytes above the algorithmic figure come from: per kernel family, counters of the slab vs the algorithmic
+            # bytes of the same launches (input + output (+ residual / accumulate) once; ConvTimer over the same slab here)
+            try:
+                was = m.concurrent_branches
+                m.concurrent_branches = False
+                ft = ops.ConvTimer(lambda pc, a: "conv_post" if pc.c_out == 1 else "conv k%d d%d mode%d" % (pc.kernel, pc.dilation, a.mode))
+                ft.select_pair = lambda pc1, a: "pair k%d d%d c%d" % (a.kernel, a.dilation, a.c)
+                ops.set_conv_timer(ft)
+                m.inference(mel[:pm_items])
+                torch.cuda.synchronize()
+                ops.set_conv_timer(None)
+                m.concurrent_branches = was
+                alg = {k: v["bytes"] for k, v in ft.results().items() if v["launches"]}
+                meas = {}
+                for fam, kib in vals["FETCH_SIZE_by_family"].items():
+                    meas[fam] = meas.get(fam, 0.0) + kib * 1024 * 2 / runs
+                for fam, kib in vals["WRITE_SIZE_by_family"].items():
+                    meas[fam] = meas.get(fam, 0.0) + kib * 1024 / runs
+                tot_alg = sum(alg.values())
+                rows = sorted(((meas.get(k, 0.0) - alg.get(k, 0.0), k) for k in set(meas) | set(alg)), reverse=True)
+                excess = {k: {"measured_MB": meas.get(k, 0.0) / 1e6, "algorithmic_MB": alg.get(k, 0.0) / 1e6,
+                              "excess_share_of_algorithmic_total": d / tot_alg} for d, k in rows}
+                DETAILS.append({"detail": "configs[2] traffic by kernel family over one %d-item slab: PMC bytes (FETCH x2 + WRITE) vs the "
+                                          "algorithmic bytes of the same launches" % pm_items, "families": excess})
+                top = [(k, v) for k, v in excess.items()][:3]
+                traffic_excess = {"measured_over_algorithmic": sum(meas.values()) / tot_alg,
+                                  "top": {k: round(v["excess_share_of_algorithmic_total"], 4) for k, v in top}}
+            except Exception as e:      # an attribution table must never cost the line
+                traffic_excess = {"error": "%s: %s" % (type(e).__name__, e)}
             traffic_note = ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over every conv / "
                             "fused-pair / conv_post dispatch (%d per slab) of a %d-item x %d-frame slab, %.0f B per output sample, scaled "
                             "to the step's samples" % (vals["FETCH_SIZE"][1] // runs, pm_items, pm_frames, per_sample))
     line["roofline"] = {"bound": "mfma", "kernel": "all conv launches of the generator (%s)" % conv_kernel_name(args.precision, "..."),
                         "achieved": ach, "peak": conv_peak(args.precision), "unit": "TFLOP/s",
                         "frac": ach / conv_peak(args.precision),
-                        "traffic": traffic, "traffic_source": traffic_note,
+                        "traffic": traffic, "traffic_source": traffic_note, "traffic_excess": traffic_excess,
                         "traffic_bytes_per_sample": per_sample, "algorithmic_bytes_per_sample": r["bytes"] / (samples / ctx.world * steps),
                         "algorithmic_bytes_per_sample_layer_by_layer": 21237.0,
                         "algorithmic_gbps": r["bytes"] / elapsed_max / 1e9, "launches_timed": r["launches"],
                         "measured": "algorithmic conv FLOP of the timed steps / wall time of the timed region",
-                        "hbm_subset_best_frac_of_8TBps": max([v["frac_of_8TBps"] for v in sub.values()] or [0.0])}
+                        "hbm_subset_best_frac_of_8TBps": max([v["frac_of_8TBps"] for v in sub.values()] or [0.0]),
+                        "hbm_subset_mean_frac_of_8TBps": sub_mean}
     DETAILS.append({"detail": "configs[2] hbm_subset: launches bound by HBM, not the matrix pipe (SURVEY App. A): algorithmic "
                               "bytes (input + output (+ residual / accumulate) once) / HIP-event time, one 16-item slab, "
                               "branches serialised; peak 8000 GB/s (a float4 copy reaches 6290)", "launches": sub})
@@ -981,14 +1041,20 @@ def wl_mas(args, ctx):
         nb = min(B, 32)
         v, mm = value[:nb].cpu().numpy(), mask[:nb].astype(np.float32)
         c32 = float(sum(int(a) * int(b) - int(a) * (int(a) - 1) for a, b in zip(tx[:nb], ty[:nb])))
-        omas.maximum_path(v, mm, "c")
+        # the reference's own Cython core (oracle/_ref, compiled from core.pyx in the build container; it travels with the
+        # snapshot) when present, else the C restatement — both single-threaded, as the reference ships it
+        impl, kind = ("ref", "reference") if omas.ref_maximum_path_c() is not None else ("c", "port")
+        omas.maximum_path(v, mm, impl)
+        reps = 5
         t0 = time.time()
-        for _ in range(3):
-            omas.maximum_path(v, mm, "c")
-        dt = (time.time() - t0) / 3
-        line["cpu_baseline"] = {"value": c32 / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-                                "sample": "first %d items of the same problem, C restatement of core.pyx (single thread, as "
-                                          "the reference ships it)" % nb}
+        for _ in range(reps):
+            omas.maximum_path(v, mm, impl)
+        dt = (time.time() - t0) / reps
+        line["cpu_baseline"] = {"value": c32 / dt, "unit": "cells/s", "cores": 1, "kind": kind,
+                                "sample": "first %d items of the same problem, %s (single thread, as the reference ships it), %d reps, "
+                                          "%.1f ms per call" % (nb, "core.pyx compiled into oracle/_ref" if impl == "ref" else
+                                                                "C restatement of core.pyx", reps, dt * 1e3)}
+        line["observed"] = {"ms_per_call": ms, "gpu_over_cpu": (cells / (ms * 1e-3)) / (c32 / dt)}
     return line
 
 
@@ -1220,7 +1286,7 @@ def main():
                          "configs[2], vocoder only; launch_check = the multi-rank skeleton without kernels (CPU-runnable)")
     ap.add_argument("--frames", type=int, default=8192, help="hifigan_v1: mel frames per item")
     ap.add_argument("--items", type=int, default=256, help="hifigan_v1: items per GPU per step")
-    ap.add_argument("--hifigan-steps", type=int, default=None, help="hifigan_v1: timed steps (default --steps; 1 as an extra)")
+    ap.add_argument("--hifigan-steps", type=int, default=None, help="hifigan_v1: timed steps (default --steps; 3 as an extra)")
     ap.add_argument("--hifigan-warmup", type=int, default=None)
     ap.add_argument("--mas-batch", type=int, default=32, help="mas: items per GPU")
     ap.add_argument("--unfused-sentence", action="store_true",
@@ -1279,7 +1345,8 @@ def _run(args):
         torch.cuda.empty_cache()
         common = ["--precision", args.precision] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
         for name, extra_args in (("configs[0] glow_hifigan_v2", ["--workload", "glow_hifigan_v2", "--steps", "200", "--warmup", "5"]),
-                                 ("configs[2] hifigan_v1", ["--workload", "hifigan_v1", "--steps", str(args.hifigan_steps or 1),
+                                 ("mas [32,257,770] (row a1)", ["--workload", "mas", "--mas-batch", "32", "--steps", "50", "--warmup", "3"]),
+                                 ("configs[2] hifigan_v1", ["--workload", "hifigan_v1", "--steps", str(args.hifigan_steps or 3),
                                                             "--warmup", str(1 if args.hifigan_warmup is None else args.hifigan_warmup),
                                                             "--items", str(args.items), "--frames", str(args.frames)] +
                                   (["--no-live-pmc"] if args.no_live_pmc else [])),
@@ -1325,7 +1392,8 @@ EXTRA_MAX_BYTES = 1100
 _ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_8TBps", "frac_of_157TF", "traffic", "traffic_bytes_per_sample",
               "algorithmic_bytes_per_sample",
               "pmc_mfma_busy_frac", "pmc_kernel_cycles", "launches_timed", "avg_launch_us", "algorithmic_bytes_per_launch",
-              "all_conv_launches", "hbm_subset_best_frac_of_8TBps", "traffic_source", "launches_per_request")
+              "all_conv_launches", "hbm_subset_best_frac_of_8TBps", "hbm_subset_mean_frac_of_8TBps", "traffic_excess", "traffic_source",
+              "launches_per_request")
 _CPU_KEEP = ("value", "unit", "cores", "kind", "host_cores", "reps", "value_min", "value_max", "batched_x_lengths_mode", "sample")
 
 

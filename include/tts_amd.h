@@ -25,6 +25,8 @@ extern "C" {
 #define TTSAMD_ERR_INVALID (-1)     /* bad argument (shape, NULL, unsupported kernel size ...) */
 #define TTSAMD_ERR_UNSUPPORTED (-2) /* valid request outside what the kernels cover (documented limits) */
 #define TTSAMD_ERR_HIP (-3)         /* a HIP runtime call / launch failed */
+#define TTSAMD_ERR_INTERNAL (-4)    /* host-side failure inside the library (out of host memory, an unexpected C++ exception): the
+                                       handle entries run behind an exception barrier, nothing unwinds into the caller */
 
 const char *ttsamd_last_error(void);
 /* ABI version (bumped on any signature change) and the gfx arch the library was compiled for. */

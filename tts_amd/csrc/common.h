@@ -5,6 +5,8 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <exception>
+#include <new>
 
 #include "../../include/tts_amd.h"
 
@@ -31,6 +33,24 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
             return TTSAMD_ERR_HIP;                                                               \
         }                                                                                        \
     } while (0)
+
+// Exception barrier of the C ABI (include/tts_amd.h: "never throws/aborts across the ABI").  The kernel-level entries are plain
+// C-style code; the model-level handles (hifigan_model.hip, vits_model.hip, glow_model.hip) use the standard library, so every
+// extern "C" entry of theirs runs its body through abi_guard: an exception becomes TTSAMD_ERR_INTERNAL + ttsamd_last_error().
+template <class F>
+inline int abi_guard(const char *where, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_error("%s: out of host memory", where);
+    } catch (const std::exception &e) {
+        set_error("%s: %s", where, e.what());
+    } catch (...) {
+        set_error("%s: unknown C++ exception", where);
+    }
+    return TTSAMD_ERR_INTERNAL;
+}
 
 extern std::atomic<unsigned long long> g_launches;       // kernel launches issued through the ABI (ttsamd_launch_count)
 #define TTSAMD_LAUNCH_CHECK()                                        \

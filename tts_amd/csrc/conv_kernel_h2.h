@@ -29,6 +29,8 @@
 // during iteration c-1, its maximum known since the last barrier), then requests chunk c+2 into the same registers, and takes
 // that chunk's maximum just before the barrier.
 #pragma once
+#include <type_traits>
+
 #include "conv_kernel_x3.h"
 
 namespace ttsamd {
@@ -51,8 +53,19 @@ struct ConvGeomH2 {
     static constexpr int kXWp = kXW + 1;                     // + one dump column per plane (idle lanes of the last staging round)
     static constexpr int kPartBytes = kXWp * 32;             // [half][column][8 ch] fp16
     static constexpr int kBufBytes = 2 * kPartBytes;
-    static constexpr int kItems = 2 * kXW;
-    static constexpr int kNStage = (kItems + kThreads - 1) / kThreads;
+    static constexpr int kItems = 2 * kXW;                      // (half, column) items of 8 channels
+    // Staging work is dealt out evenly: kFull rounds in which every thread stages one 8-channel item, and the kRem items left
+    // over (the halo columns: 4 of 260 items at k = 3 on the 128-column tile) as SINGLE elements, kSingles per thread — before
+    // round 6 they cost every thread a whole extra 8-channel round (16 staged values per thread and chunk instead of 9).
+    static constexpr int kFull = kItems / kThreads;
+    static constexpr int kRem = kItems - kFull * kThreads;
+    static constexpr int kSingles = (kRem * 8 + kThreads - 1) / kThreads;
+    static constexpr int kNStage = kFull + (kSingles > 0 ? 1 : 0);   // staging steps (K >= 7 spreads them over the taps)
+    // K < 7: too few MFMAs per chunk to cover an HBM round trip with one chunk of lead -> two register sets, requests two chunks ahead
+#ifndef TTSAMD_H2_DEEP
+#define TTSAMD_H2_DEEP 1
+#endif
+    static constexpr int kSets = (K < 7 && TTSAMD_H2_DEEP) ? 2 : 1;
     static constexpr int kSlotBytes = 2 * 8 * 4;             // [chunk parity][wave] largest magnitude (bit pattern)
     static constexpr size_t kLdsBytes = (size_t)2 * kBufBytes + kSlotBytes;
     static_assert(WM * WN == 4 || WM * WN == 8, "the maximum slots are read four at a time");
@@ -113,52 +126,76 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
     constexpr int kOob = kConvOob;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * a.x_bstride, ((long)(a.c_in - 1) * a.x_rstride + a.t_in) * 4);
 
-    int soff[G::kNStage];
-    float smask[G::kNStage];
+    constexpr int kFull = G::kFull, kRem = G::kRem, kSingles = G::kSingles, kSets = G::kSets;
+    int soff[kFull > 0 ? kFull : 1], soff1[kSingles > 0 ? kSingles : 1], lds1[kSingles > 0 ? kSingles : 1];
+    float smask[kFull > 0 ? kFull : 1], smask1[kSingles > 0 ? kSingles : 1];
+    {
+        const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.in_mask ? a.in_mask + (long)b * a.t_in : nullptr, a.in_mask ? (long)a.t_in * 4 : 0);
+        const bool has_m = a.in_mask != nullptr;
 #pragma unroll
-    for (int i = 0; i < G::kNStage; ++i) {
-        const int e = tid + i * G::kThreads;
-        const int half = e / G::kXW;
-        const int col = e - half * G::kXW;
-        const int gt = t0 - a.pad_left + col;
-        const bool ok = (e < G::kItems) && (gt >= 0) && (gt < a.t_in);
-        soff[i] = ok ? (int)(((long)(half * 8) * a.x_rstride + gt) * 4) : kOob;
-        smask[i] = 1.f;
-    }
-    if (a.in_mask) {
-        const __amdgpu_buffer_rsrc_t rm = make_rsrc(a.in_mask + (long)b * a.t_in, (long)a.t_in * 4);
-#pragma unroll
-        for (int i = 0; i < G::kNStage; ++i) {
+        for (int i = 0; i < kFull; ++i) {
             const int e = tid + i * G::kThreads;
-            const int col = e - (e / G::kXW) * G::kXW;
+            const int half = e / G::kXW;
+            const int col = e - half * G::kXW;
             const int gt = t0 - a.pad_left + col;
-            smask[i] = ld_buf(rm, (gt >= 0 && gt < a.t_in) ? gt * 4 : kOob, 0);
+            const bool ok = (gt >= 0) && (gt < a.t_in);
+            soff[i] = ok ? (int)(((long)(half * 8) * a.x_rstride + gt) * 4) : kOob;
+            smask[i] = has_m ? ld_buf(rm, ok ? gt * 4 : kOob, 0) : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < kSingles; ++q) {
+            // element s of the left-over items: channel s / kRem of item kFull * kThreads + s % kRem (consecutive lanes: consecutive columns)
+            const int sidx = tid + q * G::kThreads;
+            const bool valid = sidx < kRem * 8;
+            const int ch = sidx / (kRem > 0 ? kRem : 1);
+            const int e = kFull * G::kThreads + (sidx - ch * kRem);
+            const int half = e / G::kXW;
+            const int col = e - half * G::kXW;
+            const int gt = t0 - a.pad_left + col;
+            const bool ok = valid && (gt >= 0) && (gt < a.t_in);
+            soff1[q] = ok ? (int)(((long)(half * 8 + ch) * a.x_rstride + gt) * 4) : kOob;
+            smask1[q] = has_m ? ld_buf(rm, ok ? gt * 4 : kOob, 0) : 1.f;
+            lds1[q] = valid ? half * (G::kXWp * 16) + col * 16 + ch * 2 : G::kXW * 16 + (tid & 7) * 2;    // idle lanes: the dump column
         }
     }
     const int row_bytes = (int)a.x_rstride * 4;
-    float st[G::kNStage][8];
-    auto stage_load_item = [&](int i, int chunk) {      // chunks beyond c_in read as zeros (buffer range check), no memory traffic
+    float st8[kSets][kFull > 0 ? kFull : 1][8], st1[kSets][kSingles > 0 ? kSingles : 1];
+    // staging step i of a chunk: i < kFull one 8-channel item, i == kFull the single elements.  Chunks beyond c_in read as zeros
+    // (buffer range check), no memory traffic
+    auto stage_load_step = [&](auto set, int i, int chunk) {
         const int cb = chunk * kConvCK * row_bytes;
+        if (i < kFull) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) st[i][c] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb + c * row_bytes, 0);
+            for (int c = 0; c < 8; ++c) st8[set][i][c] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb + c * row_bytes, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < kSingles; ++q) st1[set][q] = ld_buf(rx, soff1[q] == kOob ? kOob : soff1[q] + cb, 0);
+        }
     };
     // mask + activation in place, and this wave's largest magnitude of the chunk -> its slot
     const bool has_in_mask = a.in_mask != nullptr;
-    auto stage_act_max = [&](int parity) {
+    auto stage_act_max = [&](auto set, int parity) {
         float m = 0.f;
         if (has_in_mask) {                          // block-uniform: an unmasked launch pays no multiply per value
 #pragma unroll
-            for (int i = 0; i < G::kNStage; ++i)
+            for (int i = 0; i < kFull; ++i)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) st[i][c] *= smask[i];
+                for (int c = 0; c < 8; ++c) st8[set][i][c] *= smask[i];
+#pragma unroll
+            for (int q = 0; q < kSingles; ++q) st1[set][q] *= smask1[q];
         }
 #pragma unroll
-        for (int i = 0; i < G::kNStage; ++i)
+        for (int i = 0; i < kFull; ++i)
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                st[i][c] = conv_in_act(st[i][c], a.in_act, a.in_slope);
-                m = __builtin_fmaxf(m, __builtin_fabsf(st[i][c]));
+                st8[set][i][c] = conv_in_act(st8[set][i][c], a.in_act, a.in_slope);
+                m = __builtin_fmaxf(m, __builtin_fabsf(st8[set][i][c]));
             }
+#pragma unroll
+        for (int q = 0; q < kSingles; ++q) {
+            st1[set][q] = conv_in_act(st1[set][q], a.in_act, a.in_slope);
+            m = __builtin_fmaxf(m, __builtin_fabsf(st1[set][q]));
+        }
         const unsigned wmax = wave_max_u32(__builtin_bit_cast(unsigned, m));
         slots[parity * 8 + wave] = wmax;
     };
@@ -171,23 +208,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         }
         return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
     };
-    auto stage_store_item = [&](int i, unsigned char *buf, float scale) {
-        const int e = tid + i * G::kThreads;
-        const int half = (e < G::kItems) ? e / G::kXW : 1;
-        const int col = (e < G::kItems) ? e - half * G::kXW : G::kXW;
-        unsigned pw[2][4];
+    auto stage_store_step = [&](auto set, int i, unsigned char *buf, float scale) {
+        if (i < kFull) {
+            const int e = tid + i * G::kThreads;
+            const int half = e / G::kXW;
+            const int col = e - half * G::kXW;
+            unsigned pw[2][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) conv_split2x2(st[i][2 * c] * scale, st[i][2 * c + 1] * scale, pw[0][c], pw[1][c]);
+            for (int c = 0; c < 4; ++c) conv_split2x2(st8[set][i][2 * c] * scale, st8[set][i][2 * c + 1] * scale, pw[0][c], pw[1][c]);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            u32x4 w;
-            w.x = pw[q][0];
-            w.y = pw[q][1];
-            w.z = pw[q][2];
-            w.w = pw[q][3];
-            *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + half * (G::kXWp * 16) + col * 16) = w;
+            for (int q = 0; q < 2; ++q) {
+                u32x4 w;
+                w.x = pw[q][0];
+                w.y = pw[q][1];
+                w.z = pw[q][2];
+                w.w = pw[q][3];
+                *reinterpret_cast<u32x4 *>(buf + q * G::kPartBytes + half * (G::kXWp * 16) + col * 16) = w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kSingles; ++q) {
+                const float x = st1[set][q] * scale;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);           // the arithmetic of conv_split2x2
+                *reinterpret_cast<_Float16 *>(buf + lds1[q]) = hi;
+                *reinterpret_cast<_Float16 *>(buf + G::kPartBytes + lds1[q]) = lo;
+            }
         }
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, kSets - 1>;
     // K >= 7: item i is converted (and the same registers re-requested for the chunk after) at tap i; shorter kernels do all of
     // it at the top of the iteration (too few taps to spread over)
     constexpr bool kPipe = K >= 7;
@@ -209,8 +259,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
     const int max_row_exp = reinterpret_cast<const H2RowTable *>(table)->max_row_exp;
     const float *const row_tab = reinterpret_cast<const float *>(table + sizeof(H2RowTable));     // [row][scale, unscale]
 
+    // chunk n lives in register set n % kSets
 #pragma unroll
-    for (int i = 0; i < G::kNStage; ++i) stage_load_item(i, 0);
+    for (int i = 0; i < G::kNStage; ++i) stage_load_step(Set0{}, i, 0);
+    if constexpr (kSets == 2) {
+#pragma unroll
+        for (int i = 0; i < G::kNStage; ++i) stage_load_step(Set1{}, i, 1);
+    }
     bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(accm, a, b, mb, t0, wm, wn, h, j);    // raw residual (or zeros)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -218,13 +273,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accx[mi][ni][r] = 0.f;
-    stage_act_max(0);
+    stage_act_max(Set0{}, 0);
     __syncthreads();
     int e_run = h2_exp_for(chunk_max(0));
 #pragma unroll
-    for (int i = 0; i < G::kNStage; ++i) stage_store_item(i, xh2, pow2f(e_run));
+    for (int i = 0; i < G::kNStage; ++i) stage_store_step(Set0{}, i, xh2, pow2f(e_run));
 #pragma unroll
-    for (int i = 0; i < G::kNStage; ++i) stage_load_item(i, 1);
+    for (int i = 0; i < G::kNStage; ++i) stage_load_step(Set0{}, i, kSets);       // chunk 1 (one set) / chunk 2 (two sets)
     if (folded) {
         // the residual enters the accumulators in their units: 2^(activation exponent + row exponent); kept out (and added by
         // the epilogue instead) in the corner where that factor could overflow
@@ -250,11 +305,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
                     for (int r = 0; r < 16; ++r) accm[mi][ni][r] = 0.f;
         }
     }
-    stage_act_max(1);
+    stage_act_max(Set1{}, 1);             // chunk 1
     __syncthreads();
 
     const int bbyte = h * (G::kXWp * 16) + (wn * (32 * NI) + j) * 16;
-    for (int c = 0; c < nchunks; ++c) {
+    // iteration c: chunk c + 1 (registers `s1`, maximum known since the last barrier) is converted into the other LDS buffer and its
+    // registers re-requested for chunk c + 1 + kSets; chunk c's MFMAs; chunk c + 2 (registers `s2`) gets mask / activation / maximum
+    auto iteration = [&](int c, auto s1, auto s2) {
         const unsigned char *cur = xh2 + (c & 1) * G::kBufBytes + bbyte;
         unsigned char *const nxt = xh2 + ((c + 1) & 1) * G::kBufBytes;
         // exponent of chunk c + 1 (its maximum is in the slots since the last barrier)
@@ -266,9 +323,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         const float s_next = pow2f(e_next);
         if constexpr (!kPipe) {
 #pragma unroll
-            for (int i = 0; i < G::kNStage; ++i) stage_store_item(i, nxt, s_next);
+            for (int i = 0; i < G::kNStage; ++i) stage_store_step(s1, i, nxt, s_next);
 #pragma unroll
-            for (int i = 0; i < G::kNStage; ++i) stage_load_item(i, c + 2);
+            for (int i = 0; i < G::kNStage; ++i) stage_load_step(s1, i, c + 1 + kSets);
         }
 #pragma unroll
         for (int tap = 0; tap < K; ++tap) {
@@ -280,8 +337,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
             if constexpr (kPipe) {
                 if (tap < G::kNStage) {
-                    stage_store_item(tap, nxt, s_next);
-                    stage_load_item(tap, c + 2);
+                    stage_store_step(s1, tap, nxt, s_next);
+                    stage_load_step(s1, tap, c + 1 + kSets);
                 }
             }
 #pragma unroll
@@ -301,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
 #pragma unroll
                 for (int q = 0; q < 2; ++q) a_cur[mi][q] = a_nxt[mi][q];
         }
-        stage_act_max(c & 1);             // chunk c + 2 (same parity as c)
+        stage_act_max(s2, c & 1);         // chunk c + 2 (same parity as c)
         if (e_next != e_run) {            // block-uniform, rare: the accumulators follow the running exponent (exact power of two)
             const float f = pow2f(e_next - e_run < -126 ? -126 : e_next - e_run);
 #pragma unroll
@@ -316,6 +373,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
             e_run = e_next;
         }
         __syncthreads();
+    };
+    if constexpr (kSets == 2) {
+        for (int c = 0; c < nchunks; c += 2) {
+            iteration(c, Set1{}, Set0{});
+            if (c + 1 >= nchunks) break;
+            iteration(c + 1, Set0{}, Set1{});
+        }
+    } else {
+        for (int c = 0; c < nchunks; ++c) iteration(c, Set0{}, Set0{});
     }
 
     // the two accumulators meet and leave the scaled units (activation exponent, then the row's), then the shared epilogue

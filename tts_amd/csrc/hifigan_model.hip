@@ -255,16 +255,34 @@ void fill_conv_args(const Model &m, ttsamd_conv1d_args &a, const PackedConv &pc,
     a.w_h2 = (m.precision == 0 && pc.tuned) ? pc.w_h2.p : nullptr;
 }
 
+// Activation workspace: a head (masks, padded input, conv_pre's output) and TWO stage arenas used alternately — after an upsample
+// stage only its output is live, so stage i + 1 reuses the arena of stage i - 1.  The size pass (dry) records the peak of each arena;
+// the real pass places arena 1 behind arena 0's peak.  (Before round 6 every stage took fresh memory: about 3x the live set.)
 struct Workspace {
     unsigned char *base;
     size_t used = 0, cap;
     bool dry;              // size pass: nothing is launched
+    size_t head = 0, arena_peak[2] = {0, 0}, arena_used[2] = {0, 0};
+    int arena = -1;        // -1: the head
+    void begin_stage(int i)
+    {
+        if (arena < 0) head = used;
+        arena = i & 1;
+        arena_used[arena] = 0;
+    }
     float *take(size_t floats)
     {
         const size_t bytes = (floats * 4 + 255) & ~size_t(255);
-        float *p = dry ? nullptr : reinterpret_cast<float *>(base + used);
-        used += bytes;
-        return p;
+        if (arena < 0) {
+            float *p = dry ? nullptr : reinterpret_cast<float *>(base + used);
+            used += bytes;
+            return p;
+        }
+        const size_t off = head + (arena ? arena_peak[0] : 0) + arena_used[arena];
+        arena_used[arena] += bytes;
+        if (dry && arena_used[arena] > arena_peak[arena]) arena_peak[arena] = arena_used[arena];
+        used = head + arena_peak[0] + arena_peak[1];
+        return dry ? nullptr : reinterpret_cast<float *>(base + off);
     }
 };
 
@@ -307,6 +325,21 @@ void fill_pair_args(const Model &m, ttsamd_resblock_args &r, const PackedConv &c
     r.slope = kLreluSlope;
     r.out_div = div;
 }
+
+// a packed layer by name; a missing one is an error code, not a null dereference
+const PackedConv *find_conv(const Model &m, const std::string &name)
+{
+    auto it = m.convs.find(name);
+    if (it == m.convs.end() || !it->second) {
+        set_error("hifigan: layer '%s' is not packed (ttsamd_hifigan_finalize did not complete)", name.c_str());
+        return nullptr;
+    }
+    return it->second.get();
+}
+#define CONV(var, name)                          \
+    const PackedConv *var##_p = find_conv(m, name); \
+    if (!var##_p) return TTSAMD_ERR_INVALID;     \
+    const PackedConv &var = *var##_p
 
 #define RC(call)               \
     do {                       \
@@ -363,8 +396,9 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
     int ch = c.upsample_initial_channel;
     float *o = ws.take((size_t)B * ch * T);
     ttsamd_conv1d_args a;
+    CONV(cpre, "conv_pre");
     if (!ws.dry) {
-        fill_conv_args(m, a, *m.convs["conv_pre"], x, c.in_channels, T, o, ch, T, B);
+        fill_conv_args(m, a, cpre, x, c.in_channels, T, o, ch, T, B);
         a.in_mask = sm[0];
         RC(ttsamd_conv1d(&a, s));
     }
@@ -373,9 +407,10 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
         ch /= 2;
         const int pad_up = (k_up - u) / 2;
         const int T_up = (T - 1) * u - 2 * pad_up + k_up;
+        ws.begin_stage(i);
         float *up = ws.take((size_t)B * ch * T_up);
+        CONV(pu, "ups." + std::to_string(i));
         if (!ws.dry) {
-            const PackedConv &pu = *m.convs["ups." + std::to_string(i)];
             fill_conv_args(m, a, pu, o, ch * 2, T, up, ch, T_up, B);
             a.in_act = TTSAMD_ACT_LRELU;
             a.in_slope = kLreluSlope;
@@ -391,7 +426,6 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
         T = T_up;
         float *o_next = ws.take((size_t)B * ch * T);
         float *zsum = nk > 1 ? ws.take((size_t)B * ch * T) : nullptr;
-        const size_t ws_mark = ws.used;
         // grouped stage (a single sentence): the branches of one ResBlock iteration as ONE launch, their outputs averaged by one more
         bool grouped = false;
         if (c.resblock_type == 1 && nk >= 2 && nk <= 3 && T % 4 == 0 && ttsamd_resblock_group_supported(ch, T, B)) {
@@ -409,7 +443,9 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                 for (int j = 0; j < nk && grouped; ++j)
                     for (int d = 0; d < c.num_dilations[0]; ++d) {
                         const std::string rp = "resblocks." + std::to_string(i * nk + j) + ".";
-                        if (!fuse_pair(m, *m.convs[rp + "convs1." + std::to_string(d)], *m.convs[rp + "convs2." + std::to_string(d)])) grouped = false;
+                        CONV(g1, rp + "convs1." + std::to_string(d));
+                        CONV(g2, rp + "convs2." + std::to_string(d));
+                        if (!fuse_pair(m, g1, g2)) grouped = false;
                     }
             }
         }
@@ -423,7 +459,8 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                     memset(arr, 0, sizeof(arr));
                     for (int j = 0; j < nk; ++j) {
                         const std::string rp = "resblocks." + std::to_string(i * nk + j) + ".";
-                        const PackedConv &c1 = *m.convs[rp + "convs1." + std::to_string(d)], &c2 = *m.convs[rp + "convs2." + std::to_string(d)];
+                        CONV(c1, rp + "convs1." + std::to_string(d));
+                        CONV(c2, rp + "convs2." + std::to_string(d));
                         const int slot = c1.kernel == 3 ? 0 : (c1.kernel == 7 ? 1 : 2);
                         fill_pair_args(m, arr[slot], c1, c2, cur[j], buf[2 * j + (d & 1)], nullptr, msk, ch, T, B, 0.f);
                         arr[slot].w1_h2 = arr[slot].w2_h2 = nullptr;      // grouped launches run the six-product kernels
@@ -446,7 +483,8 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                     const float *accum = (last && j > 0) ? zsum : nullptr;
                     const float div = (last && j == nk - 1) ? (float)nk : 0.f;
                     if (c.resblock_type == 1) {
-                        const PackedConv &c1 = *m.convs[rp + "convs1." + std::to_string(d)], &c2 = *m.convs[rp + "convs2." + std::to_string(d)];
+                        CONV(c1, rp + "convs1." + std::to_string(d));
+                        CONV(c2, rp + "convs2." + std::to_string(d));
                         if (fuse_pair(m, c1, c2)) {
                             ttsamd_resblock_args r;
                             fill_pair_args(m, r, c1, c2, cur, dst, accum, msk, ch, T, B, div);
@@ -471,7 +509,7 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                             RC(ttsamd_conv1d(&a, s));
                         }
                     } else {
-                        const PackedConv &cv = *m.convs[rp + "convs." + std::to_string(d)];
+                        CONV(cv, rp + "convs." + std::to_string(d));
                         fill_conv_args(m, a, cv, cur, ch, T, dst, ch, T, B);
                         a.in_act = TTSAMD_ACT_LRELU;
                         a.in_slope = kLreluSlope;
@@ -489,12 +527,12 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                 }
             }
         }
-        (void)ws_mark;
         o = o_next;
     }
+    CONV(cpost, "conv_post");
     if (!ws.dry) {
         // the final F.leaky_relu(o) uses the DEFAULT slope 0.01 (hifigan_generator.py:262), then conv_post and tanh
-        fill_conv_args(m, a, *m.convs["conv_post"], o, ch, T, wav, c.out_channels, T, B);
+        fill_conv_args(m, a, cpost, o, ch, T, wav, c.out_channels, T, B);
         a.in_act = TTSAMD_ACT_LRELU;
         a.in_slope = 0.01f;
         a.out_act = TTSAMD_ACT_TANH;
@@ -515,81 +553,99 @@ void drop_graphs(Model &m)
 
 Model *as_model(void *h) { return static_cast<Model *>(h); }
 
+// the launching pass over the handle's workspace, laid out as the size pass `dry` found it
+Workspace real_ws(Model &m, const Workspace &dry)
+{
+    Workspace w{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
+    w.arena_peak[0] = dry.arena_peak[0];
+    w.arena_peak[1] = dry.arena_peak[1];
+    return w;
+}
+
 }  // namespace
 
 extern "C" int ttsamd_hifigan_create(const ttsamd_hifigan_config *cfg, void **handle_out)
 {
-    TTSAMD_CHECK_ARG(cfg && handle_out, "hifigan_create: NULL argument");
-    const ttsamd_hifigan_config &c = *cfg;
-    TTSAMD_CHECK_ARG(c.in_channels > 0 && c.out_channels > 0 && c.upsample_initial_channel > 0, "hifigan_create: bad channel counts");
-    TTSAMD_CHECK_ARG(c.resblock_type == 1 || c.resblock_type == 2, "hifigan_create: resblock_type must be 1 or 2");
-    TTSAMD_CHECK_ARG(c.num_kernels >= 1 && c.num_kernels <= TTSAMD_HIFIGAN_MAX_KERNELS, "hifigan_create: 1..%d resblock kernels", TTSAMD_HIFIGAN_MAX_KERNELS);
-    TTSAMD_CHECK_ARG(c.num_upsamples >= 1 && c.num_upsamples <= TTSAMD_HIFIGAN_MAX_UPSAMPLES, "hifigan_create: 1..%d upsample layers", TTSAMD_HIFIGAN_MAX_UPSAMPLES);
-    TTSAMD_CHECK_ARG(c.inference_padding >= 0 && c.precision >= 0 && c.precision <= 2, "hifigan_create: bad padding / precision");
-    int ch = c.upsample_initial_channel, hop = 1;
-    for (int i = 0; i < c.num_upsamples; ++i) {
-        TTSAMD_CHECK_ARG(c.upsample_factors[i] >= 1 && c.upsample_kernel_sizes[i] >= c.upsample_factors[i],
-                         "hifigan_create: upsample layer %d: kernel %d < stride %d leaves samples without a tap", i, c.upsample_kernel_sizes[i], c.upsample_factors[i]);
-        TTSAMD_CHECK_ARG(ch % 2 == 0, "hifigan_create: channel count %d cannot be halved at upsample layer %d", ch, i);
-        ch /= 2;
-        hop *= c.upsample_factors[i];
-    }
-    for (int j = 0; j < c.num_kernels; ++j) {
-        TTSAMD_CHECK_ARG(c.num_dilations[j] >= 1 && c.num_dilations[j] <= TTSAMD_HIFIGAN_MAX_DILATIONS, "hifigan_create: resblock %d: 1..%d dilations", j, TTSAMD_HIFIGAN_MAX_DILATIONS);
-        TTSAMD_CHECK_ARG(c.resblock_kernel_sizes[j] % 2 == 1, "hifigan_create: resblock kernel sizes are odd (get_padding, hifigan_generator.py:14-15)");
-    }
-    Model *m = new (std::nothrow) Model();
-    TTSAMD_CHECK_ARG(m, "hifigan_create: out of memory");
-    m->cfg = c;
-    m->hop = hop;
-    m->precision = c.precision;
-    *handle_out = m;
-    return TTSAMD_OK;
+    return abi_guard("hifigan_create", [&]() -> int {
+        TTSAMD_CHECK_ARG(cfg && handle_out, "hifigan_create: NULL argument");
+        const ttsamd_hifigan_config &c = *cfg;
+        TTSAMD_CHECK_ARG(c.in_channels > 0 && c.out_channels > 0 && c.upsample_initial_channel > 0, "hifigan_create: bad channel counts");
+        TTSAMD_CHECK_ARG(c.resblock_type == 1 || c.resblock_type == 2, "hifigan_create: resblock_type must be 1 or 2");
+        TTSAMD_CHECK_ARG(c.num_kernels >= 1 && c.num_kernels <= TTSAMD_HIFIGAN_MAX_KERNELS, "hifigan_create: 1..%d resblock kernels", TTSAMD_HIFIGAN_MAX_KERNELS);
+        TTSAMD_CHECK_ARG(c.num_upsamples >= 1 && c.num_upsamples <= TTSAMD_HIFIGAN_MAX_UPSAMPLES, "hifigan_create: 1..%d upsample layers", TTSAMD_HIFIGAN_MAX_UPSAMPLES);
+        TTSAMD_CHECK_ARG(c.inference_padding >= 0 && c.precision >= 0 && c.precision <= 2, "hifigan_create: bad padding / precision");
+        int ch = c.upsample_initial_channel, hop = 1;
+        for (int i = 0; i < c.num_upsamples; ++i) {
+            TTSAMD_CHECK_ARG(c.upsample_factors[i] >= 1 && c.upsample_kernel_sizes[i] >= c.upsample_factors[i],
+                             "hifigan_create: upsample layer %d: kernel %d < stride %d leaves samples without a tap", i, c.upsample_kernel_sizes[i], c.upsample_factors[i]);
+            TTSAMD_CHECK_ARG(ch % 2 == 0, "hifigan_create: channel count %d cannot be halved at upsample layer %d", ch, i);
+            ch /= 2;
+            hop *= c.upsample_factors[i];
+        }
+        for (int j = 0; j < c.num_kernels; ++j) {
+            TTSAMD_CHECK_ARG(c.num_dilations[j] >= 1 && c.num_dilations[j] <= TTSAMD_HIFIGAN_MAX_DILATIONS, "hifigan_create: resblock %d: 1..%d dilations", j, TTSAMD_HIFIGAN_MAX_DILATIONS);
+            TTSAMD_CHECK_ARG(c.resblock_kernel_sizes[j] % 2 == 1, "hifigan_create: resblock kernel sizes are odd (get_padding, hifigan_generator.py:14-15)");
+        }
+        Model *m = new (std::nothrow) Model();
+        TTSAMD_CHECK_ARG(m, "hifigan_create: out of memory");
+        m->cfg = c;
+        m->hop = hop;
+        m->precision = c.precision;
+        *handle_out = m;
+        return TTSAMD_OK;
+    });
 }
 
 extern "C" int ttsamd_hifigan_load(void *handle, const char *name, const float *data, const int64_t *shape, int ndim)
 {
-    TTSAMD_CHECK_ARG(handle && name && data && shape && ndim >= 1 && ndim <= 4, "hifigan_load: bad arguments");
-    Model &m = *as_model(handle);
-    HostTensor t;
-    t.shape.assign(shape, shape + ndim);
-    for (int i = 0; i < ndim; ++i) TTSAMD_CHECK_ARG(shape[i] > 0, "hifigan_load: '%s' has a non-positive dimension", name);
-    t.data.assign(data, data + t.numel());
-    m.tensors[name] = std::move(t);
-    m.finalized = false;
-    return TTSAMD_OK;
+    return abi_guard("hifigan_load", [&]() -> int {
+        TTSAMD_CHECK_ARG(handle && name && data && shape && ndim >= 1 && ndim <= 4, "hifigan_load: bad arguments");
+        Model &m = *as_model(handle);
+        HostTensor t;
+        t.shape.assign(shape, shape + ndim);
+        for (int i = 0; i < ndim; ++i) TTSAMD_CHECK_ARG(shape[i] > 0, "hifigan_load: '%s' has a non-positive dimension", name);
+        t.data.assign(data, data + t.numel());
+        m.tensors[name] = std::move(t);
+        m.finalized = false;
+        return TTSAMD_OK;
+    });
 }
 
 extern "C" int ttsamd_hifigan_finalize(void *handle)
 {
-    TTSAMD_CHECK_ARG(handle, "hifigan_finalize: NULL handle");
-    Model &m = *as_model(handle);
-    const ttsamd_hifigan_config &c = m.cfg;
-    // graphs and packed images of a previous weight set go first (a graph holds raw pointers to them)
-    TTSAMD_HIP(hipDeviceSynchronize());
-    drop_graphs(m);
-    m.convs.clear();
-    RC(add_conv(m, "conv_pre", c.upsample_initial_channel, c.in_channels, 7, 1));
-    int ch = c.upsample_initial_channel;
-    for (int i = 0; i < c.num_upsamples; ++i) {
-        RC(add_convt(m, "ups." + std::to_string(i), ch, ch / 2, c.upsample_kernel_sizes[i], c.upsample_factors[i]));
-        ch /= 2;
-        for (int j = 0; j < c.num_kernels; ++j) {
-            const std::string rp = "resblocks." + std::to_string(i * c.num_kernels + j) + ".";
-            for (int d = 0; d < c.num_dilations[j]; ++d) {
-                if (c.resblock_type == 1) {
-                    RC(add_conv(m, rp + "convs1." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j][d]));
-                    RC(add_conv(m, rp + "convs2." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], 1));
-                } else {
-                    RC(add_conv(m, rp + "convs." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j][d]));
+    return abi_guard("hifigan_finalize", [&]() -> int {
+        TTSAMD_CHECK_ARG(handle, "hifigan_finalize: NULL handle");
+        Model &m = *as_model(handle);
+        const ttsamd_hifigan_config &c = m.cfg;
+        // a second finalize with nothing new loaded keeps the packed model (the host copies were dropped by the first one)
+        if (m.finalized && m.tensors.empty()) return TTSAMD_OK;
+        m.finalized = false;         // true again only when every layer has been packed
+        // graphs and packed images of a previous weight set go first (a graph holds raw pointers to them)
+        TTSAMD_HIP(hipDeviceSynchronize());
+        drop_graphs(m);
+        m.convs.clear();
+        RC(add_conv(m, "conv_pre", c.upsample_initial_channel, c.in_channels, 7, 1));
+        int ch = c.upsample_initial_channel;
+        for (int i = 0; i < c.num_upsamples; ++i) {
+            RC(add_convt(m, "ups." + std::to_string(i), ch, ch / 2, c.upsample_kernel_sizes[i], c.upsample_factors[i]));
+            ch /= 2;
+            for (int j = 0; j < c.num_kernels; ++j) {
+                const std::string rp = "resblocks." + std::to_string(i * c.num_kernels + j) + ".";
+                for (int d = 0; d < c.num_dilations[j]; ++d) {
+                    if (c.resblock_type == 1) {
+                        RC(add_conv(m, rp + "convs1." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j][d]));
+                        RC(add_conv(m, rp + "convs2." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], 1));
+                    } else {
+                        RC(add_conv(m, rp + "convs." + std::to_string(d), ch, ch, c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j][d]));
+                    }
                 }
             }
         }
-    }
-    RC(add_conv(m, "conv_post", c.out_channels, ch, 7, 1));
-    m.tensors.clear();           // the host copies are not needed any more
-    m.finalized = true;
-    return TTSAMD_OK;
+        RC(add_conv(m, "conv_post", c.out_channels, ch, 7, 1));
+        m.tensors.clear();           // the host copies are not needed any more
+        m.finalized = true;
+        return TTSAMD_OK;
+    });
 }
 
 extern "C" int64_t ttsamd_hifigan_output_samples(void *handle, int frames)
@@ -605,72 +661,87 @@ extern "C" int64_t ttsamd_hifigan_output_samples(void *handle, int frames)
 extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, float *wav, int use_graph,
                                       void *stream)
 {
-    TTSAMD_CHECK_ARG(handle && mel && wav, "hifigan_forward: NULL argument");
-    Model &m = *as_model(handle);
-    TTSAMD_CHECK_ARG(m.finalized, "hifigan_forward: weights not loaded (ttsamd_hifigan_load ... ttsamd_hifigan_finalize)");
-    TTSAMD_CHECK_ARG(batch >= 0 && frames >= 1 && batch <= 65535, "hifigan_forward: bad shape");
-    if (batch == 0) return TTSAMD_OK;
-    if (lengths) {
-        for (int i = 0; i < m.cfg.num_upsamples; ++i)
-            TTSAMD_CHECK_ARG((m.cfg.upsample_kernel_sizes[i] - m.cfg.upsample_factors[i]) % 2 == 0,
-                             "hifigan_forward: ragged batching needs upsample kernels with k - stride even (output = frames * hop exactly)");
-    }
-    hipStream_t st = as_stream(stream);
-    Workspace dry{nullptr, 0, 0, true};
-    RC(run(m, dry, mel, batch, frames, lengths, wav, st));
-    if (dry.used > m.work.bytes) {
-        // growing the workspace invalidates every captured graph (they hold pointers into it)
-        TTSAMD_HIP(hipDeviceSynchronize());
-        drop_graphs(m);
-        if (m.work.p) TTSAMD_HIP(hipFree(m.work.p));
-        m.work.p = nullptr;
-        m.work.bytes = 0;
-        TTSAMD_HIP(hipMalloc(&m.work.p, dry.used));
-        m.work.bytes = dry.used;
-    }
-    if (use_graph) {
-        for (auto &g : m.graphs)
-            if (g.mel == mel && g.lengths == lengths && g.wav == wav && g.batch == batch && g.frames == frames && g.stream == st) {
-                TTSAMD_HIP(hipGraphLaunch(g.exec, st));
-                return TTSAMD_OK;
+    return abi_guard("hifigan_forward", [&]() -> int {
+        TTSAMD_CHECK_ARG(handle && mel && wav, "hifigan_forward: NULL argument");
+        Model &m = *as_model(handle);
+        TTSAMD_CHECK_ARG(m.finalized, "hifigan_forward: weights not loaded (ttsamd_hifigan_load ... ttsamd_hifigan_finalize)");
+        TTSAMD_CHECK_ARG(batch >= 0 && frames >= 1 && batch <= 65535, "hifigan_forward: bad shape");
+        if (batch == 0) return TTSAMD_OK;
+        if (lengths) {
+            for (int i = 0; i < m.cfg.num_upsamples; ++i)
+                TTSAMD_CHECK_ARG((m.cfg.upsample_kernel_sizes[i] - m.cfg.upsample_factors[i]) % 2 == 0,
+                                 "hifigan_forward: ragged batching needs upsample kernels with k - stride even (output = frames * hop exactly)");
+        }
+        hipStream_t st = as_stream(stream);
+        Workspace dry{nullptr, 0, 0, true};
+        RC(run(m, dry, mel, batch, frames, lengths, wav, st));
+        if (dry.used > m.work.bytes) {
+            // growing the workspace invalidates every captured graph (they hold pointers into it)
+            TTSAMD_HIP(hipDeviceSynchronize());
+            drop_graphs(m);
+            if (m.work.p) TTSAMD_HIP(hipFree(m.work.p));
+            m.work.p = nullptr;
+            m.work.bytes = 0;
+            TTSAMD_HIP(hipMalloc(&m.work.p, dry.used));
+            m.work.bytes = dry.used;
+        }
+        if (use_graph) {
+            for (auto &g : m.graphs)
+                if (g.mel == mel && g.lengths == lengths && g.wav == wav && g.batch == batch && g.frames == frames && g.stream == st) {
+                    TTSAMD_HIP(hipGraphLaunch(g.exec, st));
+                    return TTSAMD_OK;
+                }
+            // first sighting of this (buffers, shape, stream): run it once eagerly (one-time function attributes are set outside any
+            // capture), then capture the same sequence and replay from the next call on
+            Workspace w0 = real_ws(m, dry);
+            RC(run(m, w0, mel, batch, frames, lengths, wav, st));
+            GraphEntry e{mel, lengths, wav, batch, frames, st};
+            if (!m.cap_stream) TTSAMD_HIP(hipStreamCreateWithFlags(&m.cap_stream, hipStreamNonBlocking));
+            TTSAMD_HIP(hipStreamBeginCapture(m.cap_stream, hipStreamCaptureModeThreadLocal));
+            Workspace w1 = real_ws(m, dry);
+            const int rc = run(m, w1, mel, batch, frames, lengths, wav, m.cap_stream);
+            const hipError_t he = hipStreamEndCapture(m.cap_stream, &e.graph);
+            if (rc) {
+                if (e.graph) (void)hipGraphDestroy(e.graph);
+                return rc;
             }
-        // first sighting of this (buffers, shape, stream): run it once eagerly (one-time function attributes are set outside any
-        // capture), then capture the same sequence and replay from the next call on
-        Workspace w0{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
-        RC(run(m, w0, mel, batch, frames, lengths, wav, st));
-        GraphEntry e{mel, lengths, wav, batch, frames, st};
-        if (!m.cap_stream) TTSAMD_HIP(hipStreamCreateWithFlags(&m.cap_stream, hipStreamNonBlocking));
-        TTSAMD_HIP(hipStreamBeginCapture(m.cap_stream, hipStreamCaptureModeThreadLocal));
-        Workspace w1{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
-        const int rc = run(m, w1, mel, batch, frames, lengths, wav, m.cap_stream);
-        const hipError_t he = hipStreamEndCapture(m.cap_stream, &e.graph);
-        if (rc) {
-            if (e.graph) (void)hipGraphDestroy(e.graph);
-            return rc;
+            if (he != hipSuccess) {
+                if (e.graph) (void)hipGraphDestroy(e.graph);
+                TTSAMD_HIP(he);
+            }
+            const hipError_t hi = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+            if (hi != hipSuccess) {
+                (void)hipGraphDestroy(e.graph);
+                TTSAMD_HIP(hi);
+            }
+            if (m.graphs.size() >= 16) {
+                GraphEntry &old = m.graphs.front();
+                // the oldest entry's stream may have been destroyed by its owner since: then wait for the whole device instead
+                if (hipStreamSynchronize(old.stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    (void)hipDeviceSynchronize();
+                }
+                (void)hipGraphExecDestroy(old.exec);
+                (void)hipGraphDestroy(old.graph);
+                m.graphs.erase(m.graphs.begin());
+            }
+            m.graphs.push_back(e);
+            return TTSAMD_OK;       // (the eager run above produced this call's result)
         }
-        TTSAMD_HIP(he);
-        TTSAMD_HIP(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
-        if (m.graphs.size() >= 16) {
-            GraphEntry &old = m.graphs.front();
-            TTSAMD_HIP(hipStreamSynchronize(old.stream));
-            (void)hipGraphExecDestroy(old.exec);
-            (void)hipGraphDestroy(old.graph);
-            m.graphs.erase(m.graphs.begin());
-        }
-        m.graphs.push_back(e);
-        return TTSAMD_OK;       // (the eager run above produced this call's result)
-    }
-    Workspace w{static_cast<unsigned char *>(m.work.p), 0, m.work.bytes, false};
-    return run(m, w, mel, batch, frames, lengths, wav, st);
+        Workspace w = real_ws(m, dry);
+        return run(m, w, mel, batch, frames, lengths, wav, st);
+    });
 }
 
 extern "C" int ttsamd_hifigan_destroy(void *handle)
 {
-    if (!handle) return TTSAMD_OK;
-    Model *m = as_model(handle);
-    (void)hipDeviceSynchronize();
-    drop_graphs(*m);
-    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-    delete m;
-    return TTSAMD_OK;
+    return abi_guard("hifigan_destroy", [&]() -> int {
+        if (!handle) return TTSAMD_OK;
+        Model *m = as_model(handle);
+        (void)hipDeviceSynchronize();
+        drop_graphs(*m);
+        if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+        delete m;
+        return TTSAMD_OK;
+    });
 }

@@ -21,12 +21,27 @@
 
 namespace ttsamd {
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 template <int K, int D, int C, int WM, int WN, int NI>
 struct ResGeomH2 : ResGeom<K, D, C, WM, WN, NI> {
     using B = ResGeom<K, D, C, WM, WN, NI>;
+    static constexpr int kCC = C < 32 ? 32 : C;                           // channel count of the (padded) weight images
     static constexpr size_t kImageBytes = (size_t)2 * B::kNCh * 2 * B::kPlaneX;
-    static constexpr size_t kLdsBytes = kImageBytes + 2 * 8 * 4;        // + [x tile / mid tile][wave] maximum slots
-    static constexpr int kOcc = (2 * kLdsBytes <= 160 * 1024 && B::kThreads <= 256) ? 2 : (B::kThreads >= 512 && 2 * kLdsBytes <= 160 * 1024 ? 2 : 1);
+    static constexpr size_t kTabBytes = (size_t)4 * kCC * 4;              // [bias1 | row unscale 1 | bias2 | row unscale 2][row]
+    static constexpr size_t kLdsBytes = kImageBytes + 2 * 8 * 4 + kTabBytes;   // + [x tile / mid tile][wave] maximum slots + tables
+    // waves per SIMD the kernel is compiled for (= blocks per CU of a 4-wave block; an 8-wave block puts two waves on a SIMD):
+    // as many as the LDS image allows, up to TTSAMD_PAIR_MAX_OCC — a block's life is mostly waiting (x tile from HBM, the two
+    // epilogues, barriers), and only the other blocks of its CU fill the matrix pipe meanwhile
+#ifndef TTSAMD_PAIR_MAX_OCC
+#define TTSAMD_PAIR_MAX_OCC 4
+#endif
+    static constexpr int kFit = (int)((160 * 1024) / kLdsBytes);         // blocks per CU by LDS
+    static constexpr int kOccRaw = B::kThreads <= 256 ? kFit : 2 * kFit;
+    static constexpr int kOcc = kOccRaw < 1 ? 1 : (kOccRaw > TTSAMD_PAIR_MAX_OCC ? TTSAMD_PAIR_MAX_OCC : kOccRaw);
+    static constexpr bool kResEarly = kOcc <= 3;                          // 168+ registers: the residual is requested before conv2
+    // waves that hold at least one item of the last (partly filled) staging round
+    static constexpr int kLastWaves = (B::kItems - (B::kRounds - 1) * B::kThreads + 63) / 64;
     static_assert(WM * WN == 4 || WM * WN == 8, "the maximum slots are read four at a time");
 };
 
@@ -78,8 +93,10 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
     constexpr int MI = G::kMI;
     constexpr int NCH = G::kNCh;
     constexpr int NW = WM * WN;
+    constexpr int CC = G::kCC;
     extern __shared__ __attribute__((aligned(16))) unsigned char rh2[];
     unsigned *const slots = reinterpret_cast<unsigned *>(rh2 + G::kImageBytes);
+    float *const tabs = reinterpret_cast<float *>(rh2 + G::kImageBytes + 2 * 8 * 4);
 
     const ConvTile tile = conv_tile_of_block();
     const int tid = threadIdx.x;
@@ -99,9 +116,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * creal * T, slab);
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc(a.mask ? a.mask + (long)b * T : nullptr, a.mask ? (long)T * 4 : 0);
     const bool has_mask = a.mask != nullptr;
-    constexpr int CC = C < 32 ? 32 : C;       // channel count of the (padded) weight images
-    const float *const tab1 = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.w1_h2) + conv_h2_table_offset(CC, CC, K) + sizeof(H2RowTable));
-    const float *const tab2 = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.w2_h2) + conv_h2_table_offset(CC, CC, K) + sizeof(H2RowTable));
 
     auto block_max = [&](int which) -> unsigned {      // after a barrier
         const u32x4 s0 = *reinterpret_cast<const u32x4 *>(slots + which * 8);
@@ -118,9 +132,16 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
     {
         const int tx0 = t0 - G::kH2 - G::kH1;
         const int row_bytes = T * 4;
+        // the last staging round is partly filled: waves without an item in it skip its loads, arithmetic and stores
+        const bool last_round = wave < G::kLastWaves;
         float st[G::kRounds][8];
 #pragma unroll
         for (int rr = 0; rr < G::kRounds; ++rr) {
+            if (rr == G::kRounds - 1 && G::kLastWaves < NW && !last_round) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st[rr][i] = 0.f;
+                continue;
+            }
             const int e = tid + rr * G::kThreads;
             const int pl = e / G::kXW;                 // chunk * 2 + half
             const int col = e - pl * G::kXW;
@@ -136,20 +157,35 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
                 for (int i = 0; i < 8; ++i) st[rr][i] *= sm;
             }
         }
+        // the epilogues' per-row operands (bias, 2^-e_row of the weight image) go through a small LDS table instead of living
+        // in 32 registers across both main loops: written here, read after the barriers below
+        if (tid < CC) {
+            const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(a.bias1, a.bias1 ? creal * 4 : 0);
+            const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(a.bias2, a.bias2 ? creal * 4 : 0);
+            const float *const tab1 = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.w1_h2) + conv_h2_table_offset(CC, CC, K) + sizeof(H2RowTable));
+            const float *const tab2 = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.w2_h2) + conv_h2_table_offset(CC, CC, K) + sizeof(H2RowTable));
+            tabs[tid] = ld_buf(rb1, tid * 4, 0);
+            tabs[CC + tid] = tab1[2 * tid + 1];
+            tabs[2 * CC + tid] = ld_buf(rb2, tid * 4, 0);
+            tabs[3 * CC + tid] = tab2[2 * tid + 1];
+        }
         float m = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < G::kRounds; ++rr)
+        for (int rr = 0; rr < G::kRounds; ++rr) {
+            if (rr == G::kRounds - 1 && G::kLastWaves < NW && !last_round) continue;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 st[rr][i] = conv_lrelu(st[rr][i], a.slope);
                 m = __builtin_fmaxf(m, __builtin_fabsf(st[rr][i]));
             }
+        }
         slots[wave] = wave_max_u32(__builtin_bit_cast(unsigned, m));
         __syncthreads();
         e_x = h2_exp_for(block_max(0));
         const float sx = pow2f(e_x);
 #pragma unroll
         for (int rr = 0; rr < G::kRounds; ++rr) {
+            if (rr == G::kRounds - 1 && G::kLastWaves < NW && !last_round) continue;
             const int e = tid + rr * G::kThreads;
             const int pl = e / G::kXW;
             const int col = e - pl * G::kXW;
@@ -186,38 +222,22 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
             a_cur[mi][q] = wp1[mi][q * 64];
             a_n1[mi][q] = wp1[mi][(2 + q) * 64];
         }
-    // the residual x — the tile's own columns, requested now (L2 hits right after the staging pass), added in the output epilogue
-    f32x16 resv[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+    // the residual x — the tile's own columns (L2 hits after the staging pass), added in the output epilogue.  Requested before
+    // conv2 where the register budget has room for it (<= 3 waves per SIMD), after conv2 at 4 waves per SIMD
+    f32x16 resv[MI][G::kResEarly ? NI : 1];
+    auto request_residual = [&](int mi, int ni, f32x16 &dst) {
         const int row0 = (wm * MI + mi) * 32;
+        const int o = (wn * NI + ni) * 32 + j;
+        const int t = t0 + o;
+        const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int o = (wn * NI + ni) * 32 + j;
-            const int t = t0 + o;
-            const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) resv[mi][ni][r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-        }
-    }
-    float mk[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int t = t0 - G::kH2 + (wn * NI + ni) * 32 + j;      // time of this lane's mid column
-        const bool ok = (t >= 0) && (t < T);                      // outside the tensor conv2 sees its zero padding
-        mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
-    }
-    const __amdgpu_buffer_rsrc_t rb1 = make_rsrc(a.bias1, a.bias1 ? creal * 4 : 0);
-    const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(a.bias2, a.bias2 ? creal * 4 : 0);
-    float bia[MI][16], ru[MI][16];     // bias and row unscale factor (2^-e_row) of this lane's rows
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2);
-            bia[mi][r] = ld_buf(rb1, 16 * h, row * 4);
-            ru[mi][r] = tab1[2 * (row + 4 * h) + 1];
-        }
+        for (int r = 0; r < 16; ++r) dst[r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+    };
+    // a lane's 16 rows of a table are four groups of four consecutive rows (row0 + 8 rg + 4 h + 0..3): one ds_read_b128 per group,
+    // read where it is used (no table registers live across the main loops)
+    auto table_row4 = [&](int which, int mi, int rg) -> f32x4 {
+        return *reinterpret_cast<const f32x4 *>(tabs + which * CC + (wm * MI + mi) * 32 + 4 * h + 8 * rg);
+    };
     f32x16 accm[MI][NI], accx[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -243,19 +263,31 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
     // ---- mid epilogue: leave the scaled units, + bias1, mask, leaky ReLU (in registers), tile exponent, split -> LDS -------------
     int e_m;
     {
+        float mk[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 - G::kH2 + (wn * NI + ni) * 32 + j;      // time of this lane's mid column
+            const bool ok = (t >= 0) && (t < T);                      // outside the tensor conv2 sees its zero padding
+            mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
+        }
         const float usx = pow2f(-e_x);
         float m = 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 bia = table_row4(0, mi, rg), ru = table_row4(1, mi, rg);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usx) * ru[mi][r];
-                    v = conv_lrelu((v + bia[mi][r]) * mk[ni], a.slope);
-                    accm[mi][ni][r] = v;
-                    m = __builtin_fmaxf(m, __builtin_fabsf(v));
-                }
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * rg + i;
+                        float v = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usx) * ru[i];
+                        v = conv_lrelu((v + bia[i]) * mk[ni], a.slope);
+                        accm[mi][ni][r] = v;
+                        m = __builtin_fmaxf(m, __builtin_fabsf(v));
+                    }
+            }
         slots[8 + wave] = wave_max_u32(__builtin_bit_cast(unsigned, m));
         __syncthreads();                                               // every wave is done reading the x tile; the maxima are in
         e_m = h2_exp_for(block_max(1));
@@ -289,20 +321,18 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2);
-            bia[mi][r] = ld_buf(rb2, 16 * h, row * 4);
-            ru[mi][r] = tab2[2 * (row + 4 * h) + 1];
-        }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 accm[mi][ni][r] = 0.f;
                 accx[mi][ni][r] = 0.f;
             }
+    if constexpr (G::kResEarly) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) request_residual(mi, ni, resv[mi][ni]);
+    }
     __syncthreads();                                                   // the mid tile is complete
     res_conv_mainloop_h2<K, 1, MI, NI, NCH, G::kPlaneM>(accm, accx, wp2, a_cur, a_n1, rh2 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
 
@@ -324,16 +354,26 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
                 const int o = (wn * NI + ni) * 32 + j;
                 const int t = t0 + o;
                 const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-                float vout[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    vout[r] = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usm) * ru[mi][r] + bia[mi][r];
-                    vout[r] += resv[mi][ni][r];
-                }
+                f32x16 &rv = resv[mi][G::kResEarly ? ni : 0];
+                if constexpr (!G::kResEarly) request_residual(mi, ni, rv);     // 4 waves per SIMD: no room to hold it across conv2
+                float e2[16];
                 if (has_accum) {
-                    float e2[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e2[r] = ld_buf(racc, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+                }
+                float vout[16];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const f32x4 bia = table_row4(2, mi, rg), ru = table_row4(3, mi, rg);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * rg + i;
+                        vout[r] = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usm) * ru[i] + bia[i];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vout[r] += rv[r];
+                if (has_accum) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) vout[r] = e2[r] + vout[r];
                 }
