@@ -307,7 +307,74 @@ int ttsamd_hifigan_finalize(void *handle);
 int64_t ttsamd_hifigan_output_samples(void *handle, int frames);
 int ttsamd_hifigan_forward(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, float *wav, int use_graph,
                            void *stream);
+/* The same with `in_mask` [batch, frames] (device, or NULL) multiplied into the input inside conv_pre's load: the waveform decoder
+ * inside VITS is fed `z * y_mask` (TTS/tts/models/vits.py:1161).  `lengths` and `in_mask` are alternatives. */
+int ttsamd_hifigan_forward_ex(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, const float *in_mask,
+                              float *wav, int use_graph, void *stream);
 int ttsamd_hifigan_destroy(void *handle);
+
+/* ------------------------------------------------------------------------------------------
+ * Model-level handle of VITS ("mi355_vits_{create,load,infer,destroy}") — replaces, as ONE object a non-Python
+ * host can drive:
+ *   TTS/tts/models/vits.py:653-724    Vits.__init__ layer wiring (text encoder, duration predictor, flow, waveform decoder)
+ *   :1698-1725                        load_checkpoint (weight norm stays parametrised in the checkpoint; folded at finalize)
+ *   :1088-1173                        Vits.inference: text encoder -> duration predictor (reverse) -> ceil / cumsum ->
+ *                                     generate_path -> prior expansion + noise -> flow (reverse) -> waveform decoder
+ *   TTS/tts/layers/vits/networks.py:29-100,103-232; stochastic_duration_predictor.py:150-294; glow_tts/duration_predictor.py:7-69;
+ *   glow_tts/transformer.py:10-432; generic/wavenet.py:16-123 (the layers behind it)
+ * Envelope: the single-speaker, single-language model of BASELINE.json (LJSpeech VITS): no speaker / language conditioning, no
+ * encoder_sample_rate interpolation, mean-only coupling — the Python host (tts_amd/vits.py) covers the rest through the kernel-level
+ * ABI.  A request is two calls, because the output extent is data dependent and the caller owns every buffer:
+ *   encode: tokens -> durations; returns when y_lengths are on the host (the request's ONE host wait, a pinned mirror the durations
+ *           kernel writes) -> the caller sizes its outputs and draws noise_z at the reference's shape [batch, hidden, t_dec]
+ *           (randn_like(m_p), vits.py:1155)
+ *   decode: prior expansion, flows, waveform decoder into the caller's buffers.
+ * Both issue exactly the kernel-level ABI calls of the Python host (same kernels, same tiles: bitwise the same outputs for the same
+ * folded weights, tests/test_vits_gpu.py).  One caller, one request at a time per handle; errors are return codes. */
+typedef struct ttsamd_vits_config {
+    int32_t num_chars;                         /* rows of text_encoder.emb (VitsArgs.num_chars, vits.py:544-600) */
+    int32_t hidden_channels;                   /* 192 */
+    int32_t hidden_channels_ffn_text_encoder;  /* 768 */
+    int32_t num_heads_text_encoder;            /* 2 */
+    int32_t num_layers_text_encoder;           /* 6 */
+    int32_t kernel_size_text_encoder;          /* 3 */
+    int32_t kernel_size_flow;                  /* 5 */
+    int32_t dilation_rate_flow;                /* 1 */
+    int32_t num_layers_flow;                   /* 4: WaveNet layers per coupling block */
+    int32_t num_flows;                         /* 4: ResidualCouplingBlocks(num_flows=4), networks.py:190; must be even */
+    int32_t use_sdp;                           /* 1: StochasticDurationPredictor(hidden, 192, 3, p, 4) (vits.py:684-692); 0: DurationPredictor(hidden, 256, 3, p) */
+    float inference_noise_scale;               /* 0.667 */
+    float inference_noise_scale_dp;            /* 1.0 */
+    float length_scale;                        /* 1.0 */
+    ttsamd_hifigan_config decoder;             /* waveform_decoder (vits.py:704-718): in_channels = hidden_channels, inference_padding 0 */
+} ttsamd_vits_config;
+/* every output is optional (NULL = not wanted) except wav; all device pointers, fp32 unless noted, contiguous */
+typedef struct ttsamd_vits_outputs {
+    float *wav;          /* [batch, 1, t_dec * hop]   "model_outputs" */
+    float *alignments;   /* [batch, t_text, t_dec]    "alignments" */
+    float *durations;    /* [batch, t_text]           "durations" (w_ceil) */
+    float *z, *z_p, *m_p, *logs_p;   /* [batch, hidden, t_dec] */
+    float *y_mask;       /* [batch, t_dec] */
+    int64_t *y_lengths;  /* [batch] int64 */
+    float *logw;         /* [batch, t_text]: the duration predictor's output (NULL when it did not run) */
+    float *x_hidden;     /* [batch, hidden, t_text]: the text encoder's hidden output */
+} ttsamd_vits_outputs;
+int ttsamd_vits_create(const ttsamd_vits_config *config /* host */, void **handle_out);
+/* one state_dict entry under its reference key ("text_encoder.emb.weight", "duration_predictor.flows.1.convs.norms_1.0.gamma",
+ * "flow.flows.0.enc.in_layers.0.parametrizations.weight.original0", "waveform_decoder.ups.0...", ...); "disc.*" keys are ignored */
+int ttsamd_vits_load(void *handle, const char *name, const float *data /* host */, const int64_t *shape /* host */, int ndim);
+int ttsamd_vits_finalize(void *handle);
+/* x int64 [batch, t_text], x_lengths int64 [batch] (device).  noise_dp [batch, 2, t_text] (device): the SDP's randn draw
+ * (stochastic_duration_predictor.py:287), required when use_sdp and the predictor runs.  durations_in [batch, t_text] (device) or
+ * NULL: injected durations (vits.py:1141-1143); the predictor then runs only if run_duration_predictor != 0.  On return
+ * y_lengths_host[batch] (host, may be NULL) and *t_dec_out hold every item's frame count and their maximum. */
+int ttsamd_vits_encode(void *handle, const int64_t *x, const int64_t *x_lengths, int batch, int t_text, const float *noise_dp,
+                       const float *durations_in, int run_duration_predictor, int64_t *y_lengths_host, int32_t *t_dec_out,
+                       int use_graph, void *stream);
+/* second half of the request encode started.  noise_z [batch, hidden, t_dec] (device), t_dec as returned by encode. */
+int ttsamd_vits_decode(void *handle, const float *noise_z, const ttsamd_vits_outputs *out /* host */, void *stream);
+int64_t ttsamd_vits_hop_length(void *handle);
+int ttsamd_vits_destroy(void *handle);
 
 /* ------------------------------------------------------------------------------------------
  * Channel LayerNorm on [B, C, T] (normalise over C for every (b, t)), with the fusions the text

@@ -9,63 +9,17 @@
 // Ownership: the caller owns mel / lengths / wav (device pointers); the handle owns its packed weights (device) and a grow-only
 // activation workspace (device).  One caller and one stream at a time per handle (the reference's Synthesizer is not thread-safe
 // either, synthesizer.py:302-304); errors are return codes + ttsamd_last_error(), nothing throws across the ABI.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
-
-#include "common.h"
+#include "model_common.h"
 
 using namespace ttsamd;
+using namespace ttsamd::model;
 
 namespace {
 
 constexpr float kLreluSlope = 0.1f;       // hifigan_generator.py:11
 
-struct HostTensor {
-    std::vector<int64_t> shape;
-    std::vector<float> data;
-    int64_t numel() const
-    {
-        int64_t n = 1;
-        for (auto s : shape) n *= s;
-        return n;
-    }
-};
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf()
-    {
-        if (p) (void)hipFree(p);
-    }
-    int upload(const void *src, size_t n)
-    {
-        TTSAMD_HIP(hipMalloc(&p, n ? n : 4));
-        bytes = n;
-        if (n) TTSAMD_HIP(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
-        return TTSAMD_OK;
-    }
-};
-
-// one conv layer on the device: the three fragment images + bias (tts_amd/ops.py: PackedConv)
-struct PackedConv {
-    int c_out = 0, c_in = 0, kernel = 0, dilation = 1, pad_left = 0;
-    bool tuned = false;
-    DevBuf w, w_split, w_h2, bias, w_split_pad32, w_h2_pad32;
-    bool has_bias = false;
-};
-
-struct GraphEntry {
-    const void *mel, *lengths;
+struct VocGraph {
+    const void *mel, *lengths, *in_mask;
     void *wav;
     int batch, frames;
     hipStream_t stream;
@@ -80,117 +34,16 @@ struct Model {
     bool finalized = false;
     int hop = 1;
     DevBuf work;                 // activation workspace, grow-only
-    std::vector<GraphEntry> graphs;
+    std::vector<VocGraph> graphs;
     hipStream_t cap_stream = nullptr;   // the sequence is RECORDED on this stream (the caller's may be the NULL stream, which cannot
                                         // capture) and replayed on the caller's
     int precision = 0;           // 0 = h2 (three fp16 products on large grids), 1 = x3 (six bf16 products), 2 = f32
 };
 
-int fold_weight_norm(const Model &m, const std::string &name, HostTensor &out)
-{
-    auto it = m.tensors.find(name + ".weight");
-    if (it != m.tensors.end()) {
-        out = it->second;
-        return TTSAMD_OK;
-    }
-    auto g = m.tensors.find(name + ".parametrizations.weight.original0");
-    auto v = m.tensors.find(name + ".parametrizations.weight.original1");
-    if (g == m.tensors.end()) g = m.tensors.find(name + ".weight_g");
-    if (v == m.tensors.end()) v = m.tensors.find(name + ".weight_v");
-    if (g == m.tensors.end() || v == m.tensors.end()) {
-        set_error("hifigan: no weight for '%s' (expected .weight, .parametrizations.weight.original0/1 or .weight_g/_v)", name.c_str());
-        return TTSAMD_ERR_INVALID;
-    }
-    // torch weight_norm, dim = 0: w = v * g / ||v|| with the norm over every dim but 0 (for ConvTranspose1d dim 0 is in_channels)
-    out = v->second;
-    const int64_t d0 = out.shape[0], inner = out.numel() / d0;
-    if (g->second.numel() != d0) {
-        set_error("hifigan: weight-norm gain of '%s' has %lld elements, the weight has %lld rows", name.c_str(), (long long)g->second.numel(), (long long)d0);
-        return TTSAMD_ERR_INVALID;
-    }
-    for (int64_t r = 0; r < d0; ++r) {
-        // torch._weight_norm: norm in fp32 (sum of squares, sqrt), then v * (g / norm)
-        float ss = 0.f;
-        for (int64_t i = 0; i < inner; ++i) ss += out.data[r * inner + i] * out.data[r * inner + i];
-        const float scale = g->second.data[r] / std::sqrt(ss);
-        for (int64_t i = 0; i < inner; ++i) out.data[r * inner + i] *= scale;
-    }
-    return TTSAMD_OK;
-}
-
-int pack_conv(PackedConv &pc, const float *w, const float *bias, int c_out, int c_in, int kernel, int dilation, int pad_left)
-{
-    pc.c_out = c_out;
-    pc.c_in = c_in;
-    pc.kernel = kernel;
-    pc.dilation = dilation;
-    pc.pad_left = pad_left < 0 ? (kernel - 1) * dilation / 2 : pad_left;
-    if (!ttsamd_conv1d_supported(kernel, dilation)) {
-        set_error("hifigan: conv kernel=%d dilation=%d is outside the HIP path's range", kernel, dilation);
-        return TTSAMD_ERR_UNSUPPORTED;
-    }
-    pc.tuned = ttsamd_conv1d_tuned(kernel, dilation) != 0;
-    {
-        std::vector<float> img(ttsamd_conv1d_packed_floats(c_out, c_in, kernel));
-        int rc = ttsamd_conv1d_pack_weights(img.data(), w, c_out, c_in, kernel);
-        if (rc) return rc;
-        if ((rc = pc.w.upload(img.data(), img.size() * sizeof(float)))) return rc;
-    }
-    {
-        std::vector<unsigned char> img(ttsamd_conv1d_packed_split_bytes(c_out, c_in, kernel));
-        int rc = ttsamd_conv1d_pack_weights_split(img.data(), w, c_out, c_in, kernel);
-        if (rc) return rc;
-        if ((rc = pc.w_split.upload(img.data(), img.size()))) return rc;
-    }
-    if (pc.tuned) {
-        std::vector<unsigned char> img(ttsamd_conv1d_packed_h2_bytes(c_out, c_in, kernel));
-        int rc = ttsamd_conv1d_pack_weights_h2(img.data(), w, c_out, c_in, kernel);
-        if (rc) return rc;
-        if ((rc = pc.w_h2.upload(img.data(), img.size()))) return rc;
-    }
-    if (c_out == c_in && (c_out == 8 || c_out == 16)) {       // the fused pair's 32-channel tile reads zero-padded images
-        std::vector<float> wp((size_t)32 * 32 * kernel, 0.f);
-        for (int r = 0; r < c_out; ++r)
-            for (int c = 0; c < c_in; ++c)
-                for (int t = 0; t < kernel; ++t) wp[((size_t)r * 32 + c) * kernel + t] = w[((size_t)r * c_in + c) * kernel + t];
-        std::vector<unsigned char> a(ttsamd_conv1d_packed_split_bytes(32, 32, kernel)), b(ttsamd_conv1d_packed_h2_bytes(32, 32, kernel));
-        int rc = ttsamd_conv1d_pack_weights_split(a.data(), wp.data(), 32, 32, kernel);
-        if (rc) return rc;
-        if ((rc = ttsamd_conv1d_pack_weights_h2(b.data(), wp.data(), 32, 32, kernel))) return rc;
-        if ((rc = pc.w_split_pad32.upload(a.data(), a.size()))) return rc;
-        if ((rc = pc.w_h2_pad32.upload(b.data(), b.size()))) return rc;
-    }
-    pc.has_bias = bias != nullptr;
-    if (bias) return pc.bias.upload(bias, (size_t)c_out * sizeof(float));
-    return TTSAMD_OK;
-}
-
-const float *opt_bias(const Model &m, const std::string &name, int64_t n, int *rc)
-{
-    auto it = m.tensors.find(name + ".bias");
-    if (it == m.tensors.end()) return nullptr;
-    if (it->second.numel() != n) {
-        set_error("hifigan: '%s.bias' has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel(), (long long)n);
-        *rc = TTSAMD_ERR_INVALID;
-        return nullptr;
-    }
-    return it->second.data.data();
-}
-
 int add_conv(Model &m, const std::string &name, int c_out, int c_in, int kernel, int dilation)
 {
-    HostTensor w;
-    int rc = fold_weight_norm(m, name, w);
-    if (rc) return rc;
-    if (w.shape.size() != 3 || w.shape[0] != c_out || w.shape[1] != c_in || w.shape[2] != kernel) {
-        set_error("hifigan: '%s' has shape [%lld, %lld, %lld], the config says [%d, %d, %d]", name.c_str(), (long long)(w.shape.size() > 0 ? w.shape[0] : -1),
-                  (long long)(w.shape.size() > 1 ? w.shape[1] : -1), (long long)(w.shape.size() > 2 ? w.shape[2] : -1), c_out, c_in, kernel);
-        return TTSAMD_ERR_INVALID;
-    }
-    const float *b = opt_bias(m, name, c_out, &rc);
-    if (rc) return rc;
     auto pc = std::make_unique<PackedConv>();
-    if ((rc = pack_conv(*pc, w.data.data(), b, c_out, c_in, kernel, dilation, -1))) return rc;
+    RC(pack_named_conv(m.tensors, "hifigan", name, *pc, c_out, c_in, kernel, dilation));
     m.convs[name] = std::move(pc);
     return TTSAMD_OK;
 }
@@ -201,7 +54,7 @@ int add_conv(Model &m, const std::string &name, int c_out, int c_in, int kernel,
 int add_convt(Model &m, const std::string &name, int c_in, int c_out, int k, int u)
 {
     HostTensor wt;
-    int rc = fold_weight_norm(m, name, wt);
+    int rc = fold_weight_norm(m.tensors, "hifigan", name, wt);
     if (rc) return rc;
     if (wt.shape.size() != 3 || wt.shape[0] != c_in || wt.shape[1] != c_out || wt.shape[2] != k) {
         set_error("hifigan: '%s' does not have the ConvTranspose1d shape [%d, %d, %d]", name.c_str(), c_in, c_out, k);
@@ -216,7 +69,7 @@ int add_convt(Model &m, const std::string &name, int c_in, int c_out, int k, int
                     const int tap = r + (J - 1 - jp) * u;
                     if (tap < k) w[(((size_t)co * u + r) * c_in + ci) * J + jp] = wt.data[((size_t)ci * c_out + co) * k + tap];
                 }
-    const float *b = opt_bias(m, name, c_out, &rc);
+    const float *b = opt_bias(m.tensors, "hifigan", name, c_out, &rc);
     if (rc) return rc;
     std::vector<float> br;
     if (b) {
@@ -225,34 +78,14 @@ int add_convt(Model &m, const std::string &name, int c_in, int c_out, int k, int
             for (int r = 0; r < u; ++r) br[(size_t)co * u + r] = b[co];
     }
     auto pc = std::make_unique<PackedConv>();
-    if ((rc = pack_conv(*pc, w.data(), b ? br.data() : nullptr, c_out * u, c_in, J, 1, J - 1))) return rc;
+    if ((rc = pack_conv(*pc, "hifigan", w.data(), b ? br.data() : nullptr, c_out * u, c_in, J, 1, J - 1))) return rc;
     m.convs[name] = std::move(pc);
     return TTSAMD_OK;
 }
 
 void fill_conv_args(const Model &m, ttsamd_conv1d_args &a, const PackedConv &pc, const float *x, int c_x, int t_in, float *y, int c_y, int t_y, int batch)
 {
-    memset(&a, 0, sizeof(a));
-    a.x = x;
-    a.x_bstride = (int64_t)c_x * t_in;
-    a.x_rstride = t_in;
-    a.c_in = pc.c_in;
-    a.t_in = t_in;
-    a.w_packed = static_cast<const float *>(pc.w.p);
-    a.bias = pc.has_bias ? static_cast<const float *>(pc.bias.p) : nullptr;
-    a.c_out = pc.c_out;
-    a.kernel = pc.kernel;
-    a.dilation = pc.dilation;
-    a.pad_left = pc.pad_left;
-    a.y = y;
-    a.y_bstride = (int64_t)c_y * t_y;
-    a.y_rstride = t_y;
-    a.t_out = (pc.kernel % 2 == 0) ? t_in + 2 * pc.pad_left - (pc.kernel - 1) * pc.dilation : t_in;
-    a.batch = batch;
-    a.shuffle_t_out = t_y;
-    // the precision switch of tts_amd/ops.py: conv1d
-    a.w_split = (m.precision != 2 || !pc.tuned) ? pc.w_split.p : nullptr;
-    a.w_h2 = (m.precision == 0 && pc.tuned) ? pc.w_h2.p : nullptr;
+    model::fill_conv_args(m.precision, a, pc, x, c_x, t_in, y, c_y, t_y, batch);
 }
 
 // Activation workspace: a head (masks, padded input, conv_pre's output) and TWO stage arenas used alternately — after an upsample
@@ -341,15 +174,9 @@ const PackedConv *find_conv(const Model &m, const std::string &name)
     if (!var##_p) return TTSAMD_ERR_INVALID;     \
     const PackedConv &var = *var##_p
 
-#define RC(call)               \
-    do {                       \
-        int rc_ = (call);      \
-        if (rc_) return rc_;   \
-    } while (0)
-
 // The launch sequence of HifiganGenerator.inference (hifigan_generator.py:267-282 -> forward, :236-265) on `st`; with ws.dry only the
 // workspace size is computed.
-int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t *lengths, float *wav, hipStream_t st)
+int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t *lengths, const float *in_mask, float *wav, hipStream_t st)
 {
     const ttsamd_hifigan_config &c = m.cfg;
     const int p = c.inference_padding, nk = c.num_kernels, nu = c.num_upsamples;
@@ -399,7 +226,7 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
     CONV(cpre, "conv_pre");
     if (!ws.dry) {
         fill_conv_args(m, a, cpre, x, c.in_channels, T, o, ch, T, B);
-        a.in_mask = sm[0];
+        a.in_mask = lengths ? sm[0] : in_mask;        // in_mask: VITS feeds `z * y_mask` (vits.py:1161), multiplied in inside conv_pre's load
         RC(ttsamd_conv1d(&a, s));
     }
     for (int i = 0; i < nu; ++i) {
@@ -599,13 +426,9 @@ extern "C" int ttsamd_hifigan_create(const ttsamd_hifigan_config *cfg, void **ha
 extern "C" int ttsamd_hifigan_load(void *handle, const char *name, const float *data, const int64_t *shape, int ndim)
 {
     return abi_guard("hifigan_load", [&]() -> int {
-        TTSAMD_CHECK_ARG(handle && name && data && shape && ndim >= 1 && ndim <= 4, "hifigan_load: bad arguments");
+        TTSAMD_CHECK_ARG(handle, "hifigan_load: NULL handle");
         Model &m = *as_model(handle);
-        HostTensor t;
-        t.shape.assign(shape, shape + ndim);
-        for (int i = 0; i < ndim; ++i) TTSAMD_CHECK_ARG(shape[i] > 0, "hifigan_load: '%s' has a non-positive dimension", name);
-        t.data.assign(data, data + t.numel());
-        m.tensors[name] = std::move(t);
+        RC(load_tensor(m.tensors, "hifigan", name, data, shape, ndim));
         m.finalized = false;
         return TTSAMD_OK;
     });
@@ -661,8 +484,16 @@ extern "C" int64_t ttsamd_hifigan_output_samples(void *handle, int frames)
 extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, float *wav, int use_graph,
                                       void *stream)
 {
+    return ttsamd_hifigan_forward_ex(handle, mel, batch, frames, lengths, nullptr, wav, use_graph, stream);
+}
+
+extern "C" int ttsamd_hifigan_forward_ex(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, const float *in_mask,
+                                         float *wav, int use_graph, void *stream)
+{
     return abi_guard("hifigan_forward", [&]() -> int {
         TTSAMD_CHECK_ARG(handle && mel && wav, "hifigan_forward: NULL argument");
+        TTSAMD_CHECK_ARG(!(lengths && in_mask), "hifigan_forward: lengths (ragged-exact batching) and in_mask are alternatives");
+        TTSAMD_CHECK_ARG(!in_mask || as_model(handle)->cfg.inference_padding == 0, "hifigan_forward: in_mask is the decoder-inside-VITS form (inference_padding 0)");
         Model &m = *as_model(handle);
         TTSAMD_CHECK_ARG(m.finalized, "hifigan_forward: weights not loaded (ttsamd_hifigan_load ... ttsamd_hifigan_finalize)");
         TTSAMD_CHECK_ARG(batch >= 0 && frames >= 1 && batch <= 65535, "hifigan_forward: bad shape");
@@ -674,7 +505,7 @@ extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch,
         }
         hipStream_t st = as_stream(stream);
         Workspace dry{nullptr, 0, 0, true};
-        RC(run(m, dry, mel, batch, frames, lengths, wav, st));
+        RC(run(m, dry, mel, batch, frames, lengths, in_mask, wav, st));
         if (dry.used > m.work.bytes) {
             // growing the workspace invalidates every captured graph (they hold pointers into it)
             TTSAMD_HIP(hipDeviceSynchronize());
@@ -687,19 +518,19 @@ extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch,
         }
         if (use_graph) {
             for (auto &g : m.graphs)
-                if (g.mel == mel && g.lengths == lengths && g.wav == wav && g.batch == batch && g.frames == frames && g.stream == st) {
+                if (g.mel == mel && g.lengths == lengths && g.in_mask == in_mask && g.wav == wav && g.batch == batch && g.frames == frames && g.stream == st) {
                     TTSAMD_HIP(hipGraphLaunch(g.exec, st));
                     return TTSAMD_OK;
                 }
             // first sighting of this (buffers, shape, stream): run it once eagerly (one-time function attributes are set outside any
             // capture), then capture the same sequence and replay from the next call on
             Workspace w0 = real_ws(m, dry);
-            RC(run(m, w0, mel, batch, frames, lengths, wav, st));
-            GraphEntry e{mel, lengths, wav, batch, frames, st};
+            RC(run(m, w0, mel, batch, frames, lengths, in_mask, wav, st));
+            VocGraph e{mel, lengths, in_mask, wav, batch, frames, st};
             if (!m.cap_stream) TTSAMD_HIP(hipStreamCreateWithFlags(&m.cap_stream, hipStreamNonBlocking));
             TTSAMD_HIP(hipStreamBeginCapture(m.cap_stream, hipStreamCaptureModeThreadLocal));
             Workspace w1 = real_ws(m, dry);
-            const int rc = run(m, w1, mel, batch, frames, lengths, wav, m.cap_stream);
+            const int rc = run(m, w1, mel, batch, frames, lengths, in_mask, wav, m.cap_stream);
             const hipError_t he = hipStreamEndCapture(m.cap_stream, &e.graph);
             if (rc) {
                 if (e.graph) (void)hipGraphDestroy(e.graph);
@@ -715,7 +546,7 @@ extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch,
                 TTSAMD_HIP(hi);
             }
             if (m.graphs.size() >= 16) {
-                GraphEntry &old = m.graphs.front();
+                VocGraph &old = m.graphs.front();
                 // the oldest entry's stream may have been destroyed by its owner since: then wait for the whole device instead
                 if (hipStreamSynchronize(old.stream) != hipSuccess) {
                     (void)hipGetLastError();
@@ -729,7 +560,7 @@ extern "C" int ttsamd_hifigan_forward(void *handle, const float *mel, int batch,
             return TTSAMD_OK;       // (the eager run above produced this call's result)
         }
         Workspace w = real_ws(m, dry);
-        return run(m, w, mel, batch, frames, lengths, wav, st);
+        return run(m, w, mel, batch, frames, lengths, in_mask, wav, st);
     });
 }
 
