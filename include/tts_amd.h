@@ -377,6 +377,56 @@ int64_t ttsamd_vits_hop_length(void *handle);
 int ttsamd_vits_destroy(void *handle);
 
 /* ------------------------------------------------------------------------------------------
+ * Model-level handle of Glow-TTS ("mi355_glowtts_{...}") — replaces, as ONE object:
+ *   TTS/tts/models/glow_tts.py:59-105   GlowTTS.__init__ wiring (encoder, decoder), :519-530 store_inverse / load_checkpoint
+ *   :341-374, :137-148                  GlowTTS.inference / compute_outputs
+ *   TTS/tts/layers/glow_tts/encoder.py:15-179 (rel_pos_transformer encoder with prenet and DurationPredictor),
+ *   glow_tts/decoder.py:8-141, glow.py:11-233, generic/normalization.py:5-123 (squeeze, 12 x [ActNorm, InvConvNear, CouplingBlock], unsqueeze)
+ * Envelope: the single-speaker model of BASELINE configs[0] (GlowTTSConfig defaults, glow_tts_config.py:101-152): no speaker
+ * conditioning, sigmoid_scale False, num_splits 4.  Same two-call request shape as the VITS handle: encode returns the output
+ * extent; decode writes the mel (channels first [batch, out_channels, t_mel], t_mel = t_dec / num_squeeze * num_squeeze — the
+ * reference's [B, T, C] view is a transpose) and the other compute_outputs tensors into the caller's buffers. */
+typedef struct ttsamd_glowtts_config {
+    int32_t num_chars;
+    int32_t hidden_channels_enc;        /* 192 */
+    int32_t hidden_channels_dec;        /* 192 */
+    int32_t hidden_channels_dp;         /* 256 */
+    int32_t out_channels;               /* 80 */
+    int32_t encoder_kernel_size, encoder_num_layers, encoder_num_heads, encoder_hidden_channels_ffn;   /* encoder_params: 3, 6, 2, 768 */
+    int32_t encoder_rel_attn_window_size;   /* 0 = None (the config default): plain attention */
+    int32_t encoder_layer_norm_type;    /* 1 (eps 1e-4, the default) or 2 (eps 1e-5) */
+    int32_t use_encoder_prenet;         /* 1 */
+    int32_t mean_only;                  /* 1 */
+    int32_t num_flow_blocks_dec;        /* 12 */
+    int32_t kernel_size_dec, dilation_rate, num_block_layers;   /* 5, 1, 4 */
+    int32_t num_splits, num_squeeze;    /* 4, 2 */
+    float inference_noise_scale;        /* 0.0 (glow_tts_config.py:151) */
+    float length_scale;                 /* 1.0 */
+    int32_t precision;                  /* 0 h2, 1 x3, 2 f32 (as ttsamd_hifigan_config.precision) */
+} ttsamd_glowtts_config;
+typedef struct ttsamd_glowtts_outputs {
+    float *mel;            /* [batch, out_channels, t_mel]  "model_outputs" (transposed) */
+    float *y_mean;         /* [batch, out_channels, t_dec] */
+    float *y_log_scale;    /* [batch, out_channels, t_dec] */
+    float *alignments;     /* [batch, t_text, t_dec] */
+    float *durations_log;  /* [batch, t_text] */
+    float *total_durations_log;   /* [batch, t_text] */
+    float *durations;      /* [batch, t_text]  (w_ceil) */
+    int64_t *y_lengths;    /* [batch] */
+} ttsamd_glowtts_outputs;
+int ttsamd_glowtts_create(const ttsamd_glowtts_config *config /* host */, void **handle_out);
+int ttsamd_glowtts_load(void *handle, const char *name, const float *data /* host */, const int64_t *shape /* host */, int ndim);
+int ttsamd_glowtts_finalize(void *handle);
+/* x int64 [batch, t_text], x_lengths int64 [batch] (device); durations_in [batch, t_text] or NULL (a parity harness pins the integer
+ * durations with it).  ragged_exact != 0: padded tokens own no frames (the reference gives each PADDED token one frame via
+ * clamp_min, which only matters in batches). */
+int ttsamd_glowtts_encode(void *handle, const int64_t *x, const int64_t *x_lengths, int batch, int t_text, const float *durations_in,
+                          int ragged_exact, int64_t *y_lengths_host, int32_t *t_dec_out, int use_graph, void *stream);
+/* noise [batch, out_channels, t_dec] (device) or NULL when inference_noise_scale == 0 */
+int ttsamd_glowtts_decode(void *handle, const float *noise, const ttsamd_glowtts_outputs *out /* host */, void *stream);
+int ttsamd_glowtts_destroy(void *handle);
+
+/* ------------------------------------------------------------------------------------------
  * Channel LayerNorm on [B, C, T] (normalise over C for every (b, t)), with the fusions the text
  * encoder / duration predictors need.
  * replaces: TTS/tts/layers/generic/normalization.py:5-28 (LayerNorm, eps 1e-4) and :31-53

@@ -35,7 +35,7 @@ def test_host_side_policy_queries_need_no_gpu():
     """The pure-host queries of the ABI (no kernel behind them): version, which (kernel, dilation) pairs have a tuned conv
     instantiation vs the generic kernel, which fused pairs exist, and the shape window of the grouped MRF launch."""
     L = ctypes.CDLL(_lib.LIB_PATH)
-    assert L.ttsamd_abi_version() == 3
+    assert L.ttsamd_abi_version() == 4
     for k, d, sup, tuned in ((11, 1, 1, 1), (3, 9, 1, 1), (9, 2, 1, 0), (31, 27, 1, 0), (32, 1, 0, 0), (3, 28, 0, 0), (4, 1, 1, 0)):
         assert (L.ttsamd_conv1d_supported(k, d), L.ttsamd_conv1d_tuned(k, d)) == (sup, tuned), (k, d)
     assert L.ttsamd_resblock_pair_supported(16, 7, 3) == 1 and L.ttsamd_resblock_pair_supported(48, 7, 3) == 0

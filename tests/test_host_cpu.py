@@ -471,6 +471,36 @@ def test_host_pack_code_and_mas_oracle_under_sanitizers(tmp_path):
     assert r.returncode == 0 and "sanitize_driver: ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
+def test_model_handles_hostile_inputs_under_sanitizers(tmp_path):
+    """include/tts_amd.h:7 "never throws / aborts across the ABI", by construction and by test: the REAL sources of the three
+    model-level handles (csrc/hifigan_model.hip, vits_model.hip, glow_model.hip + model_common.hip, model_layers.hip, pack_host.cpp)
+    compiled as plain C++ with -fsanitize=address,undefined against a malloc-backed stand-in for the HIP runtime
+    (tests/native/hip_stub) and stand-ins for the kernel launches that read / write exactly the extents their arguments declare
+    (tests/native/kernel_stubs.cpp).  tests/native/handles_driver.cpp then feeds them malformed configs (0 / 13 upsample layers,
+    kernel < stride, odd channels, odd flow counts), wrong-shape / duplicate / absurdly sized loads, finalize without weights and
+    twice, forward / encode / decode before finalize and out of order, NULL pointers, a token outside the embedding table, a
+    singular InvConvNear matrix, a device allocation that fails in the middle of a finalize / a workspace growth — every one a
+    negative return code with a message — and runs whole requests (plain, ragged, growing and shrinking shapes) whose every launch
+    must land inside exactly-sized heap buffers; no leaks at exit.  (the double-finalize null dereference, the
+    ever-growing workspace, the graph-cache leaks.)"""
+    import shutil
+    import subprocess
+
+    cxx = next((c for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("g++") or "", shutil.which("c++") or "") if c and os.path.exists(c)), None)
+    if cxx is None:
+        pytest.skip("no host compiler")
+    nat, csrc = os.path.join(ROOT, "tests", "native"), os.path.join(ROOT, "tts_amd", "csrc")
+    exe = str(tmp_path / "handles_driver")
+    srcs = [os.path.join(nat, f) for f in ("handles_driver.cpp", "hip_stub.cpp", "kernel_stubs.cpp")] + \
+           [os.path.join(csrc, f) for f in ("pack_host.cpp", "model_common.hip", "model_layers.hip", "hifigan_model.hip", "vits_model.hip", "glow_model.hip")]
+    r = subprocess.run([cxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-I", os.path.join(nat, "hip_stub"), "-x", "c++"] + srcs + ["-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "handles_driver: ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_h2_weight_image_matches_a_numpy_restatement():
     """ttsamd_conv1d_pack_weights_h2 against numpy: per-row power-of-two scale (row maximum in [2^13, 2^14)), hi = float16(w s),
     lo = float16((w s - hi) 2^11) with numpy's round-to-nearest-even conversions (denormal halves included), fragment order

@@ -16,7 +16,7 @@ void set_error(const char *fmt, ...)
 }  // namespace ttsamd
 
 extern "C" const char *ttsamd_last_error(void) { return ttsamd::g_err; }
-extern "C" int ttsamd_abi_version(void) { return 3; }   // 2: ttsamd_resblock_args carries the weight image sizes; 3: w_h2 / w1_h2 / w2_h2 (three-product arithmetic)
+extern "C" int ttsamd_abi_version(void) { return 4; }   // 4: model-level handles of VITS / Glow-TTS, TTSAMD_ERR_INTERNAL; 2: ttsamd_resblock_args carries the weight image sizes; 3: w_h2 / w1_h2 / w2_h2 (three-product arithmetic)
 extern "C" const char *ttsamd_arch(void) { return "gfx950"; }
 extern "C" uint64_t ttsamd_launch_count(void) { return ttsamd::g_launches.load(std::memory_order_relaxed); }
 
