@@ -1,0 +1,159 @@
+// A host that is not Python: loads a flat weight file and a request, runs VITS end to end through the model-level C ABI
+// (include/tts_amd.h: ttsamd_vits_{create,load,finalize,encode,decode,destroy}) and compares the waveform with the expected one —
+// tests/test_native_models_gpu.py feeds it the committed golden fixture generated from the REAL reference modules
+// (tests/golden/vits_small_sdp.npz).  Build (GPU box):
+//     hipcc -std=c++17 -O2 tests/native/vits_host.cpp -I include -L tts_amd -ltts_amd -Wl,-rpath,$PWD/tts_amd -o vits_host
+//     ./vits_host weights.bin case.bin
+// weights.bin: "TTSAMDW1", u32 n, then n x { u32 name_len, name, u32 ndim, i64 dims[ndim], f32 data[prod dims] }   (state_dict order)
+// case.bin:    "TTSAMDC1", u32 cfg_bytes, ttsamd_vits_config, i32 B, i32 T, i64 x[B*T], i64 x_lengths[B], f32 noise_dp[B*2*T],
+//              f32 durations[B*T], i32 t_dec, f32 noise_z[B*H*t_dec], f32 wav[B*t_dec*hop], f32 tol_rms, f32 tol_rel
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tts_amd.h"
+
+#define CHECK(c)                                                                                               \
+    do {                                                                                                       \
+        if (!(c)) {                                                                                            \
+            fprintf(stderr, "vits_host: FAILED %s:%d: %s   (%s)\n", __FILE__, __LINE__, #c, ttsamd_last_error()); \
+            return 1;                                                                                          \
+        }                                                                                                      \
+    } while (0)
+
+struct Reader {
+    FILE *f;
+    bool ok = true;
+    template <class T>
+    T get()
+    {
+        T v{};
+        ok = ok && fread(&v, sizeof(T), 1, f) == 1;
+        return v;
+    }
+    template <class T>
+    std::vector<T> vec(size_t n)
+    {
+        std::vector<T> v(n);
+        ok = ok && (n == 0 || fread(v.data(), sizeof(T), n, f) == n);
+        return v;
+    }
+};
+
+template <class T>
+static T *to_device(const std::vector<T> &v)
+{
+    T *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), v.size() * sizeof(T) + 16) != hipSuccess) return nullptr;
+    if (hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return p;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) {
+        fprintf(stderr, "usage: vits_host weights.bin case.bin\n");
+        return 2;
+    }
+    // ---- the request -----------------------------------------------------------------------------------------------------------
+    Reader c{fopen(argv[2], "rb")};
+    CHECK(c.f);
+    char magic[8];
+    CHECK(fread(magic, 1, 8, c.f) == 8 && memcmp(magic, "TTSAMDC1", 8) == 0);
+    CHECK(c.get<uint32_t>() == sizeof(ttsamd_vits_config));
+    const ttsamd_vits_config cfg = c.get<ttsamd_vits_config>();
+    const int B = c.get<int32_t>(), T = c.get<int32_t>(), H = cfg.hidden_channels;
+    auto x = c.vec<int64_t>((size_t)B * T), xl = c.vec<int64_t>((size_t)B);
+    auto noise_dp = c.vec<float>((size_t)B * 2 * T), dur = c.vec<float>((size_t)B * T);
+    const int t_dec = c.get<int32_t>();
+    int64_t hop = 1;
+    for (int i = 0; i < cfg.decoder.num_upsamples; ++i) hop *= cfg.decoder.upsample_factors[i];
+    auto noise_z = c.vec<float>((size_t)B * H * t_dec), want = c.vec<float>((size_t)B * t_dec * hop);
+    const float tol_rms = c.get<float>(), tol_rel = c.get<float>();
+    CHECK(c.ok);
+    fclose(c.f);
+    // ---- the model --------------------------------------------------------------------------------------------------------------
+    void *h = nullptr;
+    CHECK(ttsamd_vits_create(&cfg, &h) == 0);
+    Reader w{fopen(argv[1], "rb")};
+    CHECK(w.f);
+    CHECK(fread(magic, 1, 8, w.f) == 8 && memcmp(magic, "TTSAMDW1", 8) == 0);
+    const uint32_t n = w.get<uint32_t>();
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t nl = w.get<uint32_t>();
+        CHECK(w.ok && nl < 4096);
+        const auto name = w.vec<char>(nl);
+        const uint32_t nd = w.get<uint32_t>();
+        CHECK(w.ok && nd >= 1 && nd <= 4);
+        const auto dims = w.vec<int64_t>(nd);
+        size_t cnt = 1;
+        for (auto d : dims) cnt *= (size_t)d;
+        const auto data = w.vec<float>(cnt);
+        CHECK(w.ok);
+        CHECK(ttsamd_vits_load(h, std::string(name.begin(), name.end()).c_str(), data.data(), dims.data(), (int)nd) == 0);
+    }
+    fclose(w.f);
+    CHECK(ttsamd_vits_finalize(h) == 0);
+    CHECK(ttsamd_vits_hop_length(h) == hop);
+    // ---- one request: encode (durations on the host), decode ---------------------------------------------------------------------
+    int64_t *dx = to_device(x), *dxl = to_device(xl);
+    float *dnd = to_device(noise_dp), *ddur = to_device(dur), *dnz = to_device(noise_z);
+    float *dwav = nullptr, *dlogw = nullptr;
+    CHECK(dx && dxl && dnd && ddur && dnz);
+    CHECK(hipMalloc(reinterpret_cast<void **>(&dwav), want.size() * 4) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&dlogw), (size_t)B * T * 4) == hipSuccess);
+    hipStream_t st = nullptr;
+    CHECK(hipStreamCreate(&st) == hipSuccess);
+    std::vector<int64_t> ylen((size_t)B);
+    int32_t td = 0;
+    // first with the model's own durations (ceil(exp(logw)) on the device) ...
+    CHECK(ttsamd_vits_encode(h, dx, dxl, B, T, dnd, nullptr, 0, ylen.data(), &td, 0, st) == 0);
+    bool own = td == t_dec;
+    if (own) {
+        std::vector<float> got_dur((size_t)B * T);
+        float *ddur_out = nullptr;
+        CHECK(hipMalloc(reinterpret_cast<void **>(&ddur_out), got_dur.size() * 4) == hipSuccess);
+        ttsamd_vits_outputs o0;
+        memset(&o0, 0, sizeof(o0));
+        o0.wav = dwav;
+        o0.durations = ddur_out;
+        CHECK(ttsamd_vits_decode(h, dnz, &o0, st) == 0);
+        CHECK(hipStreamSynchronize(st) == hipSuccess && hipMemcpy(got_dur.data(), ddur_out, got_dur.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        own = memcmp(got_dur.data(), dur.data(), got_dur.size() * 4) == 0;
+        (void)hipFree(ddur_out);
+    }
+    if (!own) {
+        // ... a 1-ulp logw difference next to an integer may flip a ceil() between two fp32 implementations: the expected durations
+        // are then injected (the predictor still runs), as the Python parity tests do
+        printf("vits_host: duration flip against the fixture: injecting its durations\n");
+        CHECK(ttsamd_vits_encode(h, dx, dxl, B, T, dnd, ddur, 1, ylen.data(), &td, 0, st) == 0);
+        CHECK(td == t_dec);
+        ttsamd_vits_outputs o1;
+        memset(&o1, 0, sizeof(o1));
+        o1.wav = dwav;
+        o1.logw = dlogw;
+        CHECK(ttsamd_vits_decode(h, dnz, &o1, st) == 0);
+    }
+    std::vector<float> got(want.size());
+    CHECK(hipStreamSynchronize(st) == hipSuccess && hipMemcpy(got.data(), dwav, got.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+    double se = 0, sw = 0;
+    for (size_t i = 0; i < got.size(); ++i) {
+        const double d = (double)got[i] - want[i];
+        se += d * d;
+        sw += (double)want[i] * want[i];
+    }
+    const double rms = std::sqrt(se / got.size()), rel = rms / (std::sqrt(sw / got.size()) + 1e-30);
+    printf("vits_host: %d utterances, %d frames, %zu samples, %s durations: waveform RMS %.3e (relative %.3e) against the fixture\n", B, t_dec, got.size(),
+           own ? "the model's own" : "injected", rms, rel);
+    CHECK(rms < tol_rms && rel < tol_rel);
+    CHECK(ttsamd_vits_destroy(h) == 0);
+    (void)hipFree(dx), (void)hipFree(dxl), (void)hipFree(dnd), (void)hipFree(ddur), (void)hipFree(dnz), (void)hipFree(dwav), (void)hipFree(dlogw);
+    (void)hipStreamDestroy(st);
+    printf("vits_host: ok\n");
+    return 0;
+}

@@ -165,3 +165,52 @@ def test_native_glowtts_handle_equals_the_python_driven_path(gpu, variant):
     with pytest.raises(_lib.TtsAmdError):
         NativeGlowTTS(m, {k: v for k, v in sd.items() if "flows.5." not in k})
     nat.close()
+
+
+def test_cxx_host_runs_vits_from_a_flat_weight_file_and_reproduces_the_reference_golden(gpu, tmp_path):
+    """A host that is NOT Python (tests/native/vits_host.cpp, linked against libtts_amd.so and the HIP runtime only): loads the
+    weights from a flat file, runs create / load / finalize / encode / decode through the model-level C ABI and reproduces the
+    waveform of the committed fixture generated from the REAL reference modules (tests/golden/vits_small_sdp.npz) within
+    1e-4 RMS / 1e-5 relative."""
+    import ctypes
+    import os
+    import shutil
+    import struct
+    import subprocess
+
+    import numpy as np
+
+    from tests.golden import cases
+    from tts_amd import native
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    gold = np.load(os.path.join(root, "tests", "golden", "vits_small_sdp.npz"))
+    args = dict(cases.VITS_SMALL, use_sdp=True)
+    sd = W.make_vits_state(args, seed=1234)
+    x = torch.randint(0, 100, (3, 37), generator=torch.Generator().manual_seed(0))
+    xl = torch.tensor([37, 30, 21])
+    t_dec = gold["z_p"].shape[2]
+    torch.manual_seed(7)                        # the reference draws randn(B,2,T) then randn_like(m_p) (tests/test_vits_gpu.py)
+    noise_dp = torch.randn(3, 2, 37)
+    noise_z = torch.randn_like(torch.empty(3, t_dec, 192).transpose(1, 2)).contiguous()
+    m = Vits({"model_args": args})
+    m.load_state_dict(sd)                       # (CPU object: only its arguments are read)
+    cfg = native.vits_config(m, sd, precision="h2")
+    wpath, cpath, exe = str(tmp_path / "weights.bin"), str(tmp_path / "case.bin"), str(tmp_path / "vits_host")
+    native.save_flat_weights(sd, wpath)
+    wav = torch.from_numpy(gold["model_outputs"]).float().contiguous()
+    with open(cpath, "wb") as f:
+        f.write(b"TTSAMDC1" + struct.pack("<I", ctypes.sizeof(cfg)) + bytes(cfg) + struct.pack("<ii", 3, 37))
+        f.write(x.numpy().astype(np.int64).tobytes() + xl.numpy().astype(np.int64).tobytes() + noise_dp.numpy().tobytes())
+        f.write(torch.from_numpy(gold["durations"]).float().reshape(3, 37).contiguous().numpy().tobytes())
+        f.write(struct.pack("<i", t_dec) + noise_z.numpy().tobytes() + wav.numpy().tobytes() + struct.pack("<ff", 1e-4, 1e-5))
+    libdir = os.path.join(root, "tts_amd")
+    r = subprocess.run([hipcc, "-std=c++17", "-O2", os.path.join(root, "tests", "native", "vits_host.cpp"), "-I", os.path.join(root, "include"),
+                        "-L", libdir, "-ltts_amd", "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, wpath, cpath], capture_output=True, text=True, timeout=240)
+    print(r.stdout)
+    assert r.returncode == 0 and "vits_host: ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

@@ -4,6 +4,8 @@ load_checkpoint, :541-557 init_from_config).  Config field names/defaults: GlowT
 (TTS/tts/configs/glow_tts_config.py:101-152).  Single- and multi-speaker (speaker-embedding table or d-vectors);
 training is out of scope.
 """
+import os
+
 import torch
 
 from . import _lib, graphs, helpers, layers, ops
@@ -69,6 +71,12 @@ class GlowTTS:
         self.weights_version = 0               # bumped by every re-pack: dependants (SentencePipeline) key their graphs on it
         self.graph_tail_max_frames = 4096      # B * padded frames up to which the tail is captured
         self.text_bucket = 16                  # token-axis padding of graphed requests (1 = off)
+        # plain requests of a single-speaker model run behind the model-level C handle (ttsamd_glowtts_*, csrc/glow_model.hip;
+        # see tts_amd.Vits.use_native): batches there, single sentences on the captured front + tail of this class
+        self.use_native = os.environ.get("TTSAMD_NATIVE_MODELS", "1") != "0"
+        self.native_single_requests = os.environ.get("TTSAMD_NATIVE_SINGLE", "0") != "0"
+        self._native = {}
+        self._native_sd = None
 
     @staticmethod
     def init_from_config(config, samples=None, verbose=True):
@@ -109,6 +117,7 @@ class GlowTTS:
         self._front.clear()          # captured graphs hold raw pointers to the weight tensors replaced below
         self._tail.clear()
         self.weights_version += 1
+        self._drop_native()
         self.encoder = layers.GlowEncoder(sd, "encoder.", dev, a.hidden_channels_enc, a.out_channels, a.encoder_params,
                                           a.mean_only, a.use_encoder_prenet)
         self.decoder = layers.GlowDecoder(sd, "decoder.", dev, a.out_channels, a.hidden_channels_dec, a.kernel_size_dec,
@@ -119,6 +128,55 @@ class GlowTTS:
             if "emb_g.weight" not in sd:
                 raise _lib.TtsAmdError("use_speaker_embedding is set but the checkpoint has no emb_g.weight")
             self.emb_g = sd["emb_g.weight"].to(dev, torch.float32).contiguous()
+
+    # ---- the model-level C handle (tts_amd/native.py) ---------------------------------------------------
+    def _drop_native(self):
+        for n in self._native.values():
+            n.close()
+        self._native, self._native_sd = {}, None
+
+    def _native_for_stream(self):
+        """The NativeGlowTTS of the current stream (a handle holds one request's state), built on first use from the weights folded
+        here and the 4 x 4 inverses computed here (store_inverse), so that it is bitwise the Python-driven path."""
+        from . import native
+
+        key = torch.cuda.current_stream().cuda_stream
+        nat = self._native.get(key)
+        scales = (float(self.inference_noise_scale), float(self.length_scale))
+        if nat is not None and tuple(round(v, 6) for v in nat.scales) != tuple(round(v, 6) for v in scales):
+            nat.close()
+            nat = None
+        if nat is None:
+            if self._native_sd is None:
+                sd = {}
+                for k, v in self._sd.items():
+                    if k.startswith("emb_g"):
+                        continue
+                    if k.endswith(".parametrizations.weight.original0") or k.endswith(".weight_g"):
+                        name = k[: -len(".parametrizations.weight.original0")] if k.endswith("original0") else k[: -len(".weight_g")]
+                        sd[name + ".weight"] = ops.fold_weight_norm(self._sd, name)
+                    elif not (k.endswith(".parametrizations.weight.original1") or k.endswith(".weight_v")):
+                        sd[k] = v
+                for k in list(sd):          # InvConvNear: the inverse this class would compute (layers.GlowDecoder)
+                    if k.startswith("decoder.flows.") and k.endswith(".weight") and sd[k].dim() == 2 and (k[: -len("weight")] + "weight_inv") not in sd:
+                        sd[k[: -len("weight")] + "weight_inv"] = torch.inverse(sd[k].float())
+                self._native_sd = sd
+            if len(self._native) >= 4:
+                self._native.pop(next(iter(self._native))).close()
+            nat = self._native[key] = native.NativeGlowTTS(self, self._native_sd)
+        return nat
+
+    def _native_request(self, aux_input, B):
+        from . import native
+
+        a = aux_input or {}
+        if not (self.use_native and native.glow_in_envelope(self)):
+            return False
+        if any(a.get(k) is not None for k in ("speaker_ids", "d_vectors", "_front_ctx")):
+            return False
+        if B == 1 and self.use_graphs and not a.get("no_graph") and not self.native_single_requests:
+            return False
+        return True
 
     def _speaker_embedding(self, aux_input, dev):
         """glow_tts.py:162-191: g = normalize(emb_g(speaker_ids)) or normalize(d_vectors), [B, C, 1]; None if neither."""
@@ -252,6 +310,12 @@ class GlowTTS:
         tile choice: fp32 reassociation, ~1e-6 relative)."""
         # "_front_ctx": the context of a request_front() the caller has already run for this very request (a Synthesizer whose
         # fused pipeline declined a large batch): the front end — and the request's host wait — is not repeated
+        if self.encoder is not None and x.is_cuda and self._native_request(aux_input, x.shape[0]):
+            a_in = aux_input or {}
+            nat = self._native_for_stream()
+            t_dec, _ = nat.encode(x, a_in.get("x_lengths"), a_in.get("durations"), bool(a_in.get("ragged_exact")),
+                                  use_graph=bool(self.use_graphs) and not a_in.get("no_graph"))
+            return nat.decode(t_dec, a_in.get("noise"))
         ctx = (aux_input or {}).get("_front_ctx") or self.request_front(x, aux_input)
         a = self.args
         B, T, T0, dev, t_dec, ragged = ctx["B"], ctx["T"], ctx["T0"], ctx["dev"], ctx["t_dec"], ctx["ragged"]

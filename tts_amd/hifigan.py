@@ -49,6 +49,17 @@ class NativeHifigan:
     _PREC = {"h2": 0, "x3": 1, "f32": 2}
 
     def __init__(self, gen, state_dict=None, precision=None):
+        """`gen`: a tts_amd.HifiganGenerator, or — no Python generator needed — a dict of HifiganGenerator's constructor arguments
+        (in_channels, out_channels, resblock_type, resblock_dilation_sizes, resblock_kernel_sizes, upsample_kernel_sizes,
+        upsample_initial_channel, upsample_factors, inference_padding; hifigan_generator.py:163-178) with `state_dict` given."""
+        if isinstance(gen, dict):
+            import types
+
+            g = types.SimpleNamespace(**gen)
+            g.num_kernels, g.num_upsamples = len(g.resblock_kernel_sizes), len(g.upsample_factors)
+            g.inference_padding = gen.get("inference_padding", 5)
+            g.cond_channels, g.cond_in_each_up_layer, g._sd = gen.get("cond_channels", 0), gen.get("cond_in_each_up_layer", False), None
+            gen = g
         sd = state_dict if state_dict is not None else gen._sd
         if sd is None:
             raise _lib.TtsAmdError("NativeHifigan: no weights")

@@ -115,17 +115,7 @@ class NativeVits(_Handle):
         if sd is None:
             raise _lib.TtsAmdError("NativeVits: no weights")
         a = model.args
-        c = VitsConfig()
-        c.num_chars = int(sd["text_encoder.emb.weight"].shape[0])
-        c.hidden_channels, c.hidden_channels_ffn_text_encoder = a.hidden_channels, a.hidden_channels_ffn_text_encoder
-        c.num_heads_text_encoder, c.num_layers_text_encoder = a.num_heads_text_encoder, a.num_layers_text_encoder
-        c.kernel_size_text_encoder = a.kernel_size_text_encoder
-        c.kernel_size_flow, c.dilation_rate_flow, c.num_layers_flow, c.num_flows = a.kernel_size_flow, a.dilation_rate_flow, a.num_layers_flow, 4
-        c.use_sdp = int(bool(a.use_sdp))
-        c.inference_noise_scale = float(model.inference_noise_scale)
-        c.inference_noise_scale_dp = float(model.inference_noise_scale_dp)
-        c.length_scale = float(model.length_scale)
-        c.decoder = hifigan_config(model.waveform_decoder, precision)
+        c = vits_config(model, sd, precision)
         self.hidden, self.use_sdp = a.hidden_channels, bool(a.use_sdp)
         self.scales = (c.inference_noise_scale, c.inference_noise_scale_dp, c.length_scale)
         self._h = ctypes.c_void_p()
@@ -179,6 +169,7 @@ class NativeVits(_Handle):
             out["y_lengths"] = torch.empty(B, dtype=torch.int64, device=dev)
             out["x"] = new(B, H, T)
             o.y_lengths, o.x_hidden = out["y_lengths"].data_ptr(), out["x"].data_ptr()
+            out["logw"] = None
             if self._ran_dp:
                 out["logw"] = new(B, 1, T)
                 o.logw = out["logw"].data_ptr()
@@ -270,3 +261,35 @@ class NativeGlowTTS(_Handle):
     def inference(self, x, x_lengths=None, noise=None, durations=None, ragged_exact=False, use_graph=False):
         t_dec, _ = self.encode(x, x_lengths, durations, ragged_exact, use_graph)
         return self.decode(t_dec, noise)
+
+
+def save_flat_weights(sd, path):
+    """A reference-layout state_dict as the flat file a non-Python host reads (tests/native/vits_host.cpp): "TTSAMDW1", u32 n, then
+    n x { u32 name_len, name, u32 ndim, i64 dims[ndim], f32 data }."""
+    import struct
+
+    items = [(k, v.detach().to("cpu", torch.float32).contiguous()) for k, v in sd.items() if v.dim() >= 1 and v.numel() > 0]
+    with open(path, "wb") as f:
+        f.write(b"TTSAMDW1" + struct.pack("<I", len(items)))
+        for k, v in items:
+            kb = k.encode()
+            f.write(struct.pack("<I", len(kb)) + kb + struct.pack("<I", v.dim()) + struct.pack("<%dq" % v.dim(), *v.shape))
+            f.write(v.numpy().tobytes())
+
+
+def vits_config(model, state_dict=None, precision=None):
+    """`ttsamd_vits_config` of a tts_amd.Vits (what NativeVits passes to ttsamd_vits_create)."""
+    sd = state_dict if state_dict is not None else model._sd
+    a = model.args
+    c = VitsConfig()
+    c.num_chars = int(sd["text_encoder.emb.weight"].shape[0])
+    c.hidden_channels, c.hidden_channels_ffn_text_encoder = a.hidden_channels, a.hidden_channels_ffn_text_encoder
+    c.num_heads_text_encoder, c.num_layers_text_encoder = a.num_heads_text_encoder, a.num_layers_text_encoder
+    c.kernel_size_text_encoder = a.kernel_size_text_encoder
+    c.kernel_size_flow, c.dilation_rate_flow, c.num_layers_flow, c.num_flows = a.kernel_size_flow, a.dilation_rate_flow, a.num_layers_flow, 4
+    c.use_sdp = int(bool(a.use_sdp))
+    c.inference_noise_scale = float(model.inference_noise_scale)
+    c.inference_noise_scale_dp = float(model.inference_noise_scale_dp)
+    c.length_scale = float(model.length_scale)
+    c.decoder = hifigan_config(model.waveform_decoder, precision)
+    return c

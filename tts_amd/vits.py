@@ -7,6 +7,8 @@ load_checkpoint, :1771-1804 init_from_config).
 `inference(x, aux_input) -> {"model_outputs", "alignments", ...}`; all are here with
 the reference's names and argument meaning.  Training, ONNX export, voice conversion are out of scope.
 """
+import os
+
 import torch
 
 from . import _lib, graphs, helpers, layers, ops
@@ -115,6 +117,16 @@ class Vits:
         self._tail_cfg = None
         self.graph_tail_max_frames = 2048      # B * padded frames up to which the tail is captured
         self.text_bucket = 16                  # token-axis padding of graphed requests (1 = off): 16 lengths share a capture
+        # Plain requests of a single-speaker model run behind the model-level C handle (include/tts_amd.h: ttsamd_vits_*,
+        # csrc/vits_model.hip; tts_amd/native.py): the whole launch sequence, the duration sync and the front end's graph replay are
+        # C++ — this class then only marshals pointers and draws the two noise tensors.  The handle gets the weights THIS class
+        # folded, so it is bitwise the Python-driven path below, which stays for what the handle's envelope leaves out (speaker /
+        # language conditioning, ragged-exact batches, latent interpolation) and for single requests, whose captured tail
+        # (`_tail`) the handle does not have.  TTSAMD_NATIVE_MODELS=0 / use_native = False: Python-driven everywhere.
+        self.use_native = os.environ.get("TTSAMD_NATIVE_MODELS", "1") != "0"
+        self.native_single_requests = os.environ.get("TTSAMD_NATIVE_SINGLE", "0") != "0"
+        self._native = {}                      # stream handle -> NativeVits (a handle holds ONE request's state)
+        self._native_sd = None
 
     # ---- plug-in surface ---------------------------------------------------------------------------
     @staticmethod
@@ -164,6 +176,7 @@ class Vits:
         self._front.clear()
         self._tail.clear()
         self.weights_version += 1
+        self._drop_native()
         self.text_encoder = layers.TextEncoder(sd, "text_encoder.", dev, a.hidden_channels, a.num_layers_text_encoder,
                                                a.num_heads_text_encoder, a.kernel_size_text_encoder)
         spk = self.embedded_speaker_dim
@@ -191,6 +204,53 @@ class Vits:
 
     def weight_bytes(self):
         return sum(v.numel() * 4 for v in self._sd.values())
+
+    # ---- the model-level C handle (tts_amd/native.py) ---------------------------------------------------
+    def _drop_native(self):
+        for n in self._native.values():
+            n.close()
+        self._native, self._native_sd = {}, None
+
+    def _native_for_stream(self):
+        """The NativeVits of the current stream (one per request lane: a handle holds one request's state), built on first use from
+        the weights folded here; rebuilt when the inference scales were changed on the object."""
+        from . import native
+
+        key = torch.cuda.current_stream().cuda_stream
+        nat = self._native.get(key)
+        scales = (float(self.inference_noise_scale), float(self.inference_noise_scale_dp), float(self.length_scale))
+        if nat is not None and tuple(round(v, 6) for v in nat.scales) != tuple(round(v, 6) for v in scales):
+            nat.close()
+            nat = None
+        if nat is None:
+            if self._native_sd is None:
+                sd = {}
+                for k, v in self._sd.items():
+                    if k.startswith("posterior_encoder.") or k.startswith("emb_"):
+                        continue
+                    if k.endswith(".parametrizations.weight.original0") or k.endswith(".weight_g"):
+                        name = k[: -len(".parametrizations.weight.original0")] if k.endswith("original0") else k[: -len(".weight_g")]
+                        sd[name + ".weight"] = ops.fold_weight_norm(self._sd, name)
+                    elif not (k.endswith(".parametrizations.weight.original1") or k.endswith(".weight_v")):
+                        sd[k] = v
+                self._native_sd = sd
+            if len(self._native) >= 4:           # lanes come and go: keep the handles of the four most recent streams
+                self._native.pop(next(iter(self._native))).close()
+            nat = self._native[key] = native.NativeVits(self, self._native_sd)
+        return nat
+
+    def _native_request(self, aux_input, B):
+        """Does this request run behind the handle?  (See `use_native`.)"""
+        from . import native
+
+        a = aux_input or {}
+        if not (self.use_native and native.vits_in_envelope(self) and self.args.num_layers_flow > 0):
+            return False
+        if any(a.get(k) is not None for k in ("speaker_ids", "d_vectors", "language_ids")) or a.get("ragged_exact"):
+            return False
+        if B == 1 and self.use_graphs and not a.get("no_graph") and not self.native_single_requests:
+            return False          # a single request: the captured tail of the Python host (measured: profiles/r06_native_ab.txt)
+        return True
 
     def _front_eager(self, x, x_mask, noise_dp, g_dp, lang):
         """Text encoder + duration predictor: tokens -> (hidden, prior stats, logw).  g_dp [B,C,1] / lang [B,L,1] or
@@ -347,6 +407,12 @@ class Vits:
             x_lengths = torch.full((B,), T, dtype=torch.int64, device=dev)       # vits.py:1082-1086
         durations = aux_input.get("durations") if aux_input else None
         no_graph = bool((aux_input or {}).get("no_graph", False))
+        if self._native_request(aux_input, B):
+            a_in = aux_input or {}
+            nat = self._native_for_stream()
+            t_dec, _ = nat.encode(x, x_lengths, a_in.get("noise_dp"), durations, bool(a_in.get("run_duration_predictor")),
+                                  use_graph=bool(self.use_graphs) and not no_graph)
+            return nat.decode(t_dec, a_in.get("noise_z"), extras=bool(a_in.get("return_extras")))
         # Text-length buckets: real traffic brings a new token count with almost every request, and a captured front end is
         # keyed by its shape.  With graphs on, the token axis is padded to a multiple of 16 (pad ids masked out by x_mask —
         # exactly the situation of a shorter sentence inside a batch: masked convs / attention / flows give the valid
