@@ -311,6 +311,11 @@ int ttsamd_hifigan_forward(void *handle, const float *mel, int batch, int frames
  * inside VITS is fed `z * y_mask` (TTS/tts/models/vits.py:1161).  `lengths` and `in_mask` are alternatives. */
 int ttsamd_hifigan_forward_ex(void *handle, const float *mel, int batch, int frames, const int64_t *lengths, const float *in_mask,
                               float *wav, int use_graph, void *stream);
+/* Options of a vocoder handle.  CONCURRENT_BRANCHES (default 1): the MRF resblocks of a stage run on the handle's own branch streams
+ * (one per resblock kernel size), joined by events in the reference's accumulation order — right for a lone request, whose branch
+ * launches are too small to fill the chip; a host that keeps several requests in flight (one handle per request lane) sets 0. */
+#define TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES 1
+int ttsamd_hifigan_set_option(void *handle, int option, int value);
 int ttsamd_hifigan_destroy(void *handle);
 
 /* ------------------------------------------------------------------------------------------
@@ -358,6 +363,10 @@ typedef struct ttsamd_vits_outputs {
     int64_t *y_lengths;  /* [batch] int64 */
     float *logw;         /* [batch, t_text]: the duration predictor's output (NULL when it did not run) */
     float *x_hidden;     /* [batch, hidden, t_text]: the text encoder's hidden output */
+    int32_t t_text_out;  /* 0, or the token count the token-indexed outputs (alignments, durations, logw, x_hidden) are written at when
+                            the request ran on a PADDED token axis (a host that pads ids to a length bucket so that requests share a
+                            captured front end: pad ids masked out by x_lengths own no frames): [batch, t_text_out, t_dec] etc.
+                            Only with a replayed tail (decode use_graph on a single request), whose outputs are copies anyway. */
 } ttsamd_vits_outputs;
 int ttsamd_vits_create(const ttsamd_vits_config *config /* host */, void **handle_out);
 /* one state_dict entry under its reference key ("text_encoder.emb.weight", "duration_predictor.flows.1.convs.norms_1.0.gamma",
@@ -371,9 +380,13 @@ int ttsamd_vits_finalize(void *handle);
 int ttsamd_vits_encode(void *handle, const int64_t *x, const int64_t *x_lengths, int batch, int t_text, const float *noise_dp,
                        const float *durations_in, int run_duration_predictor, int64_t *y_lengths_host, int32_t *t_dec_out,
                        int use_graph, void *stream);
-/* second half of the request encode started.  noise_z [batch, hidden, t_dec] (device), t_dec as returned by encode. */
-int ttsamd_vits_decode(void *handle, const float *noise_z, const ttsamd_vits_outputs *out /* host */, void *stream);
+/* second half of the request encode started.  noise_z [batch, hidden, t_dec] (device), t_dec as returned by encode.  use_graph != 0:
+ * a single request (batch 1) replays its tail — prior expansion, flows, waveform decoder, ~110 launches — as one hipGraph per 32-frame
+ * length bucket over the handle's static buffers, run ragged-exact inside the padded tensors, and copies the outputs out cut to the
+ * true extent (one launch); batches run eagerly. */
+int ttsamd_vits_decode(void *handle, const float *noise_z, const ttsamd_vits_outputs *out /* host */, int use_graph, void *stream);
 int64_t ttsamd_vits_hop_length(void *handle);
+int ttsamd_vits_set_option(void *handle, int option, int value);   /* forwarded to the waveform decoder: TTSAMD_HIFIGAN_OPT_* */
 int ttsamd_vits_destroy(void *handle);
 
 /* ------------------------------------------------------------------------------------------

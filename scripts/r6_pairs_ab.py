@@ -14,7 +14,8 @@ from tts_amd import ops  # noqa: E402
 dev = "cuda:0"
 B = 32
 what = set(sys.argv[1:]) or {"pairs", "convs", "ups"}
-tag = os.path.basename(os.environ.get("TTSAMD_LIB_PATH", "libtts_amd.so"))
+variant = int(os.environ.get("PAIR_VARIANT", "0"))
+tag = os.path.basename(os.environ.get("TTSAMD_LIB_PATH", "libtts_amd.so")) + ("" if not variant else "/v%d" % variant)
 
 
 def time_us(f, n=10):
@@ -47,7 +48,7 @@ if "pairs" in what:
                 pc1 = ops.PackedConv(torch.randn(C, C, K, generator=g) / (C * K) ** 0.5, torch.randn(C, generator=g), dev, dilation=D)
                 pc2 = ops.PackedConv(torch.randn(C, C, K, generator=g) / (C * K) ** 0.5, torch.randn(C, generator=g), dev)
                 acc = x.roll(1, 0).contiguous() if D == 5 and K > 3 else None
-                f = lambda: ops.resblock_pair(pc1, pc2, x, y, slope=0.1, accum=acc, out_div=3.0 if (acc is not None and K == 11) else 0.0)  # noqa: E731
+                f = lambda: ops.resblock_pair(pc1, pc2, x, y, slope=0.1, accum=acc, out_div=3.0 if (acc is not None and K == 11) else 0.0, variant=variant)  # noqa: E731
                 us = time_us(f)
                 fl = 2 * 2.0 * C * C * K * T * B
                 by = (2 + (acc is not None)) * 4.0 * B * C * T

@@ -118,6 +118,106 @@ def vits_small(impl, use_sdp=True):
     return {k: out[k] for k in keys}
 
 
+def trained_like_vits_state(args, seed):
+    """Stand-in for a released VITS checkpoint (unreachable offline): the seeded weights of make_vits_state re-scaled the way
+    training leaves them, so that the acoustic half sees what the random initialisation never produces:
+      * flow WaveNets: weight-norm gains of every gate conv (in_layers) spread over 1e-2 .. 1e1 per output row — pre-activations
+        from the linear region of tanh / sigmoid to +-10 and beyond (saturated gates); the skip rows of every res/skip conv carry a
+        per-channel factor 1e-2 .. 1e1 that `post`'s input columns undo (the coupling's function is unchanged, the skip
+        accumulator spans three decades per tile);
+      * LayerNorm gains of the text encoder and of every DDSConv spread over 1e-1 .. 10^0.5 per channel (sharp attention, wide-range
+        FFN / depth-separable activations), the text encoder's projection columns compensating its last norm;
+      * ConvFlow spline parameters: the width / height rows of every `proj` scaled by 1 .. 200 per row — bin widths and heights
+        collapse to the minimum (1e-3) next to dominant bins, so knots nearly coincide and inputs land next to bin edges;
+      * the waveform decoder re-scaled as trained_like_hifigan_state does (ResBlock gains 1e-2 .. 1e1 with the next conv's columns
+        compensating)."""
+    sd = W.make_vits_state(args, seed=seed)
+    gen = _g(seed + 7)
+    g0, v1 = "parametrizations.weight.original0", "parametrizations.weight.original1"
+    h = 192
+    spread = lambda n, lo, hi: 10.0 ** (torch.rand(n, generator=gen) * (hi - lo) + lo)  # noqa: E731
+    for i in range(4):
+        q = "flow.flows.%d." % i
+        s_skip = spread(h, -2.0, 1.0)
+        for l in range(4):
+            a = q + "enc.in_layers.%d." % l
+            s = spread(2 * h, -2.0, 1.0)
+            sd[a + g0] = sd[a + g0] * s.view(-1, 1, 1)
+            sd[a + "bias"] = sd[a + "bias"] * s
+            r = q + "enc.res_skip_layers.%d." % l
+            rows = sd[r + g0].shape[0]
+            f = torch.ones(rows)
+            f[rows - h:] = s_skip                                   # skip rows: the second half (all rows of the last layer)
+            sd[r + g0] = sd[r + g0] * f.view(-1, 1, 1)
+            sd[r + "bias"] = sd[r + "bias"] * f
+        sd[q + "post.weight"] = sd[q + "post.weight"] / s_skip.view(1, h, 1)
+    for k in list(sd):
+        if k.startswith("text_encoder.encoder.norm_layers_") and k.endswith(".gamma"):
+            sd[k] = sd[k] * spread(sd[k].numel(), -1.0, 0.5).view_as(sd[k])
+        if k.startswith("duration_predictor.") and ".norms_" in k and k.endswith(".gamma") and "post_" not in k:
+            sd[k] = sd[k] * spread(sd[k].numel(), -1.0, 0.5).view_as(sd[k])
+    last = "text_encoder.encoder.norm_layers_2.%d.gamma" % (5)
+    sd["text_encoder.proj.weight"] = sd["text_encoder.proj.weight"] / sd[last].abs().clamp_min(1e-3).view(1, -1, 1) * 0.1
+    if args.get("use_sdp", True):
+        for i in range(1, 5):
+            k = "duration_predictor.flows.%d.proj." % i
+            rows = sd[k + "weight"].shape[0]                         # 10 widths | 10 heights | 9 derivatives
+            f = torch.ones(rows)
+            f[:20] = spread(20, 0.0, 2.3)
+            sd[k + "weight"] = sd[k + "weight"] * f.view(-1, 1, 1)
+            sd[k + "bias"] = sd[k + "bias"] * f
+        # the last reverse flow (ElementwiseAffine) brings the spline's +-5 range back to durations of a few frames per token
+        sd["duration_predictor.flows.0.log_scale"] = sd["duration_predictor.flows.0.log_scale"] + 1.5
+        sd["duration_predictor.flows.0.translation"] = sd["duration_predictor.flows.0.translation"] - 2.0
+    # waveform decoder (conv_pre / conv_post carry no weight norm inside VITS, vits.py:704-718)
+    nk = 3
+    for blk in range(4 * nk):
+        for m in range(3):
+            a, b = "waveform_decoder.resblocks.%d.convs1.%d." % (blk, m), "waveform_decoder.resblocks.%d.convs2.%d." % (blk, m)
+            c = sd[a + g0].shape[0]
+            s = spread(c, -2.0, 1.0)
+            sd[a + g0] = sd[a + g0] * s.view(c, 1, 1)
+            sd[a + "bias"] = sd[a + "bias"] * s
+            v = sd[b + v1]
+            ratio = sd[b + g0] / v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)
+            v = v / s.view(1, c, 1)
+            sd[b + v1] = v
+            sd[b + g0] = ratio * v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)
+    return sd
+
+
+VITS_TRAINED_LIKE = dict(upsample_initial_channel_decoder=64)
+
+
+def vits_trained_like(impl, use_sdp=True):
+    """See trained_like_vits_state.  The GPU test (tests/test_vits_gpu.py) runs this fixture on the small-grid kernels a request of
+    this size takes by itself AND with the large-grid tiles forced (ttsamd_conv1d_set_small_grid(0)): the three-product / six-product /
+    fp32 GATE, RES_SKIP and COUPLE epilogues of the B = 32 step."""
+    args = dict(VITS_TRAINED_LIKE, use_sdp=use_sdp)
+    sd = trained_like_vits_state(args, 4321)
+    x = torch.randint(0, 100, (3, 37), generator=_g(0))
+    xl = torch.tensor([37, 30, 21])
+    if impl == "ref":
+        from oracle import ref_models as RM
+
+        out = RM.RefVits(sd, args).inference(x, xl, seed=7)
+    else:
+        torch.manual_seed(7)
+        out = O.vits_inference(sd, x, xl, args)
+    keys = ["logw", "durations", "z_p", "z", "model_outputs"]
+    res = {k: out[k] for k in keys}
+    # The collapsed spline bins make logw ill-conditioned where an input lands next to a knot (slopes of ~1e2 .. 1e3): the fp32
+    # reference itself is 4e-5 away from an fp64 evaluation there.  The fixture carries that fp64 witness (the oracle restatement —
+    # bitwise the reference modules in fp32, tests/test_oracle_pin.py — run in double on the same weights, noise and inputs), so
+    # that a GPU test can bound its error by the reference's own rounding error instead of by a fixed 1e-5.
+    torch.manual_seed(7)
+    noise_dp = torch.randn(3, 2, 37)
+    o64 = O.vits_inference({k: v.double() for k, v in sd.items()}, x, xl, args, noise_dp=noise_dp.double(), stop_after="prior",
+                           noise_z=torch.zeros(3, 192, 1, dtype=torch.float64))
+    res["logw_fp64"] = o64["logw"]
+    return res
+
+
 def vits_small_speaker(impl, mode):
     """Multi-speaker conditioning (vits.py:873-886,1116-1117): speaker-embedding table or external d-vectors feeding the
     duration predictor, every flow WN and the waveform decoder."""
@@ -252,6 +352,7 @@ CASES = {
     "hifigan_trained_like": hifigan_trained_like,
     "vits_small_sdp": lambda impl: vits_small(impl, True),
     "vits_small_dp": lambda impl: vits_small(impl, False),
+    "vits_trained_like": vits_trained_like,
     "vits_small_spk_emb": lambda impl: vits_small_speaker(impl, "emb"),
     "vits_small_spk_dvec": lambda impl: vits_small_speaker(impl, "dvec"),
     "vits_small_lang_sdp": lambda impl: vits_small_language(impl, True),

@@ -181,6 +181,10 @@ static int test_hifigan()
     int64_t lens[2] = {9, 4};
     REQUIRE(ttsamd_hifigan_forward(h, mel.data(), 2, 9, lens, wav.data(), 0, nullptr) == 0);
     REQUIRE(ttsamd_hifigan_forward(h, mel.data(), 1, 3, nullptr, wav.data(), 0, nullptr) == 0);
+    // MRF branch streams off (a host with several requests in flight): one set of ping-pong buffers, one stream
+    REQUIRE(ttsamd_hifigan_set_option(h, TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES, 0) == 0 && ttsamd_hifigan_set_option(h, 99, 0) < 0);
+    REQUIRE(ttsamd_hifigan_forward(h, mel.data(), 2, 9, lens, wav.data(), 0, nullptr) == 0);
+    REQUIRE(ttsamd_hifigan_set_option(h, TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES, 1) == 0);
     std::vector<float> mel2((size_t)3 * 80 * 17, 0.2f), wav2((size_t)3 * (17 + 10) * 256);
     REQUIRE(ttsamd_hifigan_forward(h, mel2.data(), 3, 17, nullptr, wav2.data(), 0, nullptr) == 0);
     REQUIRE(ttsamd_hifigan_forward(h, nullptr, 1, 3, nullptr, wav.data(), 0, nullptr) < 0 && ttsamd_hifigan_forward(h, mel.data(), 1, 0, nullptr, wav.data(), 0, nullptr) < 0);
@@ -315,11 +319,12 @@ static int test_vits(bool use_sdp)
     REQUIRE(ttsamd_vits_encode(h, x.data(), xl.data(), B, T, ndp.data(), nullptr, 0, ylh.data(), &td, 0, nullptr) < 0);
     REQUIRE(load_all(ttsamd_vits_load, h, sd) == 0 && ttsamd_vits_finalize(h) == 0 && ttsamd_vits_finalize(h) == 0);
     REQUIRE(ttsamd_vits_hop_length(h) == 256);
+    REQUIRE(ttsamd_vits_set_option(h, TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES, 0) == 0 && ttsamd_vits_set_option(h, TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES, 1) == 0);
     // decode before encode; NULL pointers; the SDP without its noise; a token outside the table (caught by the embed stand-in)
     ttsamd_vits_outputs o;
     memset(&o, 0, sizeof(o));
     std::vector<float> nz(1, 0.f);
-    REQUIRE(ttsamd_vits_decode(h, nz.data(), &o, nullptr) < 0);
+    REQUIRE(ttsamd_vits_decode(h, nz.data(), &o, 0, nullptr) < 0);
     REQUIRE(ttsamd_vits_encode(h, nullptr, xl.data(), B, T, ndp.data(), nullptr, 0, ylh.data(), &td, 0, nullptr) < 0);
     REQUIRE(ttsamd_vits_encode(h, x.data(), xl.data(), 0, T, ndp.data(), nullptr, 0, ylh.data(), &td, 0, nullptr) < 0);
     if (use_sdp) REQUIRE(ttsamd_vits_encode(h, x.data(), xl.data(), B, T, nullptr, nullptr, 0, ylh.data(), &td, 0, nullptr) < 0);
@@ -327,7 +332,7 @@ static int test_vits(bool use_sdp)
         std::vector<int64_t> xb = x;
         xb[3] = 50;
         REQUIRE(ttsamd_vits_encode(h, xb.data(), xl.data(), B, T, ndp.data(), nullptr, 0, ylh.data(), &td, 0, nullptr) < 0);
-        REQUIRE(ttsamd_vits_decode(h, nz.data(), &o, nullptr) < 0);     // a failed encode leaves no request behind
+        REQUIRE(ttsamd_vits_decode(h, nz.data(), &o, 0, nullptr) < 0);     // a failed encode leaves no request behind
     }
     // a whole request, every output wanted / only the waveform wanted; then a larger request (workspaces grow), then a smaller one
     for (int round = 0; round < 3; ++round) {
@@ -347,10 +352,10 @@ static int test_vits(bool use_sdp)
             o.alignments = attn.data(), o.durations = dur.data(), o.z = z.data(), o.z_p = zp.data(), o.m_p = mp.data(), o.logs_p = lp.data(), o.y_mask = ym.data();
             o.y_lengths = yl_dev.data(), o.logw = lw.data(), o.x_hidden = xh.data();
         }
-        REQUIRE(ttsamd_vits_decode(h, noise.data(), &o, nullptr) == 0);
+        REQUIRE(ttsamd_vits_decode(h, noise.data(), &o, 0, nullptr) == 0);
         if (round != 2) REQUIRE(yl_dev[0] == td && dur[0] > 0.f);
         o.wav = nullptr;
-        REQUIRE(ttsamd_vits_decode(h, noise.data(), &o, nullptr) < 0);
+        REQUIRE(ttsamd_vits_decode(h, noise.data(), &o, 0, nullptr) < 0);
         // injected durations, predictor skipped
         std::vector<float> din((size_t)b * t, 3.f);
         REQUIRE(ttsamd_vits_encode(h, xx.data(), ll.data(), b, t, nullptr, din.data(), 0, yl.data(), &td, 0, nullptr) == 0 && td == 3 * t);

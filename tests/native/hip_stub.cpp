@@ -58,6 +58,18 @@ hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t, hipGraphNode_t *, 
 hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
 hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned)
+{
+    *e = static_cast<hipEvent_t>(malloc(1));        // a real allocation: an event that is never destroyed shows up as a leak
+    return *e ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e)
+{
+    free(e);
+    return hipSuccess;
+}
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipGetDevice(int *dev)
 {

@@ -15,6 +15,8 @@ typedef struct ihipStream_t *hipStream_t;
 typedef struct ihipGraph *hipGraph_t;
 typedef struct hipGraphExec *hipGraphExec_t;
 typedef struct ihipGraphNode *hipGraphNode_t;
+typedef struct ihipEvent_t *hipEvent_t;
+#define hipEventDisableTiming 2
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
@@ -38,6 +40,10 @@ hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, hipGraphNode_t *
 hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
 hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphExecDestroy(hipGraphExec_t e);
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipGetLastError(void);
 hipError_t hipGetDevice(int *dev);
 hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);

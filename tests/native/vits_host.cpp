@@ -122,7 +122,7 @@ int main(int argc, char **argv)
         memset(&o0, 0, sizeof(o0));
         o0.wav = dwav;
         o0.durations = ddur_out;
-        CHECK(ttsamd_vits_decode(h, dnz, &o0, st) == 0);
+        CHECK(ttsamd_vits_decode(h, dnz, &o0, 0, st) == 0);
         CHECK(hipStreamSynchronize(st) == hipSuccess && hipMemcpy(got_dur.data(), ddur_out, got_dur.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
         own = memcmp(got_dur.data(), dur.data(), got_dur.size() * 4) == 0;
         (void)hipFree(ddur_out);
@@ -137,7 +137,7 @@ int main(int argc, char **argv)
         memset(&o1, 0, sizeof(o1));
         o1.wav = dwav;
         o1.logw = dlogw;
-        CHECK(ttsamd_vits_decode(h, dnz, &o1, st) == 0);
+        CHECK(ttsamd_vits_decode(h, dnz, &o1, 0, st) == 0);
     }
     std::vector<float> got(want.size());
     CHECK(hipStreamSynchronize(st) == hipSuccess && hipMemcpy(got.data(), dwav, got.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);

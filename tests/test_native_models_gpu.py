@@ -105,6 +105,55 @@ def test_native_vits_handle_equals_the_python_driven_path(gpu, variant):
     nat.close()
 
 
+@pytest.mark.parametrize("c0", [64, 256])
+def test_native_vits_single_request_replays_its_tail_as_a_graph(gpu, c0):
+    """A single request through the handle with use_graph: front end and tail (prior expansion, flows, waveform decoder at the
+    32-frame bucket, ragged-exact) replay as hipGraphs, outputs cut to the true extent — bitwise the Python host's graphed request
+    (tts_amd.Vits with `_front` / `_tail` captured, text bucket off), over several requests of different noise and two lengths that
+    share a bucket."""
+    args = dict(upsample_initial_channel_decoder=c0)
+    sd = _folded(W.make_vits_state(args, seed=17))
+    g = torch.Generator().manual_seed(9)
+    m = Vits({"model_args": args})
+    m.load_state_dict(sd)
+    m.to(gpu)
+    m.use_native, m.text_bucket = False, 1
+    nat = NativeVits(m, sd)
+    for T in (33, 33, 35, 33):
+        x = torch.randint(0, 100, (1, T), generator=g).to(gpu)
+        nd = torch.randn(1, 2, T, generator=g).to(gpu)
+        pre = m.inference(x, {"noise_dp": nd, "return_extras": True})
+        t_dec = pre["z"].shape[2]
+        nz = torch.randn(1, 192, t_dec, generator=g).to(gpu)
+        ref = m.inference(x, {"noise_dp": nd, "noise_z": nz, "return_extras": True})
+        td, _ = nat.encode(x, None, nd, use_graph=True)
+        assert td == t_dec
+        got = nat.decode(td, nz, extras=True, use_graph=True)
+        for k in ("model_outputs", "alignments", "durations", "z", "z_p", "m_p", "logs_p", "y_mask", "y_lengths", "x", "logw"):
+            assert got[k].shape == ref[k].shape, (k, got[k].shape, ref[k].shape)
+            assert torch.equal(got[k], ref[k]), (T, k, float((got[k].double() - ref[k].double()).abs().max()))
+    nat.close()
+    # the same through the product class: `Vits.inference` routed to the handle (inputs staged into per-stream buffers, token axis
+    # padded to the 16-token bucket, outputs cut in the handle's copy-out) against the Python host's graphed request, a batch too
+    m.text_bucket = 16
+    for B, T in ((1, 33), (1, 37), (1, 33), (3, 37), (3, 37)):
+        x = torch.randint(0, 100, (B, T), generator=g).to(gpu)
+        xl = torch.tensor([T, T - 5, T - 11][:B]).to(gpu)
+        nd = torch.randn(B, 2, T, generator=g).to(gpu)
+        m.use_native = False
+        pre = m.inference(x, {"x_lengths": xl, "noise_dp": nd, "return_extras": True})
+        nz = torch.randn(B, 192, pre["z"].shape[2], generator=g).to(gpu)
+        aux = {"x_lengths": xl, "noise_dp": nd, "noise_z": nz, "return_extras": True}
+        ref = m.inference(x, aux)
+        m.use_native, m.native_single_requests = True, True
+        got = m.inference(x, aux)
+        m.use_native = False
+        for k in ("model_outputs", "alignments", "durations", "z", "z_p", "m_p", "logs_p", "y_mask", "y_lengths", "x", "logw"):
+            assert got[k].shape == ref[k].shape, (B, T, k, got[k].shape, ref[k].shape)
+            assert torch.equal(got[k], ref[k]), (B, T, k, float((got[k].double() - ref[k].double()).abs().max()))
+    assert len(m._native) == 1
+
+
 @pytest.mark.parametrize("variant", ["default", "relwin", "not_mean_only"])
 def test_native_glowtts_handle_equals_the_python_driven_path(gpu, variant):
     torch.set_num_threads(8)

@@ -38,6 +38,24 @@ struct Model {
     hipStream_t cap_stream = nullptr;   // the sequence is RECORDED on this stream (the caller's may be the NULL stream, which cannot
                                         // capture) and replayed on the caller's
     int precision = 0;           // 0 = h2 (three fp16 products on large grids), 1 = x3 (six bf16 products), 2 = f32
+    // MRF branch streams: the resblocks of a stage are independent until their last conv, which chains the accumulate r1 + r2 + r3 in
+    // the reference's order (hifigan_generator.py:255-261): each branch runs on its own HIP stream so that one branch's launch tail /
+    // ramp overlaps another's compute, events order only the accumulating convs (tts_amd/hifigan.py: forward).  For a lone request;
+    // a host with several requests in flight (request lanes) turns it off (TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES).
+    bool concurrent = true;
+    hipStream_t side[TTSAMD_HIFIGAN_MAX_KERNELS] = {};
+    std::vector<hipEvent_t> events;       // one per (stage, use) of the current call, created on first need, reused by later calls
+    size_t events_used = 0;
+    int take_event(hipEvent_t *out)
+    {
+        if (events_used == events.size()) {
+            hipEvent_t e = nullptr;
+            TTSAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            events.push_back(e);
+        }
+        *out = events[events_used++];
+        return TTSAMD_OK;
+    }
 };
 
 int add_conv(Model &m, const std::string &name, int c_out, int c_in, int kernel, int dilation)
@@ -181,6 +199,7 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
     const ttsamd_hifigan_config &c = m.cfg;
     const int p = c.inference_padding, nk = c.num_kernels, nu = c.num_upsamples;
     void *s = reinterpret_cast<void *>(st);
+    m.events_used = 0;
     int T = T0 + 2 * p;
     // per-stage length masks of a ragged batch (one launch), then the replicate padding of every item's own frames
     std::vector<const float *> sm(nu + 1, nullptr);
@@ -299,30 +318,49 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                 RC(ttsamd_sum_div(o_next, cur[0], cur[1], nk > 2 ? cur[2] : nullptr, (float)nk, (int64_t)B * ch * T, s));
             }
         } else {
-            float *xa = ws.take((size_t)B * ch * T), *xb = ws.take((size_t)B * ch * T), *tmp = ws.take((size_t)B * ch * T);
+            const bool side = m.concurrent && nk > 1;
+            // (a branch on its own stream needs its own ping-pong buffers)
+            std::vector<float *> xa(nk), xb(nk), tmp(nk);
+            for (int j = 0; j < nk; ++j) {
+                if (j == 0 || side) xa[j] = ws.take((size_t)B * ch * T), xb[j] = ws.take((size_t)B * ch * T), tmp[j] = ws.take((size_t)B * ch * T);
+                else xa[j] = xa[0], xb[j] = xb[0], tmp[j] = tmp[0];
+            }
+            hipEvent_t ev_up = nullptr, prev_done = nullptr;
+            if (side && !ws.dry) {
+                for (int j = 0; j < nk; ++j)
+                    if (!m.side[j]) TTSAMD_HIP(hipStreamCreateWithFlags(&m.side[j], hipStreamNonBlocking));
+                RC(m.take_event(&ev_up));
+                TTSAMD_HIP(hipEventRecord(ev_up, st));
+            }
             for (int j = 0; j < nk && !ws.dry; ++j) {
                 const std::string rp = "resblocks." + std::to_string(i * nk + j) + ".";
                 const int nd = c.num_dilations[j];
                 const float *cur = up;
+                hipStream_t sj = side ? m.side[j] : st;
+                void *s = reinterpret_cast<void *>(sj);
+                if (side) TTSAMD_HIP(hipStreamWaitEvent(sj, ev_up, 0));
                 for (int d = 0; d < nd; ++d) {
                     const bool last = d == nd - 1;
-                    float *dst = last ? (j == nk - 1 ? o_next : zsum) : (cur == xa ? xb : xa);
+                    float *dst = last ? (j == nk - 1 ? o_next : zsum) : (cur == xa[j] ? xb[j] : xa[j]);
                     const float *accum = (last && j > 0) ? zsum : nullptr;
                     const float div = (last && j == nk - 1) ? (float)nk : 0.f;
+                    const bool join = last && side && prev_done;      // zsum holds the previous branches' sum
                     if (c.resblock_type == 1) {
                         CONV(c1, rp + "convs1." + std::to_string(d));
                         CONV(c2, rp + "convs2." + std::to_string(d));
                         if (fuse_pair(m, c1, c2)) {
+                            if (join) TTSAMD_HIP(hipStreamWaitEvent(sj, prev_done, 0));
                             ttsamd_resblock_args r;
                             fill_pair_args(m, r, c1, c2, cur, dst, accum, msk, ch, T, B, div);
                             RC(ttsamd_resblock_pair(&r, s));
                         } else {
-                            fill_conv_args(m, a, c1, cur, ch, T, tmp, ch, T, B);
+                            fill_conv_args(m, a, c1, cur, ch, T, tmp[j], ch, T, B);
                             a.in_act = TTSAMD_ACT_LRELU;
                             a.in_slope = kLreluSlope;
                             a.in_mask = msk;
                             RC(ttsamd_conv1d(&a, s));
-                            fill_conv_args(m, a, c2, tmp, ch, T, dst, ch, T, B);
+                            if (join) TTSAMD_HIP(hipStreamWaitEvent(sj, prev_done, 0));
+                            fill_conv_args(m, a, c2, tmp[j], ch, T, dst, ch, T, B);
                             a.in_act = TTSAMD_ACT_LRELU;
                             a.in_slope = kLreluSlope;
                             a.in_mask = msk;
@@ -337,6 +375,7 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                         }
                     } else {
                         CONV(cv, rp + "convs." + std::to_string(d));
+                        if (join) TTSAMD_HIP(hipStreamWaitEvent(sj, prev_done, 0));
                         fill_conv_args(m, a, cv, cur, ch, T, dst, ch, T, B);
                         a.in_act = TTSAMD_ACT_LRELU;
                         a.in_slope = kLreluSlope;
@@ -352,7 +391,12 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                     }
                     cur = dst;
                 }
+                if (side) {
+                    RC(m.take_event(&prev_done));
+                    TTSAMD_HIP(hipEventRecord(prev_done, sj));
+                }
             }
+            if (side && !ws.dry) TTSAMD_HIP(hipStreamWaitEvent(st, prev_done, 0));      // the last branch's final conv completes the chain
         }
         o = o_next;
     }
@@ -471,6 +515,25 @@ extern "C" int ttsamd_hifigan_finalize(void *handle)
     });
 }
 
+extern "C" int ttsamd_hifigan_set_option(void *handle, int option, int value)
+{
+    return abi_guard("hifigan_set_option", [&]() -> int {
+        TTSAMD_CHECK_ARG(handle, "hifigan_set_option: NULL handle");
+        Model &m = *as_model(handle);
+        switch (option) {
+            case TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES:
+                if (m.concurrent != (value != 0)) {
+                    TTSAMD_HIP(hipDeviceSynchronize());
+                    drop_graphs(m);                 // a captured sequence has its branch topology baked in
+                    m.concurrent = value != 0;
+                }
+                return TTSAMD_OK;
+        }
+        set_error("hifigan_set_option: unknown option %d", option);
+        return TTSAMD_ERR_INVALID;
+    });
+}
+
 extern "C" int64_t ttsamd_hifigan_output_samples(void *handle, int frames)
 {
     if (!handle || frames < 0) return -1;
@@ -572,6 +635,9 @@ extern "C" int ttsamd_hifigan_destroy(void *handle)
         (void)hipDeviceSynchronize();
         drop_graphs(*m);
         if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+        for (auto &sd : m->side)
+            if (sd) (void)hipStreamDestroy(sd);
+        for (auto e : m->events) (void)hipEventDestroy(e);
         delete m;
         return TTSAMD_OK;
     });

@@ -408,13 +408,17 @@ int resblock_pair_h2_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
     switch (a.c) {
         case 8:
         case 16: return resblock_pair_h2_launch_cfg<K, D, 16, 1, 4, 2>(a, st);
-        case 32: return resblock_pair_h2_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
+        case 32:
+            // variant 2: four n-tiles per wave (512 mid columns per block): half the weight-fragment traffic per MFMA (A/B only)
+            if (a.variant == 2) return resblock_pair_h2_launch_cfg<K, D, 32, 1, 4, 4>(a, st);
+            return resblock_pair_h2_launch_cfg<K, D, 32, 1, 4, 2>(a, st);
         case 64:
             // (one n-tile per wave — half the columns, three blocks per CU — measured 1.14-1.22x SLOWER at 64 and 32 channels)
             // the 4-wave / 128-column tile for every kernel size (two blocks per CU: one block's staging and epilogue phases run
             // under the other's MFMAs); on six products k = 11 preferred the 8-wave / 256-column tile (4 % halo work instead of
             // 8 %), on three it is 1.5-2 % slower (scripts/h2_variants_ab.py); variant 1 selects it for A/B
             if (a.variant == 1) return resblock_pair_h2_launch_cfg<K, D, 64, 2, 4, 2>(a, st);
+            if (a.variant == 2) return resblock_pair_h2_launch_cfg<K, D, 64, 2, 2, 4>(a, st);      // 256 mid columns, four n-tiles per wave (A/B only)
             return resblock_pair_h2_launch_cfg<K, D, 64, 2, 2, 2>(a, st);
         case 128:
             // 4 waves x 64 mid columns: two blocks per CU (one block's staging / epilogue phases run under the other's MFMAs) instead

@@ -26,6 +26,7 @@ constexpr int kRelWindow = 4;            // TextEncoder: rel_attn_window_size=4 
 constexpr int kSdpHidden = 192;          // StochasticDurationPredictor(hidden + lang, 192, 3, p, 4) (vits.py:684-692)
 constexpr int kSdpKernel = 3;
 constexpr int kSdpFlows = 4;
+constexpr int kGraphTailMaxFrames = 2048;    // B * padded frames up to which a single request's tail is captured (tts_amd/vits.py)
 constexpr int kDpHidden = 256;           // DurationPredictor(hidden + lang, 256, 3, p) (vits.py:694-702)
 
 struct DdsLayer {
@@ -71,6 +72,7 @@ struct Model {
     // request state (encode -> decode)
     DevBuf work;                           // encode-phase activations + the tensors decode reads
     DevBuf work2;                          // decode-phase activations
+    DevBuf work3;                          // static buffers of the captured single-request tail
     int64_t *host_len = nullptr;           // pinned mirror of y_lengths
     int host_len_cap = 0;
     struct Req {
@@ -81,7 +83,7 @@ struct Model {
         int32_t *cum = nullptr;
         int64_t *y_lengths = nullptr;
     } req;
-    GraphCache front_graphs;
+    GraphCache front_graphs, tail_graphs;
     ~Model()
     {
         if (decoder) (void)ttsamd_hifigan_destroy(decoder);
@@ -117,6 +119,7 @@ int finalize(Model &m)
     m.flows.clear();
     m.sdp_flows.clear();
     m.front_graphs.clear();
+    m.tail_graphs.clear();
     m.req.valid = false;
     RC(upload_named(m.tensors, kWho, "text_encoder.emb.weight", (int64_t)c.num_chars * H, m.emb));
     RC(build_transformer(m.tensors, kWho, "text_encoder.encoder.", H, c.hidden_channels_ffn_text_encoder, heads, c.num_layers_text_encoder, kte, kRelWindow,
@@ -377,6 +380,19 @@ extern "C" int ttsamd_vits_finalize(void *handle)
 
 extern "C" int64_t ttsamd_vits_hop_length(void *handle) { return handle ? as_model(handle)->hop : -1; }
 
+extern "C" int ttsamd_vits_set_option(void *handle, int option, int value)
+{
+    return abi_guard("vits_set_option", [&]() -> int {
+        TTSAMD_CHECK_ARG(handle && as_model(handle)->decoder, "vits_set_option: no model (ttsamd_vits_finalize first)");
+        Model &m = *as_model(handle);
+        if (option == TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES) {      // a captured tail has the branch topology baked in
+            TTSAMD_HIP(hipDeviceSynchronize());
+            m.tail_graphs.clear();
+        }
+        return ttsamd_hifigan_set_option(m.decoder, option, value);
+    });
+}
+
 extern "C" int ttsamd_vits_encode(void *handle, const int64_t *x, const int64_t *x_lengths, int batch, int t_text, const float *noise_dp,
                                   const float *durations_in, int run_duration_predictor, int64_t *y_lengths_host, int32_t *t_dec_out, int use_graph,
                                   void *stream)
@@ -396,6 +412,7 @@ extern "C" int ttsamd_vits_encode(void *handle, const int64_t *x, const int64_t 
         RC(front(m, dry, x, x_lengths, noise_dp, run_dp, st, false));
         if (dry.used > m.work.bytes) {
             m.front_graphs.clear();               // captured sequences hold pointers into the workspace
+            m.tail_graphs.clear();
             RC(grow(m.work, dry.used));
         }
         if (batch > m.host_len_cap) {
@@ -449,7 +466,70 @@ extern "C" int ttsamd_vits_encode(void *handle, const int64_t *x, const int64_t 
     });
 }
 
-extern "C" int ttsamd_vits_decode(void *handle, const float *noise_z, const ttsamd_vits_outputs *outp, void *stream)
+namespace {
+
+struct TailBufs {
+    float *z_p, *z, *m_p, *logs_p, *y_mask, *attn, *wav, *h, *acts, *skip;
+};
+
+// Everything after the output extent is known (vits.py:1149-1161; tts_amd/vits.py: _tail_eager) at `t` frames into `b`.  ragged: the
+// single-request form a graph is captured in — `t` is the 32-frame bucket of the request, the noise draw sits packed
+// [B, C, max(y_lengths)] at the head of `noise`, and the decoder runs ragged-exact (every conv treats the row as ending at its own
+// length), which reproduces the unpadded run.
+int tail(Model &m, const TailBufs &b, const float *noise, int t, bool ragged, void *stream)
+{
+    const ttsamd_vits_config &c = m.cfg;
+    const int B = m.req.B, T = m.req.T, H = c.hidden_channels, half = H / 2;
+    Ctx cx{c.decoder.precision, stream, B, T};
+    // m_p / logs_p gathered along the path, z_p = m_p + noise * exp(logs_p) * noise_scale (vits.py:1152-1155); a second copy of z_p
+    // is what the flows transform in place
+    RC(ttsamd_expand_prior_ex(b.z_p, b.z, b.m_p, b.logs_p, b.y_mask, m.req.stats, m.req.stats + (size_t)H * T, (int64_t)2 * H * T, noise, m.req.cum, m.req.x_mask,
+                              m.req.y_lengths, c.inference_noise_scale, 0, ragged ? 1 : 0, B, H, T, t, stream));
+    if (b.attn) RC(ttsamd_generate_path(b.attn, m.req.cum, m.req.x_mask, m.req.y_lengths, B, T, t, stream));
+    // ResidualCouplingBlocks.forward(reverse=True), networks.py:226-231, in place on z
+    ttsamd_conv1d_args a;
+    for (int i = c.num_flows - 1; i >= 0; --i) {
+        const Flow &F = *m.flows[i];
+        const int src = F.flipped ? half : 0, dst = F.flipped ? 0 : half;
+        fill_conv_args(cx.precision, a, F.pre, b.z + (size_t)src * t, H, t, b.h, H, t, B);
+        a.out_mask = b.y_mask;
+        RC(conv(cx, a));
+        RC(run_wn(cx, F.wn, b.h, b.acts, b.skip, b.y_mask, H, t));
+        // x1 = (x1 - post(h) * mask) * mask (mean_only: exp(-log_scale) == 1), in place on the other half
+        fill_conv_args(cx.precision, a, F.post, b.skip, H, t, b.z + (size_t)dst * t, H, t, B);
+        a.mode = TTSAMD_CONV_COUPLE;
+        fix_conv_mode(cx.precision, a, F.post);
+        a.res = b.z + (size_t)dst * t;
+        a.res_bstride = (int64_t)H * t;
+        a.res_rstride = t;
+        a.out_mask = b.y_mask;
+        RC(conv(cx, a));
+    }
+    // waveform decoder on z * y_mask (vits.py:1161): the mask rides in conv_pre's load (ragged: the decoder's own stage-0 length mask
+    // IS y_mask)
+    return ttsamd_hifigan_forward_ex(m.decoder, b.z, B, t, ragged ? m.req.y_lengths : nullptr, ragged ? nullptr : b.y_mask, b.wav, 0, stream);
+}
+
+void seg_box(ttsamd_copy_seg &g, void *dst, const void *src, int d0, int d1, int d2, int64_t s0, int64_t s1, int64_t t0, int64_t t1, int bytes)
+{
+    memset(&g, 0, sizeof(g));
+    g.src = src;
+    g.dst = dst;
+    g.d0 = d0;
+    g.d1 = d1;
+    g.d2 = d2;
+    g.s0 = s0;
+    g.s1 = s1;
+    g.s2 = 1;
+    g.t0 = t0;
+    g.t1 = t1;
+    g.t2 = 1;
+    g.elem_bytes = bytes;
+}
+
+}  // namespace
+
+extern "C" int ttsamd_vits_decode(void *handle, const float *noise_z, const ttsamd_vits_outputs *outp, int use_graph, void *stream)
 {
     return abi_guard("vits_decode", [&]() -> int {
         TTSAMD_CHECK_ARG(handle && noise_z && outp && outp->wav, "vits_decode: NULL argument (noise_z, out, out->wav)");
@@ -457,79 +537,89 @@ extern "C" int ttsamd_vits_decode(void *handle, const float *noise_z, const ttsa
         TTSAMD_CHECK_ARG(m.finalized && m.req.valid, "vits_decode: no request in flight (ttsamd_vits_encode first)");
         const ttsamd_vits_config &c = m.cfg;
         const ttsamd_vits_outputs &o = *outp;
-        const int B = m.req.B, T = m.req.T, td = m.req.t_dec, H = c.hidden_channels, half = H / 2;
+        const int B = m.req.B, T = m.req.T, td = m.req.t_dec, H = c.hidden_channels;
         hipStream_t st = as_stream(stream);
-        Ctx cx{c.decoder.precision, stream, B, T};
-        const size_t nt = (size_t)B * td;
-        // decode-phase workspace: outputs the caller did not ask for still have to exist
-        Bump ws;
-        ws.dry = true;
-        auto layout = [&](Bump &b, float *&z_p, float *&z, float *&m_p, float *&logs_p, float *&y_mask, float *&h, float *&acts, float *&skip) {
-            z_p = o.z_p ? o.z_p : b.take(nt * H);
-            z = o.z ? o.z : b.take(nt * H);
-            m_p = o.m_p ? o.m_p : b.take(nt * H);
-            logs_p = o.logs_p ? o.logs_p : b.take(nt * H);
-            y_mask = o.y_mask ? o.y_mask : b.take(nt);
-            h = b.take(nt * H);
-            acts = b.take(nt * H);
-            skip = b.take(nt * H);
-        };
-        float *z_p, *z, *m_p, *logs_p, *y_mask, *h, *acts, *skip;
-        layout(ws, z_p, z, m_p, logs_p, y_mask, h, acts, skip);
-        RC(grow(m.work2, ws.used));
-        ws = Bump();
-        ws.base = static_cast<unsigned char *>(m.work2.p);
-        ws.dry = false;
-        layout(ws, z_p, z, m_p, logs_p, y_mask, h, acts, skip);
-        // m_p / logs_p gathered along the path, z_p = m_p + noise * exp(logs_p) * noise_scale (vits.py:1152-1155); a second copy of z_p
-        // is what the flows transform in place
-        RC(ttsamd_expand_prior_ex(z_p, z, m_p, logs_p, y_mask, m.req.stats, m.req.stats + (size_t)H * T, (int64_t)2 * H * T, noise_z, m.req.cum, m.req.x_mask,
-                                  m.req.y_lengths, c.inference_noise_scale, 0, 0, B, H, T, td, stream));
-        if (o.alignments) RC(ttsamd_generate_path(o.alignments, m.req.cum, m.req.x_mask, m.req.y_lengths, B, T, td, stream));
-        // ResidualCouplingBlocks.forward(reverse=True), networks.py:226-231, in place on z
-        ttsamd_conv1d_args a;
-        for (int i = c.num_flows - 1; i >= 0; --i) {
-            const Flow &F = *m.flows[i];
-            const int src = F.flipped ? half : 0, dst = F.flipped ? 0 : half;
-            fill_conv_args(cx.precision, a, F.pre, z + (size_t)src * td, H, td, h, H, td, B);
-            a.out_mask = y_mask;
-            RC(conv(cx, a));
-            RC(run_wn(cx, F.wn, h, acts, skip, y_mask, H, td));
-            // x1 = (x1 - post(h) * mask) * mask (mean_only: exp(-log_scale) == 1), in place on the other half
-            fill_conv_args(cx.precision, a, F.post, skip, H, td, z + (size_t)dst * td, H, td, B);
-            a.mode = TTSAMD_CONV_COUPLE;
-            fix_conv_mode(cx.precision, a, F.post);
-            a.res = z + (size_t)dst * td;
-            a.res_bstride = (int64_t)H * td;
-            a.res_rstride = td;
-            a.out_mask = y_mask;
-            RC(conv(cx, a));
-        }
-        // waveform decoder on z * y_mask (vits.py:1161): the mask rides in conv_pre's load
-        RC(ttsamd_hifigan_forward_ex(m.decoder, z, B, td, nullptr, y_mask, o.wav, 0, stream));
-        // the remaining outputs: copies of request state (one launch)
-        ttsamd_copy_seg segs[4];
+        TTSAMD_CHECK_ARG((int64_t)B * H * std::max(T, td) < ((int64_t)1 << 31) && (int64_t)td * m.hop < ((int64_t)1 << 31), "vits_decode: tensors beyond 2^31 elements");
+        ttsamd_copy_seg segs[TTSAMD_COPY_MAX_SEGS];
         int ns = 0;
-        auto add = [&](void *dst, const void *src, int64_t count, int bytes) {
-            if (!dst || !src) return;
-            ttsamd_copy_seg &g = segs[ns++];
-            memset(&g, 0, sizeof(g));
-            g.src = src;
-            g.dst = dst;
-            g.d0 = 1;
-            g.d1 = 1;
-            g.d2 = (int32_t)count;
-            g.s2 = 1;
-            g.t2 = 1;
-            g.elem_bytes = bytes;
-        };
-        TTSAMD_CHECK_ARG((int64_t)B * H * T < ((int64_t)1 << 31), "vits_decode: text tensors beyond 2^31 elements");
-        add(o.durations, m.req.w_ceil, (int64_t)B * T, 4);
-        add(o.y_lengths, m.req.y_lengths, B, 8);
-        add(o.logw, m.req.logw, (int64_t)B * T, 4);
-        add(o.x_hidden, m.req.h, (int64_t)B * H * T, 4);
+        const int t_pad = (td + 31) / 32 * 32;
+        const bool replay = use_graph && B == 1 && (int64_t)B * t_pad <= kGraphTailMaxFrames;
+        const int To = o.t_text_out > 0 ? o.t_text_out : T;          // token extent of the token-indexed outputs
+        TTSAMD_CHECK_ARG(To <= T && (To == T || replay), "vits_decode: t_text_out %d (request ran at %d tokens) needs a replayed tail", o.t_text_out, T);
+        if (replay) {
+            // A single request is launch-bound end to end: the tail (~110 launches) replays as ONE hipGraph per 32-frame bucket over
+            // static buffers; the request's own launches are the noise copy in, the replay, and one copy out cut to the true extent
+            // (tts_amd/vits.py: the `_tail` graph).  Outputs equal the eager run at the true length as long as the padding does not
+            // move a launch across the small-grid threshold of ttsamd_conv1d_set_small_grid (fp32 summation order).
+            const size_t np = (size_t)B * t_pad;
+            float *noise_pad;
+            TailBufs b;
+            auto layout = [&](Bump &w) {
+                noise_pad = w.take(np * H);
+                b.z_p = w.take(np * H), b.z = w.take(np * H), b.m_p = w.take(np * H), b.logs_p = w.take(np * H), b.y_mask = w.take(np);
+                b.attn = w.take((size_t)B * T * t_pad), b.wav = w.take(np * m.hop), b.h = w.take(np * H), b.acts = w.take(np * H), b.skip = w.take(np * H);
+            };
+            Bump ws;
+            layout(ws);
+            if (ws.used > m.work3.bytes) {
+                m.tail_graphs.clear();            // captured sequences hold pointers into the workspace
+                RC(grow(m.work3, ws.used));
+            }
+            ws = Bump();
+            ws.base = static_cast<unsigned char *>(m.work3.p);
+            ws.dry = false;
+            layout(ws);
+            // the draw at the reference's shape [B, C, t_dec] lands packed at the head of the bucket's noise buffer (columns beyond are
+            // read as zero by the kernel: masked there anyway)
+            seg_box(segs[0], noise_pad, noise_z, 1, 1, (int)((size_t)B * H * td), 0, 0, 0, 0, 4);
+            RC(ttsamd_copy_strided(segs, 1, stream));
+            // (the graph reads the encode phase's tensors in place: same (B, T) -> same addresses in the encode workspace)
+            const std::vector<const void *> kp = {m.work.p, m.work3.p};
+            const std::vector<int64_t> ki = {B, T, t_pad};
+            if (GraphEntry *g = m.tail_graphs.find(kp, ki, st)) {
+                TTSAMD_HIP(hipGraphLaunch(g->exec, st));
+            } else {
+                RC(tail(m, b, noise_pad, t_pad, true, stream));
+                RC(m.tail_graphs.capture(kp, ki, st, [&](hipStream_t s2) { return tail(m, b, noise_pad, t_pad, true, reinterpret_cast<void *>(s2)); }));
+            }
+            // hand out copies cut to the true extent: ONE launch
+            const int64_t hop = m.hop;
+            seg_box(segs[ns++], o.wav, b.wav, 1, B, (int)(td * hop), 0, t_pad * hop, 0, td * hop, 4);
+            if (o.alignments) seg_box(segs[ns++], o.alignments, b.attn, B, To, td, (int64_t)T * t_pad, t_pad, (int64_t)To * td, td, 4);
+            const float *src4[4] = {b.z, b.z_p, b.m_p, b.logs_p};
+            float *dst4[4] = {o.z, o.z_p, o.m_p, o.logs_p};
+            for (int i = 0; i < 4; ++i)
+                if (dst4[i]) seg_box(segs[ns++], dst4[i], src4[i], B, H, td, (int64_t)H * t_pad, t_pad, (int64_t)H * td, td, 4);
+            if (o.y_mask) seg_box(segs[ns++], o.y_mask, b.y_mask, 1, B, td, 0, t_pad, 0, td, 4);
+        } else {
+            const size_t nt = (size_t)B * td;
+            // decode-phase workspace: outputs the caller did not ask for still have to exist
+            TailBufs b;
+            auto layout = [&](Bump &w) {
+                b.z_p = o.z_p ? o.z_p : w.take(nt * H);
+                b.z = o.z ? o.z : w.take(nt * H);
+                b.m_p = o.m_p ? o.m_p : w.take(nt * H);
+                b.logs_p = o.logs_p ? o.logs_p : w.take(nt * H);
+                b.y_mask = o.y_mask ? o.y_mask : w.take(nt);
+                b.h = w.take(nt * H), b.acts = w.take(nt * H), b.skip = w.take(nt * H);
+                b.attn = o.alignments;
+                b.wav = o.wav;
+            };
+            Bump ws;
+            layout(ws);
+            RC(grow(m.work2, ws.used));
+            ws = Bump();
+            ws.base = static_cast<unsigned char *>(m.work2.p);
+            ws.dry = false;
+            layout(ws);
+            RC(tail(m, b, noise_z, td, false, stream));
+        }
+        // the remaining outputs: copies of request state (same launch as the cut copies of a replayed tail)
+        if (o.durations) seg_box(segs[ns++], o.durations, m.req.w_ceil, 1, B, To, 0, T, 0, To, 4);
+        if (o.y_lengths) seg_box(segs[ns++], o.y_lengths, m.req.y_lengths, 1, 1, B, 0, 0, 0, 0, 8);
+        if (o.logw && m.req.logw) seg_box(segs[ns++], o.logw, m.req.logw, 1, B, To, 0, T, 0, To, 4);
+        if (o.x_hidden) seg_box(segs[ns++], o.x_hidden, m.req.h, 1, B * H, To, 0, T, 0, To, 4);
         if (ns) RC(ttsamd_copy_strided(segs, ns, stream));
-        (void)st;
         return TTSAMD_OK;
     });
 }

@@ -313,10 +313,23 @@ class GlowTTS:
         if self.encoder is not None and x.is_cuda and self._native_request(aux_input, x.shape[0]):
             a_in = aux_input or {}
             nat = self._native_for_stream()
-            t_dec, _ = nat.encode(x, a_in.get("x_lengths"), a_in.get("durations"), bool(a_in.get("ragged_exact")),
-                                  use_graph=bool(self.use_graphs) and not a_in.get("no_graph"))
+            dev = x.device
+            B, T = x.shape
+            xl = a_in.get("x_lengths")
+            graphing = bool(self.use_graphs) and not a_in.get("no_graph")
+            x = x.to(torch.int64)
+            if graphing:          # the captured front end reads ids / lengths at fixed addresses: staged per stream in one launch
+                sc = self._scratch.get(("native", B, T), lambda: dict(x=torch.zeros((B, T), dtype=torch.int64, device=dev),
+                                                                      xl=torch.empty((B,), dtype=torch.int64, device=dev)))
+                xl = torch.full((B,), T, dtype=torch.int64, device=dev) if xl is None else xl.to(dev, torch.int64)
+                ops.copy_into([sc["x"], sc["xl"]], [x.contiguous(), xl.contiguous()])
+                x, xl = sc["x"], sc["xl"]
+            t_dec, _ = nat.encode(x, xl, a_in.get("durations"), bool(a_in.get("ragged_exact")), use_graph=graphing)
             return nat.decode(t_dec, a_in.get("noise"))
         ctx = (aux_input or {}).get("_front_ctx") or self.request_front(x, aux_input)
+        if (ctx["B"], ctx["T0"]) != tuple(x.shape):
+            raise _lib.TtsAmdError("GlowTTS.inference: the front-end context handed in belongs to another request "
+                                   "([%d, %d] tokens, this one has %s)" % (ctx["B"], ctx["T0"], tuple(x.shape)))
         a = self.args
         B, T, T0, dev, t_dec, ragged = ctx["B"], ctx["T"], ctx["T0"], ctx["dev"], ctx["t_dec"], ctx["ragged"]
         o_mean, o_logs, logw, w_ceil, cum, y_lengths, x_mask, g = (ctx[k] for k in (

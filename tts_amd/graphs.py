@@ -171,7 +171,8 @@ class GraphCache:
             self.stats["eager"] += 1
             return self.fn(*inputs)
         self.entries[key] = seg
-        self.stable_ptrs[key] = frozenset(inputs[i].data_ptr() for i in stable)
+        # (the address of the input AND of its storage: a stable input may be a slice / view of a scratch buffer)
+        self.stable_ptrs[key] = frozenset(p for i in stable for p in (inputs[i].data_ptr(), inputs[i].untyped_storage().data_ptr()))
         # the shape has to earn its next capture again: after an LRU eviction (or a change of an in-place input's address) it is
         # captured on its `capture_after`-th fresh sighting, not on the very next one — a capture costs a collection, two warm-up
         # runs and a device synchronise, and diverse traffic would otherwise thrash on them
@@ -179,6 +180,32 @@ class GraphCache:
         self.stats["captures"] += 1
         self.last_static = True
         return seg(*inputs)
+
+
+class _WeakList:
+    """The GraphCaches a StreamScratch notifies, held weakly (`append`, `+=`, iteration over the live ones)."""
+
+    def __init__(self, items=()):
+        import weakref
+
+        self._ref = weakref.ref
+        self._items = [weakref.ref(i) for i in items]
+
+    def append(self, item):
+        self._items.append(self._ref(item))
+
+    def __iadd__(self, items):
+        for i in items:
+            self.append(i)
+        return self
+
+    def __iter__(self):
+        live = [(r, r()) for r in self._items]
+        self._items = [r for r, o in live if o is not None]
+        return iter([o for _, o in live if o is not None])
+
+    def __len__(self):
+        return len(list(iter(self)))
 
 
 class StreamScratch:
@@ -190,13 +217,13 @@ class StreamScratch:
         # sized above the graph caches that key on these buffers (2 x 16 + the sentence pipeline's 12): a live graph's scratch
         # set is not the first thing to go; `dependents`: GraphCaches told to drop their graphs over a set that is evicted
         self.max_entries = max_entries
-        self.dependents = list(dependents)
+        self.dependents = _WeakList(dependents)        # weak: a pipeline that is dropped must not stay referenced from the model
         self.sets = collections.OrderedDict()
 
     @staticmethod
     def _addresses(obj):
         if torch.is_tensor(obj):
-            return [obj.data_ptr()]
+            return [obj.data_ptr(), obj.untyped_storage().data_ptr()]
         if isinstance(obj, dict):
             obj = obj.values()
         if isinstance(obj, (str, bytes)):

@@ -29,7 +29,7 @@ class VitsOutputs(ctypes.Structure):
     """Mirror of `ttsamd_vits_outputs`."""
 
     _fields_ = [(n, ctypes.c_void_p) for n in ("wav", "alignments", "durations", "z", "z_p", "m_p", "logs_p", "y_mask", "y_lengths", "logw",
-                                               "x_hidden")]
+                                               "x_hidden")] + [("t_text_out", ctypes.c_int32)]
 
 
 class GlowConfig(ctypes.Structure):
@@ -130,6 +130,14 @@ class NativeVits(_Handle):
             raise
         self.hop = int(L.ttsamd_vits_hop_length(self._h))
 
+    def set_concurrent_branches(self, on):
+        """MRF branch streams of the waveform decoder on / off (TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES): on for a lone request, off
+        when the host keeps several requests in flight."""
+        on = bool(on)
+        if getattr(self, "_concurrent", True) != on:
+            _lib.check(_lib.lib().ttsamd_vits_set_option(self._h, 1, int(on)), "vits_set_option")
+            self._concurrent = on
+
     @torch.no_grad()
     def encode(self, x, x_lengths=None, noise_dp=None, durations=None, run_duration_predictor=False, use_graph=False):
         """First half of a request -> (t_dec, y_lengths as a list of ints).  The call returns when the frame counts are on the host."""
@@ -151,36 +159,48 @@ class NativeVits(_Handle):
         return int(t_dec.value), [int(v) for v in host]
 
     @torch.no_grad()
-    def decode(self, t_dec, noise_z=None, extras=False):
-        """Second half -> the dict `Vits.inference` returns (vits.py:1163-1173)."""
-        x, xl, noise_dp, d, B, T = self._req
+    def decode(self, t_dec, noise_z=None, extras=False, use_graph=False, t_text_out=None):
+        """Second half -> the dict `Vits.inference` returns (vits.py:1163-1173).  t_text_out: the caller's token count when the
+        request ran on a padded token axis (single requests with use_graph: the outputs are cut in the handle's copy-out)."""
+        x, xl, noise_dp, d, B, T_run = self._req
+        T = T_run if t_text_out is None else int(t_text_out)
         dev, H = x.device, self.hidden
         if noise_z is None:
             noise_z = torch.randn(B, H, t_dec, device=dev, dtype=torch.float32)      # randn_like(m_p), vits.py:1155
         noise_z = noise_z.to(dev, torch.float32).contiguous()
         assert tuple(noise_z.shape) == (B, H, t_dec), "noise_z must be [B, C, T_dec]"
-        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
-        out = {"model_outputs": new(B, 1, t_dec * self.hop), "alignments": new(B, T, t_dec), "durations": new(B, 1, T), "z": new(B, H, t_dec),
-               "z_p": new(B, H, t_dec), "m_p": new(B, H, t_dec), "logs_p": new(B, H, t_dec), "y_mask": new(B, 1, t_dec)}
+        # every fp32 output is a view of ONE allocation (a request is latency-bound: eight torch.empty calls are 20+ us of host time)
+        shapes = [("model_outputs", (B, 1, t_dec * self.hop)), ("alignments", (B, T, t_dec)), ("durations", (B, 1, T)), ("z", (B, H, t_dec)),
+                  ("z_p", (B, H, t_dec)), ("m_p", (B, H, t_dec)), ("logs_p", (B, H, t_dec)), ("y_mask", (B, 1, t_dec))]
+        if extras:
+            shapes.append(("x", (B, H, T)))
+            if self._ran_dp:
+                shapes.append(("logw", (B, 1, T)))
+        sizes = [(-(-(a * b * c) // 64)) * 64 for _, (a, b, c) in shapes]          # 256-byte aligned views
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        out, off = {}, 0
+        for (k, shp), n in zip(shapes, sizes):
+            out[k] = flat[off: off + shp[0] * shp[1] * shp[2]].view(shp)
+            off += n
         o = VitsOutputs()
+        o.t_text_out = 0 if T == T_run else T
         o.wav, o.alignments, o.durations = out["model_outputs"].data_ptr(), out["alignments"].data_ptr(), out["durations"].data_ptr()
         o.z, o.z_p, o.m_p, o.logs_p, o.y_mask = (out[k].data_ptr() for k in ("z", "z_p", "m_p", "logs_p", "y_mask"))
         if extras:
             out["y_lengths"] = torch.empty(B, dtype=torch.int64, device=dev)
-            out["x"] = new(B, H, T)
             o.y_lengths, o.x_hidden = out["y_lengths"].data_ptr(), out["x"].data_ptr()
-            out["logw"] = None
             if self._ran_dp:
-                out["logw"] = new(B, 1, T)
                 o.logw = out["logw"].data_ptr()
-        _lib.check(_lib.lib().ttsamd_vits_decode(self._h, _lib.P(noise_z), ctypes.byref(o), _lib.stream_ptr()), "vits_decode")
+            else:
+                out["logw"] = None
+        _lib.check(_lib.lib().ttsamd_vits_decode(self._h, _lib.P(noise_z), ctypes.byref(o), int(bool(use_graph)), _lib.stream_ptr()), "vits_decode")
         self._keep = (self._req, noise_z, out)
         return out
 
     def inference(self, x, x_lengths=None, noise_dp=None, noise_z=None, durations=None, run_duration_predictor=False, use_graph=False,
                   extras=False):
         t_dec, _ = self.encode(x, x_lengths, noise_dp, durations, run_duration_predictor, use_graph)
-        return self.decode(t_dec, noise_z, extras)
+        return self.decode(t_dec, noise_z, extras, use_graph)
 
 
 class NativeGlowTTS(_Handle):

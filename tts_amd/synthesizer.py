@@ -90,7 +90,19 @@ class SentencePipeline:
         self._cfg = None
         self.max_frames = 4096
         self.launches = None       # kernel launches of the last captured tail (reported by bench.py)
-        self.last_ctx = None       # request_front's context of a request that did not fit the fused path (handed to inference)
+        # request_front's context of a request that did not fit the fused path (handed to inference): per host thread — two threads
+        # serving through one Synthesizer must not pick up each other's front end
+        import threading
+
+        self._tls = threading.local()
+
+    @property
+    def last_ctx(self):
+        return getattr(self._tls, "ctx", None)
+
+    @last_ctx.setter
+    def last_ctx(self, ctx):
+        self._tls.ctx = ctx
 
     def supported(self):
         return isinstance(self.tts, GlowTTS) and self.tts.use_graphs and self.voc is not None

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import _lib, graphs, helpers, layers, ops
+from . import _lib, graphs, helpers, layers, ops, parallel
 from .hifigan import HifiganGenerator
 
 VITS_ARGS_DEFAULTS = dict(  # VitsArgs, vits.py:544-600
@@ -239,6 +239,47 @@ class Vits:
             nat = self._native[key] = native.NativeVits(self, self._native_sd)
         return nat
 
+    def _native_inference(self, x, x_lengths, durations, a_in, no_graph):
+        """A plain request behind the model-level C handle (ttsamd_vits_encode / _decode).  With graphs on, everything the captured
+        front end reads — ids, lengths, the duration predictor's noise — is staged into per-stream buffers at fixed addresses (the
+        handle keys its captures on them) in ONE launch, and the token axis is padded to the text bucket so that 16 lengths share a
+        capture (pad ids masked out by x_lengths own no frames: the valid positions see the unpadded run)."""
+        dev = x.device
+        B, T0 = x.shape
+        nat = self._native_for_stream()
+        cb = self.waveform_decoder.concurrent_branches
+        nat.set_concurrent_branches((parallel.active_lanes() <= 1) if cb == "auto" else bool(cb))
+        graphing = bool(self.use_graphs) and not no_graph
+        run_dp = durations is None or bool(a_in.get("run_duration_predictor"))
+        noise_dp = a_in.get("noise_dp") if (run_dp and self.args.use_sdp) else None
+        T = T0
+        if graphing:
+            if run_dp and self.text_bucket > 1 and T0 % self.text_bucket:
+                T = -(-T0 // self.text_bucket) * self.text_bucket
+            sc = self._scratch.get(("native", B, T), lambda: dict(
+                x=torch.zeros((B, T), dtype=torch.int64, device=dev), xl=torch.empty((B,), dtype=torch.int64, device=dev),
+                nd=torch.zeros((B, 2, T), dtype=torch.float32, device=dev)))
+            dst, src = [sc["x"][:, :T0], sc["xl"]], [x, x_lengths.to(dev, torch.int64)]
+            if run_dp and self.args.use_sdp:
+                # drawn at the reference's shape [B, 2, T0] (a fixed seed gives the same draw, bucketed or not)
+                if noise_dp is None and T == T0:
+                    torch.randn((B, 2, T0), device=dev, dtype=torch.float32, out=sc["nd"])
+                else:
+                    dst.append(sc["nd"][:, :, :T0])
+                    src.append(torch.randn(B, 2, T0, device=dev, dtype=torch.float32) if noise_dp is None else noise_dp.to(dev, torch.float32))
+                noise_dp = sc["nd"]
+            ops.copy_into(dst, src)
+            x, x_lengths = sc["x"], sc["xl"]
+        d = None
+        if durations is not None:
+            d = durations.to(dev, torch.float32).reshape(B, T0)
+            d = d if T == T0 else _pad_cols(d, T)
+        t_dec, _ = nat.encode(x, x_lengths, noise_dp, d, bool(a_in.get("run_duration_predictor")), use_graph=graphing)
+        extras = bool(a_in.get("return_extras"))
+        if T != T0 and B == 1 and graphing and t_dec <= 2048 - 31:      # (the handle's own bound on a replayed tail)
+            return nat.decode(t_dec, a_in.get("noise_z"), extras=extras, use_graph=True, t_text_out=T0)      # cut in the handle's copy-out
+        return self._cut_text(nat.decode(t_dec, a_in.get("noise_z"), extras=extras, use_graph=graphing), T0, T)
+
     def _native_request(self, aux_input, B):
         """Does this request run behind the handle?  (See `use_native`.)"""
         from . import native
@@ -408,11 +449,7 @@ class Vits:
         durations = aux_input.get("durations") if aux_input else None
         no_graph = bool((aux_input or {}).get("no_graph", False))
         if self._native_request(aux_input, B):
-            a_in = aux_input or {}
-            nat = self._native_for_stream()
-            t_dec, _ = nat.encode(x, x_lengths, a_in.get("noise_dp"), durations, bool(a_in.get("run_duration_predictor")),
-                                  use_graph=bool(self.use_graphs) and not no_graph)
-            return nat.decode(t_dec, a_in.get("noise_z"), extras=bool(a_in.get("return_extras")))
+            return self._native_inference(x, x_lengths, durations, aux_input or {}, no_graph)
         # Text-length buckets: real traffic brings a new token count with almost every request, and a captured front end is
         # keyed by its shape.  With graphs on, the token axis is padded to a multiple of 16 (pad ids masked out by x_mask —
         # exactly the situation of a shorter sentence inside a batch: masked convs / attention / flows give the valid
