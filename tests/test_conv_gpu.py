@@ -52,6 +52,32 @@ def test_conv1d_matches_torch(gpu, case):
     assert _rel(y, want) < TOL
 
 
+@pytest.mark.parametrize("case", [(1, 20, 32, 3, 1, 300), (2, 3, 32, 2, 1, 500), (1, 40, 64, 7, 3, 260), (1, 17, 128, 11, 1, 200)])
+def test_rows_and_chunks_beyond_c_in_read_as_zero_not_as_whatever_follows_the_tensor(gpu, case):
+    """The K loop walks 16-channel chunks and requests up to three chunks ahead: rows >= c_in (the rest of a partial chunk, chunks
+    past the end) must come back as ZEROS through the buffer range check — not as the bytes that follow the tensor in memory.
+    (Round 6: a staging variant that moved the row offset into the load's scalar operand, which the hardware adds to the address
+    but does not range-check, read them; with the weight image zero-padded the products vanish unless those bytes are NaN / Inf —
+    and the per-tile exponent follows their magnitude.)  Here the tensor sits at the head of an allocation whose tail is NaN and
+    1e30: the result must not notice."""
+    B, Cin, Cout, K, D, T = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / np.sqrt(Cin * K)
+    b = torch.randn(Cout, generator=g)
+    pad = (K - 1) * D // 2
+    want = F.conv1d(F.pad(F.leaky_relu(x, 0.1), (pad, (K - 1) * D - pad)), w, b, dilation=D)
+    n = B * Cin * T
+    big = torch.full((n + 80 * T + 4096,), float("nan"), device=gpu)
+    big[n + 7::2] = 1e30
+    xg = big[:n].view(B, Cin, T)
+    xg.copy_(x.to(gpu))
+    pc = ops.PackedConv(w, b, gpu, dilation=D)
+    y = torch.full((B, Cout, want.shape[2]), float("nan"), device=gpu)
+    ops.conv1d(pc, xg, y, in_act=ops.ACT_LRELU, in_slope=0.1, t_out=want.shape[2])
+    assert torch.isfinite(y).all() and _rel(y, want) < TOL
+
+
 def test_conv1d_epilogue_res_accum_mask_div(gpu):
     g = torch.Generator().manual_seed(1)
     B, C, T, K = 2, 64, 333, 7

@@ -175,13 +175,16 @@ def test_inference_slabbed_full_width_against_oracle(gpu):
         assert rms < 1e-4 and rel < 1e-5, (b, rms, rel)
 
 
-def test_single_item_inference_graph_equals_eager(gpu):
+@pytest.mark.parametrize("host", ["python", "handle"])
+def test_single_item_inference_graph_equals_eager(gpu, host):
     """`inference` on one item replays as a hipGraph per 32-frame length bucket (the item runs ragged-exact inside the padded
     tensor): same waveform as the eager launches at the true length — for several lengths sharing a bucket, across capture
-    (3rd call) and replay, and after a weight re-pack (captured graphs are dropped with the weights they point to)."""
+    and replay, and after a weight re-pack (captured graphs are dropped with the weights they point to).  "python": the Python
+    host's own graph cache; "handle": the default route through the vocoder handle (use_native), staged into its static buffers."""
     cfg = dict(W.HIFIGAN_V2)
     sd = W.make_hifigan_state(cfg, 80, seed=3)
     m = _make(cfg, 80, gpu, sd)
+    m.use_native = host == "handle"
     g = torch.Generator().manual_seed(4)
     for T in (41, 64, 50, 41, 41):
         c = torch.randn(1, 80, T, generator=g).to(gpu)
@@ -192,7 +195,10 @@ def test_single_item_inference_graph_equals_eager(gpu):
             got = m.inference(c)
             assert got.shape == want.shape == (1, 1, (T + 10) * 256)
             assert _errs(got, want)[1] < 2e-6
-    assert m._graph.stats["captures"] >= 1 and m._graph.stats["replays"] >= 6 and len(m._graph.entries) <= 2
+    if host == "python":
+        assert m._graph.stats["captures"] >= 1 and m._graph.stats["replays"] >= 6 and len(m._graph.entries) <= 2
+    else:
+        assert len(m._native) == 1 and m._graph.stats["captures"] == 0
     m.load_state_dict(W.make_hifigan_state(cfg, 80, seed=5))          # re-pack: graphs of the old weights must not replay
     c = torch.randn(1, 80, 41, generator=g).to(gpu)
     m.use_graphs = False

@@ -163,6 +163,25 @@ def test_fused_pair_h2_mask_accum_div_and_edges(gpu, case):
         assert _rel(y[i], ref[i]) < 1e-5, (i, _rel(y[i], ref[i]))
 
 
+@pytest.mark.parametrize("ck", [(8, 3), (16, 7), (8, 11)])
+def test_fused_pair_h2_rows_beyond_the_tensor_read_as_zero(gpu, ck):
+    """8- and 16-channel pairs run on a padded tile: the rows beyond the tensor's own channels must come back as zeros through the
+    buffer range check, not as the bytes that follow the tensor (here: NaN and 1e30) — see the conv test of the same name."""
+    C, K = ck
+    B, T = 1, 900
+    w, pc1, pc2, g = _pair(C, K, 3, C + K, gpu)
+    x = torch.randn(B, C, T, generator=g)
+    n = B * C * T
+    big = torch.full((n + 40 * T + 4096,), float("nan"), device=gpu)
+    big[n + 3::2] = 1e30
+    xg = big[:n].view(B, C, T)
+    xg.copy_(x.to(gpu))
+    with _H2():
+        y = torch.full((B, C, T), float("nan"), device=gpu)
+        ops.resblock_pair(pc1, pc2, xg, y, slope=SLOPE)
+    assert torch.isfinite(y).all() and _rel(y, _torch_ref(w, x, None, None, 0.0, K, 3)) < 1e-5
+
+
 @pytest.mark.parametrize("case", [(32, 11, 5, 3, 60000), (64, 3, 1, 2, 120000), (64, 7, 3, 5, 30011), (128, 3, 3, 4, 20000)])
 def test_fused_pair_h2_many_tiles_default_dispatch(gpu, case):
     """Large tensors take the three-product kernel by default (no variant): many more (item, tile) pairs than resident blocks,

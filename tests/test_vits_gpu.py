@@ -391,6 +391,7 @@ def test_vits_text_length_buckets_share_one_capture(gpu):
     args = dict(upsample_initial_channel_decoder=64)
     sd = W.make_vits_state(args, seed=14)
     m = _model(args, sd, gpu)
+    m.use_native = False         # this test reads the Python host's own graph cache (the handle's: tests/test_native_models_gpu.py)
     g = torch.Generator().manual_seed(10)
     for T in (29, 17, 32, 23, 29, 31):
         x = torch.randint(0, 100, (1, T), generator=g).to(gpu)
@@ -455,6 +456,7 @@ def test_vits_small_request_tail_graph_equals_eager(gpu):
     args = dict(upsample_initial_channel_decoder=64)
     sd = W.make_vits_state(args, seed=12)
     m = _model(args, sd, gpu)
+    m.use_native = False         # this test reads the Python host's own graph cache (the handle's: tests/test_native_models_gpu.py)
     g = torch.Generator().manual_seed(9)
     T = 29
     for rep in range(4):

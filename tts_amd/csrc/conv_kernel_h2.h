@@ -127,6 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (long)b * a.x_bstride, ((long)(a.c_in - 1) * a.x_rstride + a.t_in) * 4);
 
     constexpr int kFull = G::kFull, kRem = G::kRem, kSingles = G::kSingles, kSets = G::kSets;
+    constexpr int kInvalid = (int)0x80000000u;      // byte offset of a lane outside the tensor: + any row / chunk offset (< 2^31, conv_h2_offsets_ok) stays out of range
     int soff[kFull > 0 ? kFull : 1], soff1[kSingles > 0 ? kSingles : 1], lds1[kSingles > 0 ? kSingles : 1];
     float smask[kFull > 0 ? kFull : 1], smask1[kSingles > 0 ? kSingles : 1];
     {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
             const int col = e - half * G::kXW;
             const int gt = t0 - a.pad_left + col;
             const bool ok = (gt >= 0) && (gt < a.t_in);
-            soff[i] = ok ? (int)(((long)(half * 8) * a.x_rstride + gt) * 4) : kOob;
+            soff[i] = ok ? (int)(((long)(half * 8) * a.x_rstride + gt) * 4) : kInvalid;
             smask[i] = has_m ? ld_buf(rm, ok ? gt * 4 : kOob, 0) : 1.f;
         }
 #pragma unroll
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
             const int col = e - half * G::kXW;
             const int gt = t0 - a.pad_left + col;
             const bool ok = valid && (gt >= 0) && (gt < a.t_in);
-            soff1[q] = ok ? (int)(((long)(half * 8 + ch) * a.x_rstride + gt) * 4) : kOob;
+            soff1[q] = ok ? (int)(((long)(half * 8 + ch) * a.x_rstride + gt) * 4) : kInvalid;
             smask1[q] = has_m ? ld_buf(rm, ok ? gt * 4 : kOob, 0) : 1.f;
             lds1[q] = valid ? half * (G::kXWp * 16) + col * 16 + ch * 2 : G::kXW * 16 + (tid & 7) * 2;    // idle lanes: the dump column
         }
@@ -166,10 +167,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         const int cb = chunk * kConvCK * row_bytes;
         if (i < kFull) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) st8[set][i][c] = ld_buf(rx, soff[i] == kOob ? kOob : soff[i] + cb + c * row_bytes, 0);
+            // (2^31 + row offset stays beyond the range check and below 2^32 (conv_h2_offsets_ok): one add per load, no select; the
+            // row offset must be part of the VECTOR offset: a raw buffer load's scalar offset is not range-checked, and chunks beyond
+            // c_in rely on the check to read zeros)
+            for (int c = 0; c < 8; ++c) st8[set][i][c] = ld_buf(rx, (int)((unsigned)soff[i] + (unsigned)(cb + c * row_bytes)), 0);
         } else {
 #pragma unroll
-            for (int q = 0; q < kSingles; ++q) st1[set][q] = ld_buf(rx, soff1[q] == kOob ? kOob : soff1[q] + cb, 0);
+            for (int q = 0; q < kSingles; ++q) st1[set][q] = ld_buf(rx, (int)((unsigned)soff1[q] + (unsigned)cb), 0);
         }
     };
     // mask + activation in place, and this wave's largest magnitude of the chunk -> its slot
@@ -267,12 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         for (int i = 0; i < G::kNStage; ++i) stage_load_step(Set1{}, i, 1);
     }
     bool folded = conv_acc_init<MODE, MI, NI, WM, WN>(accm, a, b, mb, t0, wm, wn, h, j);    // raw residual (or zeros)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accx[mi][ni][r] = 0.f;
+    // (accx is an output of the main loop: its first product takes a zero C operand — an inline constant — instead of 16 NI MI v_mov)
     stage_act_max(Set0{}, 0);
     __syncthreads();
     int e_run = h2_exp_for(chunk_max(0));
@@ -311,7 +310,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
     const int bbyte = h * (G::kXWp * 16) + (wn * (32 * NI) + j) * 16;
     // iteration c: chunk c + 1 (registers `s1`, maximum known since the last barrier) is converted into the other LDS buffer and its
     // registers re-requested for chunk c + 1 + kSets; chunk c's MFMAs; chunk c + 2 (registers `s2`) gets mask / activation / maximum
-    auto iteration = [&](int c, auto s1, auto s2) {
+    constexpr f32x16 kZero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto iteration = [&](auto first, int c, auto s1, auto s2) {
         const unsigned char *cur = xh2 + (c & 1) * G::kBufBytes + bbyte;
         unsigned char *const nxt = xh2 + ((c + 1) & 1) * G::kBufBytes;
         // exponent of chunk c + 1 (its maximum is in the slots since the last barrier)
@@ -348,7 +348,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
                 for (int q = 0; q < 2; ++q) bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * 16);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][1]), __builtin_bit_cast(f16x8, bq[0]), accx[mi][ni], 0, 0, 0);
+                    const bool zero = decltype(first)::value && tap == 0;
+                    accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][1]), __builtin_bit_cast(f16x8, bq[0]), zero ? kZero : accx[mi][ni], 0, 0, 0);
                     accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[1]), accx[mi][ni], 0, 0, 0);
                     accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[0]), accm[mi][ni], 0, 0, 0);
                 }
@@ -374,14 +375,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         }
         __syncthreads();
     };
+    iteration(std::true_type{}, 0, Set1{}, Set0{});           // (one set: Set1 == Set0)
     if constexpr (kSets == 2) {
-        for (int c = 0; c < nchunks; c += 2) {
-            iteration(c, Set1{}, Set0{});
+        for (int c = 1; c < nchunks; c += 2) {
+            iteration(std::false_type{}, c, Set0{}, Set1{});
             if (c + 1 >= nchunks) break;
-            iteration(c + 1, Set0{}, Set1{});
+            iteration(std::false_type{}, c + 1, Set1{}, Set0{});
         }
     } else {
-        for (int c = 0; c < nchunks; ++c) iteration(c, Set0{}, Set0{});
+        for (int c = 1; c < nchunks; ++c) iteration(std::false_type{}, c, Set0{}, Set0{});
     }
 
     // the two accumulators meet and leave the scaled units (activation exponent, then the row's), then the shared epilogue
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
             for (int r = 0; r < 16; ++r) {
                 const float ru = row_tab[2 * (row0 + (r & 3) + 8 * (r >> 2)) + 1];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) accm[mi][ni][r] = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * us) * ru;
+                for (int ni = 0; ni < NI; ++ni) accm[mi][ni][r] = (__builtin_fmaf(accx[mi][ni][r], 1.f / 2048.f, accm[mi][ni][r]) * us) * ru;   // (x 2^-11 exact: same bits)
             }
         }
     }

@@ -34,6 +34,11 @@
 #define TTSAMD_X3_CFG64 1, 4, 2, 2
 #endif
 namespace ttsamd {
+
+// The three-product kernel adds row / chunk offsets to a lane's byte offset without a select (an invalid lane starts from 2^31, chunks
+// up to three beyond c_in are requested ahead and must read zeros through the range check): the sums must stay below 2^32, i.e. the
+// per-item slab plus 64 rows below 2 GiB.  Larger slabs (never seen: a per-item [C, T] tensor of ~2 GiB) take the six-product kernel.
+inline bool conv_h2_offsets_ok(const ttsamd_conv1d_args &a) { return ((long)(a.c_in + 64) * a.x_rstride + a.t_in) * 4 < 0x7FFFFFF0L; }
 extern long g_conv_small_grid_blocks;       // conv.hip (default 128): up to this many 128x128-class blocks a launch takes the small-grid tiles
 #define kConvSmallGridBlocks g_conv_small_grid_blocks
 constexpr long kConvWaveTileBlocks = 1024;  // up to this many 32x32 tiles those kernels run a wave per tile and K slice
@@ -449,7 +454,7 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
             // Mid-size grids (one utterance's 256-channel decoder stage: 98 of the 128x128-class blocks): too few blocks for the
             // large-grid tile, long enough reductions that the K-split small-grid tiles pay six products per output — the
             // three-product kernel on 128-row x 64-column blocks (twice the blocks, half the serial chain of the 128x128 tile)
-            if (a.w_h2 && g_conv_small_grid && mtiles % 4 == 0 && blocks_default >= g_conv_h2_mid_min && blocks_default <= kConvSmallGridBlocks)
+            if (a.w_h2 && conv_h2_offsets_ok(a) && g_conv_small_grid && mtiles % 4 == 0 && blocks_default >= g_conv_h2_mid_min && blocks_default <= kConvSmallGridBlocks)
                 return conv1d_h2_launch_mid<K, D, MODE>(a, st);
         }
         if (g_conv_small_grid && blocks_default <= kConvSmallGridBlocks) {
@@ -485,7 +490,7 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     // the 256-channel layers stage their tile once instead of twice) 77.5 -> 77.9; the conflict-free planar LDS image
     // (TTSAMD_X3_PLANAR) +-0 on the 128/256-row layers (SQ_LDS_BANK_CONFLICT 0, but LDS was not the limiter).
     // large grids with the two-part fp16 image present: three products per fp32 product instead of six (conv_kernel_h2.h)
-    if (a.w_h2) return conv1d_h2_launch_tiles<K, D, MODE>(a, st);
+    if (a.w_h2 && conv_h2_offsets_ok(a)) return conv1d_h2_launch_tiles<K, D, MODE>(a, st);
     if (mtiles % 4 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
     // same bench, same box: <2,2,1,4> 90.6 ms/step, <1,4,2,2> 89.7; (<1,8,4,1> on the 128-row blocks: 93.4)
     if (mtiles % 2 == 0) return conv1d_x3_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);

@@ -45,45 +45,55 @@ struct ResGeomH2 : ResGeom<K, D, C, WM, WN, NI> {
     static_assert(WM * WN == 4 || WM * WN == 8, "the maximum slots are read four at a time");
 };
 
-// acc{m,x}[mi][ni] += sum over (chunk, tap) of the three products; weight fragments requested two taps ahead (a_cur: this tap,
-// a_n1: the next), as in res_conv_mainloop
+// acc{m,x}[mi][ni] = sum over (chunk, tap) of the three products; weight fragments requested two taps ahead (a_cur: this tap,
+// a_n1: the next), as in res_conv_mainloop.  The accumulators are OUTPUTS: the first products of chunk 0 / tap 0 take a zero C
+// operand (an inline constant of the MFMA) instead of 64 v_mov of zero-initialisation per conv — on this chip a VALU instruction
+// costs the SIMD the issue slots of an eighth of an MFMA (matrix-pipe busy + 4 cycles per other VALU instruction add up
+// to the kernel's cycles).
+template <bool FIRST, int KK, int DD, int MI, int NI, int NCH, int PLANE>
+__device__ __forceinline__ void res_conv_chunk_h2(f32x16 (&accm)[MI][NI], f32x16 (&accx)[MI][NI], const u32x4 *const (&wp)[MI], u32x4 (&a_cur)[MI][2],
+                                                  u32x4 (&a_n1)[MI][2], const unsigned char *cb, int c)
+{
+    u32x4 a_n2[MI][2];
+    constexpr f32x16 kZero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+        const long g = ((long)c * KK + tap + 2) * (2 * 64);   // the packed image ends with two groups of slack
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a_n2[mi][q] = wp[mi][g + q * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            u32x4 bq[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bq[q] = *reinterpret_cast<const u32x4 *>(cb + q * (NCH * 2 * PLANE) + (ni * 32 + tap * DD) * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const bool zero = FIRST && tap == 0;
+                accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][1]), __builtin_bit_cast(f16x8, bq[0]), zero ? kZero : accx[mi][ni], 0, 0, 0);
+                accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[1]), accx[mi][ni], 0, 0, 0);
+                accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[0]), zero ? kZero : accm[mi][ni], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a_cur[mi][q] = a_n1[mi][q];
+                a_n1[mi][q] = a_n2[mi][q];
+            }
+    }
+}
+
 template <int KK, int DD, int MI, int NI, int NCH, int PLANE>
 __device__ __forceinline__ void res_conv_mainloop_h2(f32x16 (&accm)[MI][NI], f32x16 (&accx)[MI][NI], const u32x4 *const (&wp)[MI],
                                                      u32x4 (&a_cur)[MI][2], u32x4 (&a_n1)[MI][2], const unsigned char *bbase)
 {
-    u32x4 a_n2[MI][2];
+    res_conv_chunk_h2<true, KK, DD, MI, NI, NCH, PLANE>(accm, accx, wp, a_cur, a_n1, bbase, 0);
 #pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        const unsigned char *cb = bbase + c * (2 * PLANE);
-#pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-            const long g = ((long)c * KK + tap + 2) * (2 * 64);   // the packed image ends with two groups of slack
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) a_n2[mi][q] = wp[mi][g + q * 64];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                u32x4 bq[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) bq[q] = *reinterpret_cast<const u32x4 *>(cb + q * (NCH * 2 * PLANE) + (ni * 32 + tap * DD) * 16);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][1]), __builtin_bit_cast(f16x8, bq[0]), accx[mi][ni], 0, 0, 0);
-                    accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[1]), accx[mi][ni], 0, 0, 0);
-                    accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_cur[mi][0]), __builtin_bit_cast(f16x8, bq[0]), accm[mi][ni], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    a_cur[mi][q] = a_n1[mi][q];
-                    a_n1[mi][q] = a_n2[mi][q];
-                }
-        }
-    }
+    for (int c = 1; c < NCH; ++c) res_conv_chunk_h2<false, KK, DD, MI, NI, NCH, PLANE>(accm, accx, wp, a_cur, a_n1, bbase + c * (2 * PLANE), c);
 }
 
 template <int K, int D, int C, int WM, int WN, int NI>
@@ -149,8 +159,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
             const bool ok = (e < G::kItems) && (gt >= 0) && (gt < T);
             const int off = ok ? (pl * 8 * row_bytes + gt * 4) : kOob;
             float sm;
+            // an invalid lane's kOob + i * row_bytes stays beyond the range check (a slab is < 2 GiB: no wrap below 2^32): one add per
+            // load, no select.  (The row offset must stay in the VECTOR offset: the scalar offset of a raw buffer load is added to the
+            // address but not range-checked — rows beyond a 8- / 16-channel tensor would read whatever follows it.)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off == kOob ? kOob : off + i * row_bytes, 0);
+            for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, (int)((unsigned)off + (unsigned)(i * row_bytes)), 0);
             if (has_mask) {                         // block-uniform: an unmasked call pays no multiply per value
                 sm = ld_buf(rmask, ok ? gt * 4 : kOob, 0);
 #pragma unroll
@@ -238,16 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
     auto table_row4 = [&](int which, int mi, int rg) -> f32x4 {
         return *reinterpret_cast<const f32x4 *>(tabs + which * CC + (wm * MI + mi) * 32 + 4 * h + 8 * rg);
     };
-    f32x16 accm[MI][NI], accx[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                accm[mi][ni][r] = 0.f;
-                accx[mi][ni][r] = 0.f;
-            }
+    f32x16 accm[MI][NI], accx[MI][NI];          // outputs of the main loops (their first products start from a zero C operand)
     __syncthreads();
     res_conv_mainloop_h2<K, D, MI, NI, NCH, G::kPlaneX>(accm, accx, wp1, a_cur, a_n1, rh2 + h * G::kPlaneX + (wn * (32 * NI) + j) * 16);
 
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 4 * rg + i;
-                        float v = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usx) * ru[i];
+                        float v = (__builtin_fmaf(accx[mi][ni][r], 1.f / 2048.f, accm[mi][ni][r]) * usx) * ru[i];     // (x 2^-11 is exact: same bits as mul, add)
                         v = conv_lrelu((v + bia[i]) * mk[ni], a.slope);
                         accm[mi][ni][r] = v;
                         m = __builtin_fmaxf(m, __builtin_fabsf(v));
@@ -318,15 +322,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
     }
 
     // ---- conv2 ----------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                accm[mi][ni][r] = 0.f;
-                accx[mi][ni][r] = 0.f;
-            }
     if constexpr (G::kResEarly) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -368,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 4 * rg + i;
-                        vout[r] = ((accm[mi][ni][r] + accx[mi][ni][r] * (1.f / 2048.f)) * usm) * ru[i] + bia[i];
+                        vout[r] = (__builtin_fmaf(accx[mi][ni][r], 1.f / 2048.f, accm[mi][ni][r]) * usm) * ru[i] + bia[i];
                     }
                 }
 #pragma unroll

@@ -97,6 +97,14 @@ class NativeHifigan:
     def output_samples(self, frames):
         return int(_lib.lib().ttsamd_hifigan_output_samples(self._h, int(frames)))
 
+    def set_concurrent_branches(self, on):
+        """MRF branch streams on / off (TTSAMD_HIFIGAN_OPT_CONCURRENT_BRANCHES): on for a lone request, off when the host keeps
+        several requests in flight."""
+        on = bool(on)
+        if getattr(self, "_concurrent", True) != on:
+            _lib.check(_lib.lib().ttsamd_hifigan_set_option(self._h, 1, int(on)), "hifigan_set_option")
+            self._concurrent = on
+
     @torch.no_grad()
     def forward(self, mel, lengths=None, use_graph=False, out=None):
         """mel [B, C, T] fp32 on the GPU (+ lengths [B] int64 on the GPU for ragged-exact batching) -> wav [B, 1, samples]."""
@@ -177,6 +185,13 @@ class HifiganGenerator:
         # hipGraph per 32-frame length bucket (the item runs ragged-exact inside the padded tensor: same samples).
         self.use_graphs = True
         self.graph_max_frames = 2048
+        # A single item through `inference` runs behind the model-level C handle (ttsamd_hifigan_*, csrc/hifigan_model.hip): weights
+        # folded HERE handed over once, then per request one staging copy, ONE C call (the handle replays its hipGraph of the
+        # 32-frame bucket, ragged-exact) and one clone — measured 320 vs 361 us per sentence against this class's own graph replay
+        # (profiles/r05_native_vocoder_ab.txt).  Speaker-conditioned generators and batches stay on the Python host below.
+        # TTSAMD_NATIVE_MODELS=0 / use_native = False: Python host everywhere.
+        self.use_native = os.environ.get("TTSAMD_NATIVE_MODELS", "1") != "0"
+        self._native = {}                      # stream handle -> (NativeHifigan, {t_pad: (mel, lengths, wav) static buffers})
         self._graph = graphs.GraphCache(self._inference_ragged, max_entries=12)
         self.weights_version = 0    # bumped by every re-pack: dependants (SentencePipeline) key their graphs on it
 
@@ -260,7 +275,46 @@ class HifiganGenerator:
         P["conv_post"] = PackedConv(ops.fold_weight_norm(sd, "conv_post"), sd.get("conv_post.bias"), dev)
         self._graph.clear()          # captured graphs hold raw pointers to the previous weight tensors
         self.weights_version += 1
+        self._drop_native()
         self._packed = P
+
+    def _drop_native(self):
+        for nat, _ in self._native.values():
+            nat.close()
+        self._native = {}
+
+    def _native_single(self, c):
+        """One item [1, C, T] behind the vocoder handle: staged into the 32-frame bucket's static buffers, replayed, cloned."""
+        key = torch.cuda.current_stream().cuda_stream
+        ent = self._native.get(key)
+        if ent is None:
+            sd = {}
+            for k, v in self._sd.items():
+                if k.endswith(".parametrizations.weight.original0") or k.endswith(".weight_g"):
+                    name = k[: -len(".parametrizations.weight.original0")] if k.endswith("original0") else k[: -len(".weight_g")]
+                    sd[name + ".weight"] = ops.fold_weight_norm(self._sd, name)
+                elif not (k.endswith(".parametrizations.weight.original1") or k.endswith(".weight_v")):
+                    sd[k] = v
+            if len(self._native) >= 4:
+                self._native.pop(next(iter(self._native)))[0].close()
+            ent = self._native[key] = (NativeHifigan(self, sd), {})
+        nat, bufs = ent
+        T = c.shape[2]
+        t_pad = -(-T // 32) * 32
+        b = bufs.get(t_pad)
+        if b is None:
+            if len(bufs) >= 12:
+                bufs.pop(next(iter(bufs)))
+            b = bufs[t_pad] = (torch.zeros((1, c.shape[1], t_pad), dtype=torch.float32, device=c.device),
+                               torch.empty((1,), dtype=torch.int64, device=c.device),
+                               torch.empty((1, self.out_channels, nat.output_samples(t_pad)), dtype=torch.float32, device=c.device))
+        mel, lens, wav = b
+        ops.copy_into([mel[:, :, :T]], [c])            # (frames beyond T keep an earlier request's values: masked out by `lengths`)
+        lens.fill_(T)
+        nat.set_concurrent_branches((parallel.active_lanes() <= 1) if self.concurrent_branches == "auto" else bool(self.concurrent_branches))
+        nat.forward(mel, lens, use_graph=True, out=wav)
+        hop = wav.shape[-1] // (t_pad + 2 * self.inference_padding)
+        return wav[:, :, : (T + 2 * self.inference_padding) * hop].clone()      # the handle's buffer is static: hand out a copy
 
     def _group_stage(self, i, ch, B, T, P):
         """Can stage i's MRF run as grouped launches (ops.resblock_group)?  All branches ResBlock1 with the same dilation list,
@@ -484,6 +538,8 @@ class HifiganGenerator:
         (lengths[b] + 2*pad)*hop samples equal `inference(c[b:b+1, :, :lengths[b]])`."""
         c = c.to(self.device).contiguous().float()
         if (self.use_graphs and self.exact_hop and lengths is None and c.shape[0] == 1 and 0 < c.shape[2] <= self.graph_max_frames):
+            if self.use_native and not (self.cond_channels > 0 or self.cond_in_each_up_layer) and self._sd is not None:
+                return self._native_single(c)
             T = c.shape[2]
             t_pad = -(-T // 32) * 32
             cp = torch.zeros((1, c.shape[1], t_pad), dtype=torch.float32, device=c.device)

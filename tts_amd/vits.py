@@ -121,10 +121,12 @@ class Vits:
         # csrc/vits_model.hip; tts_amd/native.py): the whole launch sequence, the duration sync and the front end's graph replay are
         # C++ — this class then only marshals pointers and draws the two noise tensors.  The handle gets the weights THIS class
         # folded, so it is bitwise the Python-driven path below, which stays for what the handle's envelope leaves out (speaker /
-        # language conditioning, ragged-exact batches, latent interpolation) and for single requests, whose captured tail
-        # (`_tail`) the handle does not have.  TTSAMD_NATIVE_MODELS=0 / use_native = False: Python-driven everywhere.
+        # language conditioning, ragged-exact batches, latent interpolation).  Single requests replay front end and tail as
+        # hipGraphs inside the handle (same-box A/B against this class's own `_front` / `_tail` graphs: 3.32-3.36 vs 3.23-3.35 ms,
+        # profiles/r06_native_ab.txt); TTSAMD_NATIVE_SINGLE=0 keeps them on the Python host.  TTSAMD_NATIVE_MODELS=0 /
+        # use_native = False: Python-driven everywhere.
         self.use_native = os.environ.get("TTSAMD_NATIVE_MODELS", "1") != "0"
-        self.native_single_requests = os.environ.get("TTSAMD_NATIVE_SINGLE", "0") != "0"
+        self.native_single_requests = os.environ.get("TTSAMD_NATIVE_SINGLE", "1") != "0"
         self._native = {}                      # stream handle -> NativeVits (a handle holds ONE request's state)
         self._native_sd = None
 
@@ -290,7 +292,7 @@ class Vits:
         if any(a.get(k) is not None for k in ("speaker_ids", "d_vectors", "language_ids")) or a.get("ragged_exact"):
             return False
         if B == 1 and self.use_graphs and not a.get("no_graph") and not self.native_single_requests:
-            return False          # a single request: the captured tail of the Python host (measured: profiles/r06_native_ab.txt)
+            return False          # (opt-out) single requests on the Python host's own captured front + tail
         return True
 
     def _front_eager(self, x, x_mask, noise_dp, g_dp, lang):
