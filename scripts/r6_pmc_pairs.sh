@@ -34,3 +34,4 @@ for k, d in agg.items():
         a.get("SQ_WAVES", 0), a.get("SQ_LDS_BANK_CONFLICT", 0) / max(a.get("SQ_LDS_IDX_ACTIVE", 1), 1)))
 
 PY
+rm -f $OUT/*.csv $OUT/*.log

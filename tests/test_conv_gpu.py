@@ -56,10 +56,11 @@ def test_conv1d_matches_torch(gpu, case):
 def test_rows_and_chunks_beyond_c_in_read_as_zero_not_as_whatever_follows_the_tensor(gpu, case):
     """The K loop walks 16-channel chunks and requests up to three chunks ahead: rows >= c_in (the rest of a partial chunk, chunks
     past the end) must come back as ZEROS through the buffer range check — not as the bytes that follow the tensor in memory.
-    (Round 6: a staging variant that moved the row offset into the load's scalar operand, which the hardware adds to the address
-    but does not range-check, read them; with the weight image zero-padded the products vanish unless those bytes are NaN / Inf —
-    and the per-tile exponent follows their magnitude.)  Here the tensor sits at the head of an allocation whose tail is NaN and
-    1e30: the result must not notice."""
+    (Round 6 moved the row / chunk offsets of the staging loads into the load's scalar operand; the range check of a raw buffer
+    access on gfx950 covers voffset + soffset — scripts/ubench/soffset_range.hip — and this test holds the kernels to it.  With the
+    weight image zero-padded a stray read would vanish from the products unless the bytes are NaN / Inf — and the per-tile exponent
+    would follow their magnitude.)  Here the tensor sits at the head of an allocation whose tail is NaN and 1e30: the result must
+    not notice."""
     B, Cin, Cout, K, D, T = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, T, generator=g)

@@ -338,6 +338,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
             (MODE == TTSAMD_CONV_RES_SKIP) ? ((long)(c_out - split - 1) * y2_rs + t_out) * 4 : 0);
         const int y2_rs4 = (MODE == TTSAMD_CONV_RES_SKIP) ? (int)y2_rs * 4 : 0;
         const bool has_accum = accum0 != nullptr;
+        const bool all_rows = (c_out & 31) == 0;
         // polyphase ConvTranspose with a stride that is a multiple of 4 (HiFiGAN ups[0], ups[1]: 8): 16-byte stores.  Groups
         // start at sample indices that are multiples of 4, so with shuffle_t_out % 4 == 0 no group straddles the row end
         // (a C-ABI caller's odd output length takes the dword path below instead of losing its last partial group)
@@ -350,20 +351,17 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
             const int row0 = ((mb * WM + wm) * MI + mi) * 32;
             const bool lower = (MODE == TTSAMD_CONV_RES_SKIP) && (row0 < split);   // res rows vs skip rows
             float radd[NR];   // bias (+ per-item row bias) of this lane's 16 rows of the m-tile
+            // through buffer resources: rows >= c_out (and an absent operand: zero-length resource) read as 0 by the range check —
+            // no 64-bit address arithmetic, no clamp per row (round 6: 64 VALU instructions per m-tile, on a chip where every
+            // VALU instruction costs the matrix pipe an eighth of an MFMA's issue time)
+            {
+                const __amdgpu_buffer_rsrc_t rbi = make_rsrc(bias, bias ? (long)c_out * 4 : 0);
+                const __amdgpu_buffer_rsrc_t rrb = make_rsrc(rbias, rbias ? (long)c_out * 4 : 0);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) radd[r] = 0.f;
-            if (bias) {
+                for (int r = 0; r < NR; ++r) radd[r] = ld_buf(rbi, 16 * h, (row0 + conv_erow<NR>(r, rq)) * 4);
+                if (rbias) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int row = row0 + conv_erow<NR>(r, rq) + 4 * h;
-                    radd[r] = bias[row < c_out ? row : 0];
-                }
-            }
-            if (rbias) {
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int row = row0 + conv_erow<NR>(r, rq) + 4 * h;
-                    radd[r] += rbias[row < c_out ? row : 0];
+                    for (int r = 0; r < NR; ++r) radd[r] += ld_buf(rrb, 16 * h, (row0 + conv_erow<NR>(r, rq)) * 4);
                 }
             }
 #pragma unroll
@@ -413,10 +411,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                     // residual, accumulate, mask, division: each behind ONE wave-uniform branch around its whole pass (inside
                     // the element loop hipcc evaluates the IEEE division sequence — 12 VALU instructions — for every element of
                     // every launch and selects afterwards).  Same operations in the same order as before.
+                    if (need_res) {                                                    // (absent / folded: no pass of + 0)
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) acc[mi][ni][r] += e1[r];              // 0 when absent / folded
+                        for (int r = 0; r < NR; ++r) acc[mi][ni][r] += e1[r];
+                    }
+                    if (need_acc) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) acc[mi][ni][r] = e2[r] + acc[mi][ni][r];
+                        for (int r = 0; r < NR; ++r) acc[mi][ni][r] = e2[r] + acc[mi][ni][r];
+                    }
                     if (omask) {
 #pragma unroll
                         for (int r = 0; r < NR; ++r) acc[mi][ni][r] *= om;
@@ -488,7 +490,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MI][NI], int b, int 
                             st_buf(ry2, v, rok ? voy2 : kOob, (rb - split) * y2_rs4);
                         }
                     } else {
-                        st_buf(ry, v, rok ? voy : kOob, rb * y_rs4);      // NORMAL: finished above
+                        // NORMAL: finished above.  c_out a multiple of 32 (wave-uniform): every row of the tile exists, no compare +
+                        // select per store
+                        st_buf(ry, v, (all_rows || rok) ? voy : kOob, rb * y_rs4);
                     }
                 }
             }

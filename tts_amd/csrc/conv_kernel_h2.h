@@ -167,13 +167,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
         const int cb = chunk * kConvCK * row_bytes;
         if (i < kFull) {
 #pragma unroll
-            // (2^31 + row offset stays beyond the range check and below 2^32 (conv_h2_offsets_ok): one add per load, no select; the
-            // row offset must be part of the VECTOR offset: a raw buffer load's scalar offset is not range-checked, and chunks beyond
-            // c_in rely on the check to read zeros)
-            for (int c = 0; c < 8; ++c) st8[set][i][c] = ld_buf(rx, (int)((unsigned)soff[i] + (unsigned)(cb + c * row_bytes)), 0);
+            // the chunk / row offset rides in the load's SCALAR offset (no VALU instruction per load): the range check of a raw buffer
+            // access on gfx950 covers voffset + soffset (measured: scripts/ubench/soffset_range.hip), so chunks beyond c_in read zeros,
+            // and an invalid lane's 2^31 + offset stays out of range and below 2^32 (conv_h2_offsets_ok)
+            for (int c = 0; c < 8; ++c) st8[set][i][c] = ld_buf(rx, soff[i], cb + c * row_bytes);
         } else {
 #pragma unroll
-            for (int q = 0; q < kSingles; ++q) st1[set][q] = ld_buf(rx, (int)((unsigned)soff1[q] + (unsigned)cb), 0);
+            for (int q = 0; q < kSingles; ++q) st1[set][q] = ld_buf(rx, soff1[q], cb);
         }
     };
     // mask + activation in place, and this wave's largest magnitude of the chunk -> its slot

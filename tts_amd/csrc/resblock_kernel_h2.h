@@ -159,11 +159,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
             const bool ok = (e < G::kItems) && (gt >= 0) && (gt < T);
             const int off = ok ? (pl * 8 * row_bytes + gt * 4) : kOob;
             float sm;
-            // an invalid lane's kOob + i * row_bytes stays beyond the range check (a slab is < 2 GiB: no wrap below 2^32): one add per
-            // load, no select.  (The row offset must stay in the VECTOR offset: the scalar offset of a raw buffer load is added to the
-            // address but not range-checked — rows beyond a 8- / 16-channel tensor would read whatever follows it.)
+            // the row offset rides in the load's SCALAR offset: no VALU instruction per load.  The hardware range check of a raw buffer
+            // access on gfx950 covers voffset + soffset (measured: scripts/ubench/soffset_range.hip), so rows beyond an 8- / 16-channel
+            // tensor read as zeros and an invalid lane's kOob + i * row_bytes stays out of range (a slab is < 2 GiB: no wrap below 2^32)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, (int)((unsigned)off + (unsigned)(i * row_bytes)), 0);
+            for (int i = 0; i < 8; ++i) st[rr][i] = ld_buf(rx, off, i * row_bytes);
             if (has_mask) {                         // block-uniform: an unmasked call pays no multiply per value
                 sm = ld_buf(rmask, ok ? gt * 4 : kOob, 0);
 #pragma unroll
