@@ -3,8 +3,8 @@ rocprofv3 --pmc passes of scripts/gpu_round6.sh over `bench.py --serial-branches
     python scripts/pmc_table_full.py <pass1.csv> <pass2.csv> ...
 Columns: launches, HBM traffic (FETCH_SIZE KiB x 1024 x 2 — the gfx950 correction of MI355X_MICROARCH.md — + WRITE_SIZE KiB x 1024),
 kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs), matrix-pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles), instruction mix per MFMA
-(SQ_INSTS_VALU excluding MFMA, SQ_INSTS_LDS, SQ_INSTS_VMEM_RD), the issue-slot model 32 / (32 + 4 (valu + lds + vmem)) next to the
-measured busy fraction, LDS bank-conflict cycles / LDS-array cycles, share of wave cycles parked (SQ_WAIT_ANY) / issue-stalled
+(SQ_INSTS_VALU excluding MFMA, SQ_INSTS_LDS, SQ_INSTS_VMEM_RD), the issue-slot model 32 / (36 + 4 (valu + lds + vmem)) — an MFMA holds the matrix pipe 32 cycles and its own issue takes a
+quad-cycle like every other instruction's — next to the measured busy fraction, LDS bank-conflict cycles / LDS-array cycles, share of wave cycles parked (SQ_WAIT_ANY) / issue-stalled
 (SQ_WAIT_INST_ANY) / issuing (SQ_ACTIVE_INST_ANY)."""
 import collections
 import csv
@@ -31,7 +31,7 @@ for _, k, n, a, cyc in rows:
     valu = (a["SQ_INSTS_VALU"] - mf) / mf if (mf and "SQ_INSTS_VALU" in a) else None
     lds = a["SQ_INSTS_LDS"] / mf if (mf and "SQ_INSTS_LDS" in a) else None
     vm = a["SQ_INSTS_VMEM_RD"] / mf if (mf and "SQ_INSTS_VMEM_RD" in a) else None
-    model = 32.0 / (32.0 + 4.0 * (valu + lds + vm)) if None not in (valu, lds, vm) else None
+    model = 32.0 / (36.0 + 4.0 * (valu + lds + vm)) if None not in (valu, lds, vm) else None
     print("%-52s %5d %9s %9s %10s %6s %7s %6s %6s %6s %7s %6s %6s %6s" % (
         k[:52], n, f(a["FETCH_SIZE"] * 2048 / 1e6, "%.1f") if "FETCH_SIZE" in a else "-", f(a["WRITE_SIZE"] * 1024 / 1e6, "%.1f") if "WRITE_SIZE" in a else "-",
         f(cyc, "%.4g") if cyc else "-", f(a["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc) if (cyc and "SQ_VALU_MFMA_BUSY_CYCLES" in a and mf) else "-",

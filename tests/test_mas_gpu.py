@@ -119,10 +119,14 @@ def test_maximum_path_beyond_2048_rows(gpu, shape):
     assert np.array_equal(dv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_any_tx_kernel_on_the_small_cases(gpu, mode):
-    """The any-T_x kernel forced onto the ordinary shapes (TTSAMD_MAS_FORCE_BIG=1: column state in LDS, =2: in the
-    workspace, the T_x > 16 384 arrangement) in a fresh process: same bit-exact cases, ties, ragged items, the in-place mirror."""
+@pytest.mark.parametrize("env", [{"TTSAMD_MAS_FORCE_BIG": "1"}, {"TTSAMD_MAS_FORCE_BIG": "2"}, {"TTSAMD_MAS_MW": "1"},
+                                 {"TTSAMD_MAS_SINGLE_WAVE": "1"}],
+                         ids=["any_tx_lds", "any_tx_workspace", "mw_round3_column_step", "one_dp_wave"])
+def test_any_tx_kernel_on_the_small_cases(gpu, env):
+    """The kernels the default dispatch does not pick for these shapes, forced onto them in a fresh process: the any-T_x kernel
+    (TTSAMD_MAS_FORCE_BIG=1: column state in LDS, =2: in the workspace, the T_x > 16 384 arrangement), the round-3 column
+    step of the skewed pipeline (TTSAMD_MAS_MW=1; the default since round 6 is the branch-free step), the one-DP-wave kernel.
+    Same bit-exact cases, ties, ragged items, the in-place mirror."""
     import os
     import subprocess
     import sys
@@ -153,5 +157,5 @@ for shape in [(4, 17, 40), (3, 64, 64), (2, 65, 200), (5, 1, 9), (2, 7, 7), (1, 
 print("any-T_x kernel OK")
 ''' % root
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280,
-                       env=dict(os.environ, TTSAMD_MAS_FORCE_BIG=mode), cwd=root)
+                       env=dict(os.environ, **env), cwd=root)
     assert p.returncode == 0 and "any-T_x kernel OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

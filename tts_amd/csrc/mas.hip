@@ -332,6 +332,146 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw_kernel(
     }
 }
 
+#undef MAS_RING_LD
+#undef MAS_RING_ST
+
+// Round 6: the same skewed pipeline with a branch-free column step.  What the ISA of the kernel above spends per column and DP
+// wave besides the five instructions of the recurrence: the bit-plane word stored by lane 0 (save exec / branch / two moves /
+// store / restore), the ring slot published by lane 63 (the same dance + address arithmetic), `lane == 0 ? carry : up`,
+// ballot lowered through v_cndmask + v_cmp_ne, a wave-uniform branch around the in-place write, register rotation at the
+// loop's back edge: ~50 instructions, five branches.  Here:
+//   * the carry from the row group below is the `old` operand of the DPP wave shift (lane 0 has no source lane and keeps it);
+//     the first row group passes max_neg_val there (row 0's missing neighbour);
+//   * a column's direction word goes into lane (y mod 32) of a register pair with two v_writelane and is stored once per
+//     32-column tile by one coalesced store;
+//   * every lane publishes {value, column} each column: lane 63 into the ring, the others into a per-wave dump strip — one
+//     unconditional ds_write_b64, no exec games;
+//   * band membership is ONE unsigned compare of d = y - x against t_y - t_x; NEED_COPY is a template parameter.
+// Same fp32 add per cell on the same operands => bit-exact (tests/test_mas_gpu.py runs every case through both kernels).
+constexpr int kMasDump = 128;
+
+template <bool NEED_COPY>
+__global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw2_kernel(
+    const float *in_values, const float *__restrict__ mask, float *dp_values, unsigned long long *__restrict__ dirs,
+    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R, float neg)
+{
+    constexpr int YT = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int XP = 64 * R + 1;
+    float *buf0 = smem;
+    float *buf1 = smem + YT * XP;
+    unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + 2 * YT * XP);       // [R][kMasRing] {value, column}
+    unsigned long long *dump = ring + R * kMasRing;                                              // [R][kMasDump]
+    auto ring_ld = [](const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto ring_st = [](unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    const int t_x = min(t_xs[b], Tx);
+    const int t_y = min(t_ys[b], Ty);
+    const long base = (long)b * Tx * Ty;
+    const int nt = (Ty + YT - 1) / YT;
+    const int nt_work = NEED_COPY ? nt : ((t_x > 0 && t_y > 0) ? (min(t_y, Ty) + YT - 1) / YT : 0);
+    const bool dp_wave = wave < R;
+    const int mover = wave - R;
+    const int nmov = kMasMwWaves - R;
+
+    for (int i = threadIdx.x; i < R * kMasRing; i += blockDim.x) ring_st(ring + i, ~0ull);      // tag -1: nothing published
+    for (int i = threadIdx.x; i < 2 * YT * XP; i += blockDim.x) {   // padding rows x >= Tx (no mover writes them) read as 0
+        const int xx = i % XP;
+        if (xx >= Tx) smem[i] = 0.f;
+    }
+    if (!dp_wave && nt_work > 0)
+        mas_stage_tile<YT, 16>(buf0, in_values, mask, base, Tx, Ty, XP, 0, mover, lane, nmov);
+    __syncthreads();
+
+    const int r = wave;
+    const int x = r * 64 + lane;
+    float prev = 0.f;      // this row's value in the previous column
+    const int band = t_y - t_x;
+    const unsigned band_u = band >= 0 ? (unsigned)band : 0u;
+    const unsigned xe = (x < t_x && band >= 0) ? (unsigned)x : 0x3fffffffu;                      // rows outside never enter the band
+    // where this lane publishes: lane 63 of a wave with a consumer into the ring, every other lane into the wave's dump strip
+    unsigned long long *pub = (r + 1 < R && lane == 63) ? ring + r * kMasRing : dump + (dp_wave ? r : 0) * kMasDump + lane;
+    const unsigned long long *sub = ring + (r > 0 ? r - 1 : 0) * kMasRing;                       // the row group below publishes here
+    auto vmax = [](float a_, float b_) {
+        float o;
+        asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a_), "v"(b_));
+        return o;
+    };
+    auto dp_tile = [&](auto first_tag, float *cur, int t) {
+        constexpr bool kFirst = decltype(first_tag)::value;
+        const int y0 = t * YT;
+        int y = y0;
+        const int y_end = min(t_y, min(Ty, (t + 1) * YT));
+        if (y >= y_end) return;
+        float *cp = cur + x;                                    // this lane's row in the tile, one column = XP floats
+        float cnext = cp[0];
+        int acc_lo = 0, acc_hi = 0;                             // lane j: direction word of column y0 - 1 + j
+        if (t == 0) {                                           // column 0: value[x,0] = value (x = 0: max(neg, 0) + value)
+            prev = cnext;
+            cnext = cp[XP];
+            ring_st(pub, (unsigned long long)__builtin_bit_cast(unsigned, prev));
+            cp += XP;
+            y = 1;
+        }
+        if (y < y_end) {
+            unsigned long long wq = ~0ull;                      // ring slot of column y - 1 (requested a column ahead)
+            if (!kFirst) wq = ring_ld(sub + ((y - 1) & (kMasRing - 1)));
+#pragma unroll 2
+            for (; y < y_end; ++y, cp += XP) {
+                const float c = cnext;
+                cnext = cp[XP];
+                // x-1 neighbour of the previous column: DPP wave shift inside the group; lane 0 keeps `old` = the carry
+                int old = __builtin_bit_cast(int, neg);
+                if constexpr (!kFirst) {
+                    while (__builtin_amdgcn_readfirstlane((int)(wq >> 32)) != y - 1) wq = ring_ld(sub + ((y - 1) & (kMasRing - 1)));
+                    old = (int)(unsigned)(wq & 0xffffffffull);
+                    wq = ring_ld(sub + (y & (kMasRing - 1)));                         // the slot the NEXT column needs
+                }
+                const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, prev), 0x138, 0xf, 0xf, false));
+                // direction word of column y-1: value[x,y-1] < value[x-1,y-1] (row 0 has no upper neighbour)
+                unsigned long long bits = __builtin_amdgcn_ballot_w64(prev < up);
+                if constexpr (kFirst) bits &= ~1ull;
+                // (no writelane builtin in this clang; two scalar sources of one VOP3 = the lane select goes through m0)
+                asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                             : "+v"(acc_lo), "+v"(acc_hi)
+                             : "s"((int)(unsigned)(bits & 0xffffffffull)), "s"(y - y0), "s"((int)(unsigned)(bits >> 32))
+                             : "m0");
+                const unsigned d = (unsigned)y - xe;
+                const float v_cur = (d == 0u) ? neg : prev;                          // x == y
+                const float nv = vmax(v_cur, up) + c;
+                prev = (d <= band_u) ? nv : c;
+                if constexpr (NEED_COPY) cp[0] = prev;
+                ring_st(pub + (y & (kMasRing - 1)), ((unsigned long long)(unsigned)y << 32) | __builtin_bit_cast(unsigned, prev));
+            }
+        }
+        const int j0 = (t == 0) ? 1 : 0;
+        if (lane >= j0 && lane < y_end - y0)
+            dirs[((long)b * Ty + (y0 - 1 + lane)) * R + r] = ((unsigned long long)(unsigned)acc_hi << 32) | (unsigned)acc_lo;
+    };
+    for (int t = 0; t < nt_work; ++t) {
+        float *cur = (t & 1) ? buf1 : buf0;
+        float *oth = (t & 1) ? buf0 : buf1;
+        if (dp_wave) {
+            if (t_x > 0) {
+                if (r == 0) dp_tile(std::true_type{}, cur, t);
+                else dp_tile(std::false_type{}, cur, t);
+            }
+        } else {
+            if (NEED_COPY && t > 0)
+                mas_writeback_tile<YT>(oth, dp_values, base, Tx, Ty, XP, t - 1, mover, lane, nmov);
+            if (t + 1 < nt_work)
+                mas_stage_tile<YT, 16>(oth, in_values, mask, base, Tx, Ty, XP, t + 1, mover, lane, nmov);
+        }
+        __syncthreads();
+    }
+    if (NEED_COPY && nt_work > 0 && !dp_wave) {
+        const float *last = ((nt_work - 1) & 1) ? buf1 : buf0;
+        mas_writeback_tile<YT>(last, dp_values, base, Tx, Ty, XP, nt_work - 1, mover, lane, nmov);
+    }
+}
+
 
 // ---- forward DP, any T_x (T_x > 2048) ----------------------------------------------------------------
 // The kernels above keep a [T_x x 32]-column tile (and the previous column) on the CU; core.pyx:11-47 has no bound on t_x, so
@@ -523,6 +663,23 @@ __global__ void mask_lengths_kernel(int *__restrict__ t_xs, int *__restrict__ t_
 static int launch_forward_mw(const float *in, const float *mask, float *dp, unsigned long long *dirs, const int *t_xs,
                              const int *t_ys, int B, int Tx, int Ty, int R, float neg, hipStream_t st)
 {
+    // A/B switch: TTSAMD_MAS_MW=1 selects the round-3 column step (branches per column), default the branch-free one
+    static const bool v1 = getenv("TTSAMD_MAS_MW") && atoi(getenv("TTSAMD_MAS_MW")) == 1;
+    if (!v1) {
+        const size_t lds2 = ((size_t)2 * 32 * (64 * R + 1) + (size_t)2 * R * (kMasRing + kMasDump)) * sizeof(float);
+        static std::atomic<unsigned long long> done_c{0}, done_n{0};
+        if (dp) {
+            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw2_kernel<true>), 160 * 1024, done_c));
+            hipLaunchKernelGGL(mas_forward_mw2_kernel<true>, dim3(B), dim3(64 * kMasMwWaves), lds2, st, in, mask, dp, dirs, t_xs,
+                               t_ys, Tx, Ty, R, neg);
+        } else {
+            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw2_kernel<false>), 160 * 1024, done_n));
+            hipLaunchKernelGGL(mas_forward_mw2_kernel<false>, dim3(B), dim3(64 * kMasMwWaves), lds2, st, in, mask, dp, dirs, t_xs,
+                               t_ys, Tx, Ty, R, neg);
+        }
+        TTSAMD_LAUNCH_CHECK();
+        return TTSAMD_OK;
+    }
     const size_t lds = ((size_t)2 * 32 * (64 * R + 1) + (size_t)2 * R * kMasRing) * sizeof(float);
     static std::atomic<unsigned long long> lds_attr_done{0};
     TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw_kernel), 160 * 1024, lds_attr_done));

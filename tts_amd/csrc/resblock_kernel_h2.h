@@ -33,13 +33,18 @@ struct ResGeomH2 : ResGeom<K, D, C, WM, WN, NI> {
     // waves per SIMD the kernel is compiled for (= blocks per CU of a 4-wave block; an 8-wave block puts two waves on a SIMD):
     // as many as the LDS image allows, up to TTSAMD_PAIR_MAX_OCC — a block's life is mostly waiting (x tile from HBM, the two
     // epilogues, barriers), and only the other blocks of its CU fill the matrix pipe meanwhile
+    // Measured (profiles/r06_pairs_occupancy_ab.txt): 2, 3 or 4 waves per SIMD are within 0.5 % of each other — the kernels are
+    // issue-bound, not latency-bound — so the register budget goes to the residual instead: at <= 3 waves per SIMD (168 registers) the
+    // tile's own x columns are requested together with the staging loads (the same cache lines: no second trip to HBM) and held
+    // across both main loops.  With the request placed before conv2 or in the output epilogue (4 waves per SIMD, 128 registers) the
+    // lines had left the L2 by then: FETCH_SIZE 2.0x the x tensor instead of 1.0x (profiles/r06_pair_traffic.txt).
 #ifndef TTSAMD_PAIR_MAX_OCC
-#define TTSAMD_PAIR_MAX_OCC 4
+#define TTSAMD_PAIR_MAX_OCC 3
 #endif
     static constexpr int kFit = (int)((160 * 1024) / kLdsBytes);         // blocks per CU by LDS
     static constexpr int kOccRaw = B::kThreads <= 256 ? kFit : 2 * kFit;
     static constexpr int kOcc = kOccRaw < 1 ? 1 : (kOccRaw > TTSAMD_PAIR_MAX_OCC ? TTSAMD_PAIR_MAX_OCC : kOccRaw);
-    static constexpr bool kResEarly = kOcc <= 3;                          // 168+ registers: the residual is requested before conv2
+    static constexpr bool kResEarly = kOcc <= 3;                          // 168+ registers: the residual is requested with the staging loads
     // waves that hold at least one item of the last (partly filled) staging round
     static constexpr int kLastWaves = (B::kItems - (B::kRounds - 1) * B::kThreads + 63) / 64;
     static_assert(WM * WN == 4 || WM * WN == 8, "the maximum slots are read four at a time");
@@ -137,6 +142,18 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
         return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
     };
 
+    // the residual x — the tile's own columns, added in the output epilogue.  Requested right behind the staging loads (same lines)
+    // where the register budget has room for it (<= 3 waves per SIMD), in the output epilogue at 4 waves per SIMD
+    f32x16 resv[MI][G::kResEarly ? NI : 1];
+    auto request_residual = [&](int mi, int ni, f32x16 &dst) {
+        const int row0 = (wm * MI + mi) * 32;
+        const int o = (wn * NI + ni) * 32 + j;
+        const int t = t0 + o;
+        const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
+    };
+
     // ---- stage the x tile: columns [t0 - H2 - H1, +kXW) of all C channels: mask, leaky ReLU, block exponent, split, LDS ------
     int e_x;
     {
@@ -181,6 +198,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
             tabs[CC + tid] = tab1[2 * tid + 1];
             tabs[2 * CC + tid] = ld_buf(rb2, tid * 4, 0);
             tabs[3 * CC + tid] = tab2[2 * tid + 1];
+        }
+        if constexpr (G::kResEarly) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) request_residual(mi, ni, resv[mi][ni]);
         }
         float m = 0.f;
 #pragma unroll
@@ -235,17 +258,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
             a_cur[mi][q] = wp1[mi][q * 64];
             a_n1[mi][q] = wp1[mi][(2 + q) * 64];
         }
-    // the residual x — the tile's own columns (L2 hits after the staging pass), added in the output epilogue.  Requested before
-    // conv2 where the register budget has room for it (<= 3 waves per SIMD), after conv2 at 4 waves per SIMD
-    f32x16 resv[MI][G::kResEarly ? NI : 1];
-    auto request_residual = [&](int mi, int ni, f32x16 &dst) {
-        const int row0 = (wm * MI + mi) * 32;
-        const int o = (wn * NI + ni) * 32 + j;
-        const int t = t0 + o;
-        const int vo = (o < G::kBN && t < T) ? (4 * h * T + t) * 4 : kOob;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r] = ld_buf(rx, vo, (row0 + (r & 3) + 8 * (r >> 2)) * T * 4);
-    };
     // a lane's 16 rows of a table are four groups of four consecutive rows (row0 + 8 rg + 4 h + 0..3): one ds_read_b128 per group,
     // read where it is used (no table registers live across the main loops)
     auto table_row4 = [&](int which, int mi, int rg) -> f32x4 {
@@ -322,12 +334,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
     }
 
     // ---- conv2 ----------------------------------------------------------------------------------------------------------
-    if constexpr (G::kResEarly) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) request_residual(mi, ni, resv[mi][ni]);
-    }
     __syncthreads();                                                   // the mid tile is complete
     res_conv_mainloop_h2<K, 1, MI, NI, NCH, G::kPlaneM>(accm, accx, wp2, a_cur, a_n1, rh2 + h * G::kPlaneM + (wn * (32 * NI) + j) * 16);
 
