@@ -120,12 +120,13 @@ def test_maximum_path_beyond_2048_rows(gpu, shape):
 
 
 @pytest.mark.parametrize("env", [{"TTSAMD_MAS_FORCE_BIG": "1"}, {"TTSAMD_MAS_FORCE_BIG": "2"}, {"TTSAMD_MAS_MW": "1"},
-                                 {"TTSAMD_MAS_SINGLE_WAVE": "1"}],
-                         ids=["any_tx_lds", "any_tx_workspace", "mw_round3_column_step", "one_dp_wave"])
+                                 {"TTSAMD_MAS_SINGLE_WAVE": "1"}, {"TTSAMD_MAS_BT": "1"}],
+                         ids=["any_tx_lds", "any_tx_workspace", "mw_round3_column_step", "one_dp_wave", "round2_backtrack_walk"])
 def test_any_tx_kernel_on_the_small_cases(gpu, env):
     """The kernels the default dispatch does not pick for these shapes, forced onto them in a fresh process: the any-T_x kernel
     (TTSAMD_MAS_FORCE_BIG=1: column state in LDS, =2: in the workspace, the T_x > 16 384 arrangement), the round-3 column
-    step of the skewed pipeline (TTSAMD_MAS_MW=1; the default since round 6 is the branch-free step), the one-DP-wave kernel.
+    step of the skewed pipeline (TTSAMD_MAS_MW=1; the default since round 6 is the branch-free step), the one-DP-wave kernel,
+    the round-2 backtrack walk (TTSAMD_MAS_BT=1; default since round 6: conditions folded into the window words).
     Same bit-exact cases, ties, ragged items, the in-place mirror."""
     import os
     import subprocess

@@ -23,6 +23,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace ttsamd {
 
@@ -350,17 +351,33 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw_kernel(
 // Same fp32 add per cell on the same operands => bit-exact (tests/test_mas_gpu.py runs every case through both kernels).
 constexpr int kMasDump = 128;
 
-template <bool NEED_COPY>
+template <int N, class F, int... I>
+__device__ __forceinline__ void mas_static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void mas_static_for(F &&f)
+{
+    mas_static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// R (row groups = DP waves) is a template parameter: the tile's row pitch 64 R + 1 is a constant, and a FULL 32-column tile is
+// walked by an unrolled body in which every LDS address of the column step (next value, in-place write, ring slot to read, ring /
+// dump slot to publish) is base + immediate and the direction word's lane is an instruction constant — per column and DP wave
+// ~22 instructions (13 VALU, 3-4 LDS, one readfirstlane + compare + branch for the ring tag) instead of ~43; the first tile
+// (column 0) and a last partial tile keep the generic loop.
+template <int R, bool NEED_COPY>
 __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw2_kernel(
     const float *in_values, const float *__restrict__ mask, float *dp_values, unsigned long long *__restrict__ dirs,
-    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R, float neg)
+    const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, float neg)
 {
     constexpr int YT = 32;
+    constexpr int XP = 64 * R + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int XP = 64 * R + 1;
     float *buf0 = smem;
     float *buf1 = smem + YT * XP;
     unsigned long long *ring = reinterpret_cast<unsigned long long *>(smem + 2 * YT * XP);       // [R][kMasRing] {value, column}
@@ -374,7 +391,7 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw2_kernel(
     const int nt_work = NEED_COPY ? nt : ((t_x > 0 && t_y > 0) ? (min(t_y, Ty) + YT - 1) / YT : 0);
     const bool dp_wave = wave < R;
     const int mover = wave - R;
-    const int nmov = kMasMwWaves - R;
+    constexpr int nmov = kMasMwWaves - R;
 
     for (int i = threadIdx.x; i < R * kMasRing; i += blockDim.x) ring_st(ring + i, ~0ull);      // tag -1: nothing published
     for (int i = threadIdx.x; i < 2 * YT * XP; i += blockDim.x) {   // padding rows x >= Tx (no mover writes them) read as 0
@@ -402,12 +419,55 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw2_kernel(
     auto dp_tile = [&](auto first_tag, float *cur, int t) {
         constexpr bool kFirst = decltype(first_tag)::value;
         const int y0 = t * YT;
-        int y = y0;
         const int y_end = min(t_y, min(Ty, (t + 1) * YT));
-        if (y >= y_end) return;
+        if (y0 >= y_end) return;
         float *cp = cur + x;                                    // this lane's row in the tile, one column = XP floats
-        float cnext = cp[0];
         int acc_lo = 0, acc_hi = 0;                             // lane j: direction word of column y0 - 1 + j
+        if (t > 0 && y_end - y0 == YT) {
+            // ---- a full tile: 32 unrolled column steps, immediates everywhere ------------------------------------------------
+            const int half = (t & 1) * YT;                      // y & 63 = half + k
+            const unsigned long long *sub_t = sub + half;
+            unsigned long long *pub_t = pub + half;
+            float cnext = cp[0];
+            unsigned long long wq = ~0ull;
+            if constexpr (!kFirst) wq = ring_ld(sub + ((y0 - 1) & (kMasRing - 1)));
+            const unsigned d0 = (unsigned)y0 - xe;
+            mas_static_for<YT>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int y = y0 + k;
+                const float c = cnext;
+                cnext = cp[(k + 1) * XP];
+                int old = __builtin_bit_cast(int, neg);
+                if constexpr (!kFirst) {
+                    __builtin_amdgcn_sched_barrier(0);          // the look at the tag stays HERE, a whole step after its request
+                    // the first look is peeled out of the retry loop: on the straight path the wait covers only the (older) ring read,
+                    // not the publish and the value read issued after it — as the loop's header it waited for every LDS access
+                    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(wq >> 32)) != y - 1, 0)) {
+                        do wq = ring_ld(k == 0 ? sub + ((y0 - 1) & (kMasRing - 1)) : sub_t + (k - 1));
+                        while (__builtin_amdgcn_readfirstlane((int)(wq >> 32)) != y - 1);
+                    }
+                    old = (int)(unsigned)(wq & 0xffffffffull);
+                    wq = ring_ld(sub_t + k);                                          // the slot the NEXT column needs
+                }
+                const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, prev), 0x138, 0xf, 0xf, false));
+                unsigned long long bits = __builtin_amdgcn_ballot_w64(prev < up);
+                if constexpr (kFirst) bits &= ~1ull;
+                asm volatile("v_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                             : "+v"(acc_lo), "+v"(acc_hi)
+                             : "s"((int)(unsigned)(bits & 0xffffffffull)), "s"((int)(unsigned)(bits >> 32)), "n"(k));
+                const unsigned d = d0 + (unsigned)k;
+                const float v_cur = (d == 0u) ? neg : prev;                          // x == y
+                const float nv = vmax(v_cur, up) + c;
+                prev = (d <= band_u) ? nv : c;
+                if constexpr (NEED_COPY) cp[k * XP] = prev;
+                ring_st(pub_t + k, ((unsigned long long)(unsigned)y << 32) | __builtin_bit_cast(unsigned, prev));
+            });
+            if (lane < YT) dirs[((long)b * Ty + (y0 - 1 + lane)) * R + r] = ((unsigned long long)(unsigned)acc_hi << 32) | (unsigned)acc_lo;
+            return;
+        }
+        // ---- the first tile (column 0 is just prev = value) and a last, partly filled one: the generic loop --------------------
+        int y = y0;
+        float cnext = cp[0];
         if (t == 0) {                                           // column 0: value[x,0] = value (x = 0: max(neg, 0) + value)
             prev = cnext;
             cnext = cp[XP];
@@ -418,7 +478,6 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw2_kernel(
         if (y < y_end) {
             unsigned long long wq = ~0ull;                      // ring slot of column y - 1 (requested a column ahead)
             if (!kFirst) wq = ring_ld(sub + ((y - 1) & (kMasRing - 1)));
-#pragma unroll 2
             for (; y < y_end; ++y, cp += XP) {
                 const float c = cnext;
                 cnext = cp[XP];
@@ -471,7 +530,6 @@ __global__ __launch_bounds__(64 * kMasMwWaves) void mas_forward_mw2_kernel(
         mas_writeback_tile<YT>(last, dp_values, base, Tx, Ty, XP, nt_work - 1, mover, lane, nmov);
     }
 }
-
 
 // ---- forward DP, any T_x (T_x > 2048) ----------------------------------------------------------------
 // The kernels above keep a [T_x x 32]-column tile (and the previous column) on the CU; core.pyx:11-47 has no bound on t_x, so
@@ -556,7 +614,13 @@ __global__ __launch_bounds__(kMasBigThreads) void mas_forward_big_kernel(
 // serial chain.
 constexpr int kMasBtThreads = 512;
 
-template <typename PathT>
+// WALK2 (round 6, default): the chunk's serial walk with nothing but the recurrence on the chain.  The two conditions of
+// core.pyx:35 that do not come from the DP values — `index == y` (on the diagonal the path must step) and `index != 0` — and the
+// chunk's column range are folded into the per-column window words by the lanes BEFORE the walk (a few vector instructions per
+// chunk); the walk then carries one scalar, the bit position k = index - index0 + 63, through 64 unrolled steps of
+// {two v_readlane, one v_writelane recording k, shift, and, subtract} with instruction-constant lanes, and the indices are
+// rebuilt from the recorded k afterwards.  The round-2 walk spent ~25 instructions per column on the same chain.
+template <typename PathT, bool WALK2>
 __global__ __launch_bounds__(kMasBtThreads) void mas_backtrack_kernel(
     PathT *__restrict__ paths, const unsigned long long *__restrict__ dirs,
     const int *__restrict__ t_xs, const int *__restrict__ t_ys, int Tx, int Ty, int R,
@@ -605,6 +669,27 @@ __global__ __launch_bounds__(kMasBtThreads) void mas_backtrack_kernel(
                 const int wlo = (int)(unsigned)(window & 0xffffffffull);
                 const int whi = (int)(unsigned)(window >> 32);
                 const int jmax = min(63, t_y - 1 - y_lo);
+                if constexpr (WALK2) {
+                    const int sidx0 = __builtin_amdgcn_readfirstlane(idx);
+                    const int yy = y_lo + lane;
+                    unsigned long long w = window;
+                    const int kd = yy - sidx0 + 63;                                 // the diagonal row (index == y) in window bits
+                    if ((unsigned)kd < 64u) w |= 1ull << kd;
+                    if (sidx0 <= 63) w &= ~(1ull << (63 - sidx0));                  // row 0 never steps
+                    if (yy <= 0 || lane > jmax) w = 0ull;                           // column 0 / columns outside the item
+                    const int vlo = (int)(unsigned)(w & 0xffffffffull), vhi = (int)(unsigned)(w >> 32);
+                    int sk = 63, vk = 63;
+                    mas_static_for<64>([&](auto jc) {
+                        constexpr int j = 63 - decltype(jc)::value;
+                        const unsigned ulo = (unsigned)__builtin_amdgcn_readlane(vlo, j);
+                        const unsigned uhi = (unsigned)__builtin_amdgcn_readlane(vhi, j);
+                        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vk) : "s"(sk), "n"(j));
+                        const unsigned long long ww = ((unsigned long long)uhi << 32) | ulo;
+                        sk = __builtin_amdgcn_readfirstlane(sk - (int)((ww >> (sk & 63)) & 1ull));
+                    });
+                    myidx = (lane <= jmax) ? sidx0 - 63 + vk : -1;
+                    idx = sidx0 - 63 + sk;
+                } else {
                 // the index chain is serial (core.pyx:34-37): kept in a SCALAR register (readfirstlane pins it: left to itself
                 // hipcc ran the chain on the vector ALU — a 64-bit vector shift and three selects per column, ~140 cycles;
                 // the scalar chain is a handful of one-cycle ops), the per-lane bookkeeping (myidx) stays off the chain
@@ -621,6 +706,7 @@ __global__ __launch_bounds__(kMasBtThreads) void mas_backtrack_kernel(
                     sidx = __builtin_amdgcn_readfirstlane(sidx - (dec ? 1 : 0));
                 }
                 idx = sidx;
+                }
             }
             s_idx[c & 1][lane] = myidx;
             if (prezeroed && myidx >= 0) paths[base + (long)myidx * Ty + y_lo + lane] = (PathT)1;
@@ -667,16 +753,25 @@ static int launch_forward_mw(const float *in, const float *mask, float *dp, unsi
     static const bool v1 = getenv("TTSAMD_MAS_MW") && atoi(getenv("TTSAMD_MAS_MW")) == 1;
     if (!v1) {
         const size_t lds2 = ((size_t)2 * 32 * (64 * R + 1) + (size_t)2 * R * (kMasRing + kMasDump)) * sizeof(float);
-        static std::atomic<unsigned long long> done_c{0}, done_n{0};
-        if (dp) {
-            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw2_kernel<true>), 160 * 1024, done_c));
-            hipLaunchKernelGGL(mas_forward_mw2_kernel<true>, dim3(B), dim3(64 * kMasMwWaves), lds2, st, in, mask, dp, dirs, t_xs,
-                               t_ys, Tx, Ty, R, neg);
-        } else {
-            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw2_kernel<false>), 160 * 1024, done_n));
-            hipLaunchKernelGGL(mas_forward_mw2_kernel<false>, dim3(B), dim3(64 * kMasMwWaves), lds2, st, in, mask, dp, dirs, t_xs,
-                               t_ys, Tx, Ty, R, neg);
+        static std::atomic<unsigned long long> done[2][9];
+#define TTSAMD_MAS_MW2(n)                                                                                                              \
+    case n:                                                                                                                            \
+        if (dp) {                                                                                                                      \
+            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw2_kernel<n, true>), 160 * 1024, done[1][n]));   \
+            hipLaunchKernelGGL((mas_forward_mw2_kernel<n, true>), dim3(B), dim3(64 * kMasMwWaves), lds2, st, in, mask, dp, dirs, t_xs, \
+                               t_ys, Tx, Ty, neg);                                                                                     \
+        } else {                                                                                                                       \
+            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(mas_forward_mw2_kernel<n, false>), 160 * 1024, done[0][n]));  \
+            hipLaunchKernelGGL((mas_forward_mw2_kernel<n, false>), dim3(B), dim3(64 * kMasMwWaves), lds2, st, in, mask, dp, dirs,      \
+                               t_xs, t_ys, Tx, Ty, neg);                                                                               \
+        }                                                                                                                              \
+        break;
+        switch (R) {
+            TTSAMD_MAS_MW2(1) TTSAMD_MAS_MW2(2) TTSAMD_MAS_MW2(3) TTSAMD_MAS_MW2(4)
+            TTSAMD_MAS_MW2(5) TTSAMD_MAS_MW2(6) TTSAMD_MAS_MW2(7) TTSAMD_MAS_MW2(8)
+            default: set_error("maximum_path: %d row groups have no skewed-pipeline instantiation", R); return TTSAMD_ERR_INVALID;
         }
+#undef TTSAMD_MAS_MW2
         TTSAMD_LAUNCH_CHECK();
         return TTSAMD_OK;
     }
@@ -784,10 +879,15 @@ extern "C" int ttsamd_maximum_path(void *paths, const float *values_in, const fl
     else              rc = launch_forward<32, 8>(values_in, mask, dp_values_out, dirs, t_xs, t_ys, b, t_x, t_y, R, max_neg_val, st);
     if (rc != TTSAMD_OK) return rc;
     const int prezeroed = (flags & TTSAMD_MAS_PATHS_PREZEROED) ? 1 : 0;
-    if (flags & TTSAMD_MAS_PATHS_F32)
-        hipLaunchKernelGGL(mas_backtrack_kernel<float>, dim3(b), dim3(kMasBtThreads), 0, st, (float *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
-    else
-        hipLaunchKernelGGL(mas_backtrack_kernel<int>, dim3(b), dim3(kMasBtThreads), 0, st, (int *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed);
+    static const bool walk1 = getenv("TTSAMD_MAS_BT") && atoi(getenv("TTSAMD_MAS_BT")) == 1;     // A/B switch: the round-2 walk
+#define TTSAMD_MAS_BT(T, W) \
+    hipLaunchKernelGGL((mas_backtrack_kernel<T, W>), dim3(b), dim3(kMasBtThreads), 0, st, (T *)paths, dirs, t_xs, t_ys, t_x, t_y, R, prezeroed)
+    if (flags & TTSAMD_MAS_PATHS_F32) {
+        if (walk1) TTSAMD_MAS_BT(float, false); else TTSAMD_MAS_BT(float, true);
+    } else {
+        if (walk1) TTSAMD_MAS_BT(int, false); else TTSAMD_MAS_BT(int, true);
+    }
+#undef TTSAMD_MAS_BT
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }
