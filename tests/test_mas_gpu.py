@@ -50,6 +50,23 @@ def test_maximum_path_c_mirror_in_place_values(gpu, shape):
     assert np.array_equal(dv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
 
 
+@pytest.mark.parametrize("shape", [(3, 40, 25), (2, 130, 64), (2, 257, 100)])
+def test_items_with_fewer_columns_than_rows(gpu, shape):
+    """t_y < t_x: core.pyx:21-27 then fills no cell at all (the band is empty) and the backtrack (core.pyx:32-37) walks the
+    UNMODIFIED values; no caller of the reference produces such items (a mel is longer than its text), the kernels still have to
+    agree with the Cython core on them, ragged lengths included."""
+    B, TX, TY = shape
+    rng = np.random.default_rng(TX + TY)
+    tx = rng.integers(TY + 1, TX + 1, B)
+    ty = rng.integers(max(1, TY // 2), TY + 1, B)
+    tx[0], ty[0] = TX, TY
+    mask = (mas.sequence_mask(tx, TX)[:, :, None] & mas.sequence_mask(ty, TY)[:, None, :]).astype(np.float32)
+    v = rng.standard_normal((B, TX, TY)).astype(np.float32)
+    want = mas.maximum_path(v, mask, "c")
+    got = helpers.maximum_path(torch.from_numpy(v).to(gpu), torch.from_numpy(mask).to(gpu))
+    assert np.array_equal(got.cpu().numpy().astype(np.int32), want)
+
+
 def test_non_rectangular_mask_is_applied(gpu):
     """value*mask happens inside the kernel (helpers.py:184) even for masks with holes."""
     rng = np.random.default_rng(9)

@@ -49,6 +49,23 @@ def test_c_restatement_matches_reference_cython_and_numpy(shape, ties):
         assert ((np.diff(rows) == 0) | (np.diff(rows) == 1)).all()
 
 
+@pytest.mark.parametrize("shape", [(3, 40, 25), (2, 130, 64), (2, 257, 100)])
+def test_c_restatement_matches_reference_on_items_with_fewer_columns_than_rows(shape):
+    """t_y < t_x (no caller produces it; core.pyx:21-27 fills nothing, :32-37 walks the unmodified values): the restatement
+    follows the Cython core there too — the GPU test of the same name compares the kernels with it."""
+    ref = mas.ref_maximum_path_c()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box and no prebuilt core)")
+    B, TX, TY = shape
+    rng = np.random.default_rng(TX + TY)
+    tx = rng.integers(TY + 1, TX + 1, B)
+    ty = rng.integers(max(1, TY // 2), TY + 1, B)
+    tx[0], ty[0] = TX, TY
+    mask = (mas.sequence_mask(tx, TX)[:, :, None] & mas.sequence_mask(ty, TY)[:, None, :]).astype(np.float32)
+    v = rng.standard_normal((B, TX, TY)).astype(np.float32)
+    assert np.array_equal(mas.maximum_path(v, mask, "c"), mas.maximum_path(v, mask, "ref"))
+
+
 def test_reference_cython_core_was_built():
     import os
 

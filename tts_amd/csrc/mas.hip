@@ -19,6 +19,10 @@
 //   * backtrack — per 64-column chunk every lane extracts a 64-row window of its column's bit-plane around the current
 //     index, then wave 0 walks the chunk with scalar readlane ops while the other waves write the previous chunk's
 //     256-byte path row segments (zeros included).
+// Round 6 (profiles/r06_mas_column_step_ab.txt; [32,257,770]: 207 -> 106 us, forward 142 -> 76, backtrack 59 -> 26): a lone
+// wave issues roughly one instruction per 8-10 cycles, so both serial chains were cut to the instructions of the recurrence —
+// mas_forward_mw2_kernel<R, NEED_COPY> (~23 instructions per column and DP wave, no taken branch on the straight path) and the
+// WALK2 backtrack (6 per column).  The older kernels stay selectable (TTSAMD_MAS_MW=1, TTSAMD_MAS_BT=1) and tested.
 #include "common.h"
 
 #include <cstdlib>
