@@ -474,41 +474,6 @@ typedef struct ttsamd_norm_args {
 } ttsamd_norm_args;
 int ttsamd_channel_norm(const ttsamd_norm_args *args /* host */, void *stream);
 
-/* [norm ->] 1x1 conv -> norm in one launch, for text-length tensors (the launch chains of a single request are latency-bound).
- * replaces: one layer of DilatedDepthSeparableConv (TTS/tts/layers/vits/stochastic_duration_predictor.py:46-63):
- *     y = x + gelu(LN2(conv1x1(gelu(LN1(dwconv(x * mask))))))                (three ttsamd_* launches before)
- *   and the text encoder's  y = LN(x + conv_o(att)) * mask  (TTS/tts/layers/glow_tts/transformer.py:419-423; has_first = 0).
- *   u       = has_first ? act1(LN1(dw ? dwconv(x * in_mask) : x)) : x       (ttsamd_channel_norm's formulas)
- *   w[c,t]  = pw_b[c] + sum_k pw_w[c,k] * u[k,t]                             (fp32-input MFMA: exact products, fp32 sums)
- *   w      += pre_res[c,t];  v = act2(LN2(w));  v = post_res[c,t] + v;  y = v * out_mask[t]
- * pw_w: plain fp32 [c][c] row-major, 16-byte aligned (weight norm already folded).  Limits: ttsamd_pw_norm_supported(c, t):
- * c % 16 == 0, c <= 256, t <= 2048 — callers keep the three-launch form elsewhere.  The kernel is chosen by (c, t) alone. */
-typedef struct ttsamd_pw_norm_args {
-    const float *x;
-    int64_t x_bstride, x_rstride;
-    int32_t c, t, batch;
-    int32_t has_first;
-    const float *gamma1, *beta1; /* [c], used when has_first */
-    float eps1;
-    int32_t act1;
-    const float *dw_w, *dw_bias; /* [c, dw_kernel], [c] or NULL */
-    int32_t dw_kernel, dw_dilation;
-    const float *in_mask; /* [batch, t], used by the depthwise prologue */
-    const float *pw_w, *pw_b; /* [c, c], [c] or NULL */
-    const float *pre_res;
-    int64_t pre_bstride, pre_rstride;
-    const float *gamma2, *beta2; /* [c] */
-    float eps2;
-    int32_t act2;
-    const float *post_res;
-    int64_t post_bstride, post_rstride;
-    const float *out_mask; /* [batch, t] */
-    float *y;
-    int64_t y_bstride, y_rstride;
-} ttsamd_pw_norm_args;
-int ttsamd_pw_norm(const ttsamd_pw_norm_args *args /* host */, void *stream);
-int ttsamd_pw_norm_supported(int c, int t);
-
 /* ------------------------------------------------------------------------------------------
  * Relative-position multi-head attention core (everything between conv_q/k/v and conv_o).
  * replaces: RelativePositionMultiHeadAttention.attention, TTS/tts/layers/glow_tts/transformer.py:118-163

@@ -195,30 +195,6 @@ int ttsamd_channel_norm(const ttsamd_norm_args *ap, void *)
     }
     return TTSAMD_OK;
 }
-int ttsamd_pw_norm_supported(int c, int t) { return (c > 0 && (c & 15) == 0 && c <= 256 && t > 0 && t <= 2048) ? 1 : 0; }
-int ttsamd_pw_norm(const ttsamd_pw_norm_args *ap, void *)
-{
-    BAD(!ap || !ap->x || !ap->y || !ap->pw_w || !ap->gamma2 || !ap->beta2, "pw_norm stub: NULL tensor");
-    const ttsamd_pw_norm_args &a = *ap;
-    BAD(!ttsamd_pw_norm_supported(a.c, a.t), "pw_norm stub: shape outside the fused kernel");
-    ++g_stub_launches;
-    rd(a.pw_w, (size_t)a.c * a.c * 4), rd(a.gamma2, (size_t)a.c * 4), rd(a.beta2, (size_t)a.c * 4);
-    if (a.pw_b) rd(a.pw_b, (size_t)a.c * 4);
-    if (a.has_first) {
-        BAD(!a.gamma1 || !a.beta1, "pw_norm stub: first norm without gamma / beta");
-        rd(a.gamma1, (size_t)a.c * 4), rd(a.beta1, (size_t)a.c * 4);
-        if (a.dw_w) rd(a.dw_w, (size_t)a.c * a.dw_kernel * 4), rd(a.dw_bias, (size_t)a.c * 4);
-    }
-    for (int b = 0; b < a.batch; ++b) {
-        rd2(a.x + b * a.x_bstride, a.c, a.x_rstride, a.t);
-        if (a.pre_res) rd2(a.pre_res + b * a.pre_bstride, a.c, a.pre_rstride, a.t);
-        if (a.post_res) rd2(a.post_res + b * a.post_bstride, a.c, a.post_rstride, a.t);
-        if (a.has_first && a.in_mask) rd(a.in_mask + (int64_t)b * a.t, (size_t)a.t * 4);
-        if (a.out_mask) rd(a.out_mask + (int64_t)b * a.t, (size_t)a.t * 4);
-        wr2(a.y + b * a.y_bstride, a.c, a.y_rstride, a.t);
-    }
-    return TTSAMD_OK;
-}
 int ttsamd_rel_attention(float *out, const float *q, const float *k, const float *v, int64_t qkv_bstride, const float *mask, const float *emb_rel_k,
                          const float *emb_rel_v, int window, int batch, int heads, int dk, int t, void *)
 {

@@ -50,64 +50,6 @@ def test_channel_norm_plain_and_residual(gpu, C, T, eps):
     assert _rel(y, want1) < TOL
 
 
-@pytest.mark.parametrize("C,T,lens,dil", [(192, 257, [257, 200, 31], 1), (192, 17, [17, 3, 1], 3), (192, 300, [300, 299, 1], 9),
-                                          (256, 70, [70, 33, 16], 3), (64, 33, [33, 32, 2], 1), (16, 5, [5, 4, 1], 1)])
-def test_fused_norm_conv_norm_launch(gpu, C, T, lens, dil):
-    """ttsamd_pw_norm against fp64 torch: (a) a whole DilatedDepthSeparableConv layer (stochastic_duration_predictor.py:46-63),
-    (b) the text encoder's LN(x + conv_o(att)) * mask (transformer.py:419-423) — and against the three- / two-launch forms it
-    replaces."""
-    g = _g(C * 7 + T)
-    B = len(lens)
-    x, att = torch.randn(B, C, T, generator=g), torch.randn(B, C, T, generator=g)
-    dw_w, dw_b = torch.randn(C, 3, generator=g) * 0.5, torch.randn(C, generator=g) * 0.1
-    pw_w, pw_b = torch.randn(C, C, generator=g) / math.sqrt(C), torch.randn(C, generator=g) * 0.1
-    g1, b1, g2, b2 = (torch.randn(C, generator=g) for _ in range(4))
-    mask = _mask(lens, T)
-    D = torch.double
-
-    def ln(v, gam, bet, eps):
-        m = v.mean(1, keepdim=True)
-        var = ((v - m) ** 2).mean(1, keepdim=True)
-        return (v - m) * torch.rsqrt(var + eps) * gam.to(v.dtype).view(1, -1, 1) + bet.to(v.dtype).view(1, -1, 1)
-
-    xm = (x * mask[:, None]).to(D)
-    u = F.gelu(ln(F.conv1d(xm, dw_w.to(D)[:, None], dw_b.to(D), padding=dil, dilation=dil, groups=C), g1, b1, 1e-5))
-    w = F.conv1d(u, pw_w.to(D)[:, :, None], pw_b.to(D))
-    want_a = (x.to(D) + F.gelu(ln(w, g2, b2, 1e-5))) * mask[:, None].to(D)
-    dev = lambda t: t.to(gpu).contiguous()  # noqa: E731
-    assert ops.pw_norm_supported(C, T)
-    ya = ops.pw_norm(dev(x), torch.empty(B, C, T, device=gpu), dev(pw_w), dev(pw_b), dev(g2), dev(b2), 1e-5,
-                     first=(dev(g1), dev(b1), 1e-5, ops.ACT_GELU), dw_w=dev(dw_w), dw_bias=dev(dw_b), dw_dilation=dil, in_mask=dev(mask),
-                     act2=ops.ACT_GELU, post_res=dev(x), out_mask=dev(mask))
-    assert _rel(ya, want_a) < TOL
-    # the three launches it replaces
-    t1 = ops.channel_norm(dev(x), torch.empty(B, C, T, device=gpu), dev(g1), dev(b1), 1e-5, dw_w=dev(dw_w), dw_bias=dev(dw_b),
-                          dw_dilation=dil, in_mask=dev(mask), act=ops.ACT_GELU)
-    pc = layers.PackedConv(pw_w[:, :, None], pw_b, gpu)
-    t2 = torch.empty(B, C, T, device=gpu)
-    ops.conv1d(pc, t1, t2)
-    t3 = ops.channel_norm(t2, torch.empty(B, C, T, device=gpu), dev(g2), dev(b2), 1e-5, act=ops.ACT_GELU, post_res=dev(x), out_mask=dev(mask))
-    assert _rel(ya, t3) < TOL
-    # (b) no first norm: LN(x + conv(att) + bias) * mask
-    want_b = ln(x.to(D) + F.conv1d(att.to(D), pw_w.to(D)[:, :, None], pw_b.to(D)), g2, b2, 1e-5) * mask[:, None].to(D)
-    yb = ops.pw_norm(dev(att), torch.empty(B, C, T, device=gpu), dev(pw_w), dev(pw_b), dev(g2), dev(b2), 1e-5, pre_res=dev(x), out_mask=dev(mask))
-    assert _rel(yb, want_b) < TOL
-    # no bias, ReLU, no residuals
-    want_c = F.relu(ln(F.conv1d(att.to(D), pw_w.to(D)[:, :, None]), g2, b2, 1e-4))
-    yc = ops.pw_norm(dev(att), torch.empty(B, C, T, device=gpu), dev(pw_w), None, dev(g2), dev(b2), 1e-4, act2=ops.ACT_RELU)
-    assert _rel(yc, want_c) < TOL
-
-
-def test_fused_norm_conv_norm_limits(gpu):
-    assert not ops.lib().ttsamd_pw_norm_supported(200, 100) and not ops.lib().ttsamd_pw_norm_supported(272, 100)
-    assert not ops.lib().ttsamd_pw_norm_supported(192, 4000) and ops.lib().ttsamd_pw_norm_supported(192, 2048)
-    x = torch.randn(1, 200, 9, device=gpu)
-    w = torch.randn(200, 200, device=gpu)
-    v = torch.randn(200, device=gpu)
-    with pytest.raises(Exception, match="outside the fused kernel"):
-        ops.pw_norm(x, torch.empty_like(x), w, None, v, v, 1e-5)
-
-
 def test_dds_conv_matches_oracle(gpu):
     C, T, B = 192, 101, 3
     f = W._F(3)

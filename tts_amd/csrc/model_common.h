@@ -87,7 +87,6 @@ struct PackedConv {
     int c_out = 0, c_in = 0, kernel = 0, dilation = 1, pad_left = 0;
     bool tuned = false;
     DevBuf w, w_split, w_h2, bias, w_split_pad32, w_h2_pad32;
-    DevBuf w_raw;      // square 1x1 convs of <= 256 channels (c % 16 == 0): the plain fp32 [c][c] weight ttsamd_pw_norm reads
     bool has_bias = false;
 };
 

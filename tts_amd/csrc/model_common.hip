@@ -106,7 +106,6 @@ int pack_conv(PackedConv &pc, const char *who, const float *w, const float *bias
         RC(pc.w_split_pad32.upload(a.data(), a.size()));
         RC(pc.w_h2_pad32.upload(b.data(), b.size()));
     }
-    if (kernel == 1 && c_out == c_in && (c_out & 15) == 0 && c_out <= 256) RC(pc.w_raw.upload(w, (size_t)c_out * c_in * sizeof(float)));
     pc.has_bias = bias != nullptr;
     if (bias) return pc.bias.upload(bias, (size_t)c_out * sizeof(float));
     return TTSAMD_OK;

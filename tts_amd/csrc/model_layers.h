@@ -31,12 +31,6 @@ inline int conv(const Ctx &c, ttsamd_conv1d_args &a) { return ttsamd_conv1d(&a, 
 int norm(const Ctx &c, const float *x, float *y, int ch, int t, const Norm &n, int act = TTSAMD_ACT_NONE, const float *out_mask = nullptr,
          const float *post_res = nullptr, const float *dw_w = nullptr, const float *dw_b = nullptr, int dw_kernel = 0, int dw_dilation = 1,
          const float *in_mask = nullptr);
-// the fused [norm ->] 1x1 conv -> norm launch (ttsamd_pw_norm) where the library takes the shape; `first`: the layer's first norm with its
-// depthwise prologue (a DilatedDepthSeparableConv layer), nullptr: the conv reads x directly (the text encoder's LN(x + conv_o(att)))
-bool pw_norm_ok(const PackedConv &pw, int ch, int t);
-int pw_norm(const Ctx &c, const float *x, float *y, int ch, int t, const PackedConv &pw, const Norm &n2, int act2, const float *pre_res,
-            const float *post_res, const float *out_mask, const Norm *first = nullptr, int act1 = TTSAMD_ACT_NONE, const float *dw_w = nullptr,
-            const float *dw_b = nullptr, int dw_kernel = 0, int dw_dilation = 1, const float *in_mask = nullptr);
 
 // WaveNet block (TTS/tts/layers/generic/wavenet.py:16-123; tts_amd/layers.py: WN), no speaker conditioning
 struct Wn {

@@ -1,8 +1,6 @@
 // Layer drivers shared by the acoustic-model handles (see model_layers.h).
 #include "model_layers.h"
 
-#include <cstring>
-
 namespace ttsamd {
 namespace model {
 
@@ -50,55 +48,6 @@ int norm(const Ctx &c, const float *x, float *y, int ch, int t, const Norm &n, i
         a.in_mask = in_mask;
     }
     return ttsamd_channel_norm(&a, c.s);
-}
-
-bool pw_norm_ok(const PackedConv &pw, int ch, int t) { return pw.w_raw.p && pw.c_out == ch && ttsamd_pw_norm_supported(ch, t) != 0; }
-
-int pw_norm(const Ctx &c, const float *x, float *y, int ch, int t, const PackedConv &pw, const Norm &n2, int act2, const float *pre_res,
-            const float *post_res, const float *out_mask, const Norm *first, int act1, const float *dw_w, const float *dw_b, int dw_kernel,
-            int dw_dilation, const float *in_mask)
-{
-    ttsamd_pw_norm_args a;
-    memset(&a, 0, sizeof(a));
-    a.x = x;
-    a.x_bstride = (int64_t)ch * t;
-    a.x_rstride = t;
-    a.c = ch;
-    a.t = t;
-    a.batch = c.B;
-    if (first) {
-        a.has_first = 1;
-        a.gamma1 = first->gamma.f();
-        a.beta1 = first->beta.f();
-        a.eps1 = first->eps;
-        a.act1 = act1;
-        a.dw_w = dw_w;
-        a.dw_bias = dw_b;
-        a.dw_kernel = dw_kernel;
-        a.dw_dilation = dw_dilation;
-        a.in_mask = in_mask;
-    }
-    a.pw_w = pw.w_raw.f();
-    a.pw_b = pw.has_bias ? pw.bias.f() : nullptr;
-    if (pre_res) {
-        a.pre_res = pre_res;
-        a.pre_bstride = (int64_t)ch * t;
-        a.pre_rstride = t;
-    }
-    a.gamma2 = n2.gamma.f();
-    a.beta2 = n2.beta.f();
-    a.eps2 = n2.eps;
-    a.act2 = act2;
-    if (post_res) {
-        a.post_res = post_res;
-        a.post_bstride = (int64_t)ch * t;
-        a.post_rstride = t;
-    }
-    a.out_mask = out_mask;
-    a.y = y;
-    a.y_bstride = (int64_t)ch * t;
-    a.y_rstride = t;
-    return ttsamd_pw_norm(&a, c.s);
 }
 
 int build_wn(const TensorMap &t, const char *who, const std::string &p, int hidden, int kernel, int dilation_rate, int layers, Wn &wn)
@@ -227,16 +176,12 @@ int run_transformer(const Ctx &cx, const Transformer &tr, const TransformerBufs 
         RC(conv(cx, a));
         RC(ttsamd_rel_attention(b.att, b.qkv, b.qkv + (size_t)H * T, b.qkv + (size_t)2 * H * T, (int64_t)3 * H * T, x_mask, tr.window ? L.emb_k.f() : nullptr,
                                 tr.window ? L.emb_v.f() : nullptr, tr.window, B, tr.heads, H / tr.heads, T, cx.s));
-        if (pw_norm_ok(L.o, H, T)) {
-            RC(pw_norm(cx, b.att, b.x1, H, T, L.o, L.n1, TTSAMD_ACT_NONE, xc, nullptr, x_mask));       // LN(x + conv_o(att)) * mask
-        } else {
-            fill_conv_args(cx.precision, a, L.o, b.att, H, T, b.xy, H, T, B);       // x + attn(x)
-            a.res = xc;
-            a.res_bstride = (int64_t)H * T;
-            a.res_rstride = T;
-            RC(conv(cx, a));
-            RC(norm(cx, b.xy, b.x1, H, T, L.n1, TTSAMD_ACT_NONE, x_mask));
-        }
+        fill_conv_args(cx.precision, a, L.o, b.att, H, T, b.xy, H, T, B);           // x + attn(x)
+        a.res = xc;
+        a.res_bstride = (int64_t)H * T;
+        a.res_rstride = T;
+        RC(conv(cx, a));
+        RC(norm(cx, b.xy, b.x1, H, T, L.n1, TTSAMD_ACT_NONE, x_mask));
         fill_conv_args(cx.precision, a, L.f1, b.x1, H, T, b.hid, F, T, B);          // relu(conv_1(x * mask)) * mask
         a.out_act = TTSAMD_ACT_RELU;
         a.out_mask = x_mask;

@@ -207,12 +207,6 @@ int dds(const Ctx &c, const Dds &layers, float *const bufs[4], const float *mask
     const int n = (int)layers.size();
     for (int i = 0; i < n; ++i) {
         const DdsLayer &L = *layers[i];
-        if (pw_norm_ok(L.pw, ch, c.T)) {          // the whole layer in one launch (tts_amd/layers.py: DDSConv)
-            RC(pw_norm(c, x, alt, ch, c.T, L.pw, L.n2, TTSAMD_ACT_GELU, nullptr, x, i == n - 1 ? mask : nullptr, &L.n1, TTSAMD_ACT_GELU, L.dw_w.f(),
-                       L.dw_b.f(), kSdpKernel, L.dil, mask));
-            std::swap(x, alt);
-            continue;
-        }
         RC(norm(c, x, t1, ch, c.T, L.n1, TTSAMD_ACT_GELU, nullptr, nullptr, L.dw_w.f(), L.dw_b.f(), kSdpKernel, L.dil, mask));
         ttsamd_conv1d_args a;
         fill_conv_args(c.precision, a, L.pw, t1, ch, c.T, t2, ch, c.T, c.B);

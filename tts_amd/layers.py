@@ -73,14 +73,9 @@ class RelativePositionTransformer:
             ops.conv1d(L["qkv"], x, qkv)
             att = _new(x)
             ops.rel_attention(qkv, att, mask, self.num_heads, L.get("emb_k"), L.get("emb_v"), self.window or 0)
-            if L["o"].w_raw is not None and ops.pw_norm_supported(H, T):
-                # LN(x + conv_o(att)) * mask in one launch (text-length tensors: the chain is launch-bound)
-                x1 = ops.pw_norm(att, _new(x), L["o"].w_raw, L["o"].bias, L["n1"].gamma, L["n1"].beta, L["n1"].eps, pre_res=x,
-                                 out_mask=mask)
-            else:
-                xy = _new(x)
-                ops.conv1d(L["o"], att, xy, res=x)                              # x + attn(x)
-                x1 = ops.channel_norm(xy, _new(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, out_mask=mask)
+            xy = _new(x)
+            ops.conv1d(L["o"], att, xy, res=x)                                  # x + attn(x)
+            x1 = ops.channel_norm(xy, _new(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, out_mask=mask)
             hid = _new(x, L["f1"].c_out)
             # (t_out = T: an even FFN kernel pads (k-1)//2 left, k//2 right — transformer.py:306-313 — and keeps the length)
             ops.conv1d(L["f1"], x1, hid, out_act=ACT_RELU, out_mask=mask, t_out=T)       # relu(conv_1(x*mask)) * mask
@@ -142,13 +137,6 @@ class DDSConv:
         """x [B,C,T] (conditioning already added) -> DDSConv(x) * mask."""
         n = len(self.layers)
         for i, L in enumerate(self.layers):
-            if L["pw"].w_raw is not None and ops.pw_norm_supported(x.shape[1], x.shape[2]):
-                # the whole layer in one launch: x + gelu(LN2(conv1x1(gelu(LN1(dwconv(x * mask))))))
-                x = ops.pw_norm(x, _new(x), L["pw"].w_raw, L["pw"].bias, L["n2"].gamma, L["n2"].beta, L["n2"].eps,
-                                first=(L["n1"].gamma, L["n1"].beta, L["n1"].eps, ACT_GELU), dw_w=L["dw_w"], dw_bias=L["dw_b"],
-                                dw_dilation=L["dil"], in_mask=mask, act2=ACT_GELU, post_res=x,
-                                out_mask=mask if i == n - 1 else None)
-                continue
             y = ops.channel_norm(x, _new(x), L["n1"].gamma, L["n1"].beta, L["n1"].eps, dw_w=L["dw_w"], dw_bias=L["dw_b"],
                                  dw_dilation=L["dil"], in_mask=mask, act=ACT_GELU)
             y2 = _new(x)

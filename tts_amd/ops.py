@@ -144,10 +144,6 @@ class PackedConv:
         if self.tuned:
             self.w_h2 = _pack_h2(w, self.c_out, self.c_in, self.kernel).to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
-        # square 1x1 convs the fused [norm ->] conv -> norm launch can take (ttsamd_pw_norm) also keep the plain fp32 [C, C] weight
-        self.w_raw = None
-        if self.kernel == 1 and self.c_out == self.c_in and self.c_out % 16 == 0 and self.c_out <= 256:
-            self.w_raw = w.reshape(self.c_out, self.c_in).to(device).contiguous()
         # square convs of fewer than 32 channels also keep the split image of the weight zero-padded to [32, 32, k]: what the
         # fused ResBlock kernel's 32-channel tile reads (ttsamd_resblock_pair, c = 8 / 16)
         self.w_split_pad32 = self.w_h2_pad32 = None
@@ -517,60 +513,6 @@ def channel_norm(x, y, gamma, beta, eps, *, dw_w=None, dw_bias=None, dw_dilation
     a.out_mask = _dp(out_mask)
     a.y, a.y_bstride, a.y_rstride = y.data_ptr(), C * T, T
     check(lib().ttsamd_channel_norm(ctypes.byref(a), stream_ptr()), "channel_norm")
-    return y
-
-
-class PwNormArgs(ctypes.Structure):
-    """Mirror of `ttsamd_pw_norm_args` (include/tts_amd.h)."""
-
-    _fields_ = [
-        ("x", ctypes.c_void_p), ("x_bstride", ctypes.c_int64), ("x_rstride", ctypes.c_int64),
-        ("c", ctypes.c_int32), ("t", ctypes.c_int32), ("batch", ctypes.c_int32),
-        ("has_first", ctypes.c_int32),
-        ("gamma1", ctypes.c_void_p), ("beta1", ctypes.c_void_p), ("eps1", ctypes.c_float), ("act1", ctypes.c_int32),
-        ("dw_w", ctypes.c_void_p), ("dw_bias", ctypes.c_void_p),
-        ("dw_kernel", ctypes.c_int32), ("dw_dilation", ctypes.c_int32),
-        ("in_mask", ctypes.c_void_p),
-        ("pw_w", ctypes.c_void_p), ("pw_b", ctypes.c_void_p),
-        ("pre_res", ctypes.c_void_p), ("pre_bstride", ctypes.c_int64), ("pre_rstride", ctypes.c_int64),
-        ("gamma2", ctypes.c_void_p), ("beta2", ctypes.c_void_p), ("eps2", ctypes.c_float), ("act2", ctypes.c_int32),
-        ("post_res", ctypes.c_void_p), ("post_bstride", ctypes.c_int64), ("post_rstride", ctypes.c_int64),
-        ("out_mask", ctypes.c_void_p),
-        ("y", ctypes.c_void_p), ("y_bstride", ctypes.c_int64), ("y_rstride", ctypes.c_int64),
-    ]
-
-
-def pw_norm_supported(c, t):
-    """The fused [norm ->] 1x1 conv -> norm launch covers (c, t) (TTSAMD_PW_NORM=0 makes the library answer no for every shape:
-    the three-launch form, for A/B)."""
-    return bool(lib().ttsamd_pw_norm_supported(int(c), int(t)))
-
-
-def pw_norm(x, y, pw_w, pw_b, gamma2, beta2, eps2, *, first=None, dw_w=None, dw_bias=None, dw_dilation=1, in_mask=None,
-            pre_res=None, act2=ACT_NONE, post_res=None, out_mask=None):
-    """y = [post_res +] act2(LN2(pw_w . u + pw_b [+ pre_res])) [* out_mask] with u = x or, with first = (gamma1, beta1, eps1, act1),
-    u = act1(LN1([dwconv](x))) — one launch (include/tts_amd.h: ttsamd_pw_norm).  pw_w: fp32 [C, C]."""
-    B, C, T = x.shape
-    assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and tuple(pw_w.shape) == (C, C) and pw_w.is_contiguous()
-    a = PwNormArgs()
-    a.x, a.x_bstride, a.x_rstride, a.c, a.t, a.batch = x.data_ptr(), C * T, T, C, T, B
-    if first is not None:
-        g1, b1, e1, act1 = first
-        a.has_first, a.gamma1, a.beta1, a.eps1, a.act1 = 1, g1.data_ptr(), b1.data_ptr(), e1, act1
-        if dw_w is not None:
-            a.dw_w, a.dw_bias, a.dw_kernel, a.dw_dilation = dw_w.data_ptr(), _dp(dw_bias), dw_w.shape[-1], dw_dilation
-        a.in_mask = _dp(in_mask)
-    a.pw_w, a.pw_b = pw_w.data_ptr(), _dp(pw_b)
-    if pre_res is not None:
-        assert pre_res.shape == x.shape and pre_res.is_contiguous()
-        a.pre_res, a.pre_bstride, a.pre_rstride = pre_res.data_ptr(), C * T, T
-    a.gamma2, a.beta2, a.eps2, a.act2 = gamma2.data_ptr(), beta2.data_ptr(), eps2, act2
-    if post_res is not None:
-        assert post_res.shape == x.shape and post_res.is_contiguous()
-        a.post_res, a.post_bstride, a.post_rstride = post_res.data_ptr(), C * T, T
-    a.out_mask = _dp(out_mask)
-    a.y, a.y_bstride, a.y_rstride = y.data_ptr(), C * T, T
-    check(lib().ttsamd_pw_norm(ctypes.byref(a), stream_ptr()), "pw_norm")
     return y
 
 
