@@ -114,11 +114,12 @@ def test_rel_attention_long_kernel_on_the_short_cases(gpu):
     assert p.returncode == 0 and "long attention OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 
-@pytest.mark.parametrize("force", ["0", "1"])
+@pytest.mark.parametrize("force", ["0", "1", "v3"])
 def test_rel_attention_both_block_shapes_on_the_same_cases(gpu, force):
-    """Launches of up to 96 blocks take the 8-wave small-grid kernel (attention_v2.h), larger ones the 4-wave kernel; here each
-    is forced onto every ordinary case in a fresh process (TTSAMD_ATT_V2=0 / 1): windows, ragged masks, T < 5, head sizes that
-    are not multiples of 32, one and several key tiles per wave."""
+    """T <= 1024 takes the 16-query-block kernel (attention_v3.h); the 32-query kernels behind it (8-wave small-grid kernel of
+    attention_v2.h up to 96 blocks, the 4-wave kernel above) stay selectable.  Here each of the three is forced onto every
+    ordinary case in a fresh process (TTSAMD_ATT_V3=0 + TTSAMD_ATT_V2=0 / 1, TTSAMD_ATT_V3=1): windows, ragged masks, T < 5,
+    head sizes that are not multiples of 32, one and several key tiles per wave."""
     import os
     import subprocess
     import sys
@@ -133,7 +134,8 @@ def test_rel_attention_both_block_shapes_on_the_same_cases(gpu, force):
             "    t.test_rel_attention_matches_oracle(gpu, *c)\n"
             "print('attention OK')\n" % root)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280,
-                       env=dict(os.environ, TTSAMD_ATT_V2=force), cwd=root)
+                       env=dict(os.environ, **({"TTSAMD_ATT_V3": "1"} if force == "v3" else {"TTSAMD_ATT_V3": "0", "TTSAMD_ATT_V2": force})),
+                       cwd=root)
     assert p.returncode == 0 and "attention OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 

@@ -432,8 +432,12 @@ __global__ __launch_bounds__(kAttThreads, 2) void rel_attention_long_kernel(
 
 }  // namespace ttsamd
 #include "attention_v2.h"
+#include "attention_v3.h"
 namespace ttsamd {
 
+#ifndef TTSAMD_ATT_V3_DEFAULT
+#define TTSAMD_ATT_V3_DEFAULT true
+#endif
 constexpr long kAttV2MaxBlocks = 96;     // (query tile, head, item) blocks up to which the 8-wave small-grid kernel is taken
 
 template <int DK>
@@ -459,6 +463,20 @@ static int launch_att(float *out, const float *q, const float *k, const float *v
                            window, heads, dk, T);
         TTSAMD_LAUNCH_CHECK();
         return TTSAMD_OK;
+    }
+    {
+        // 16-query blocks (attention_v3.h): TTSAMD_ATT_V3=0 / 1 forces the choice (tests run every kernel on the same inputs)
+        static const char *force_v3 = getenv("TTSAMD_ATT_V3");
+        const size_t lds_v3 = att3::lds_bytes(T, nrel, DK);
+        if ((force_v3 ? force_v3[0] == '1' : TTSAMD_ATT_V3_DEFAULT) && lds_v3 <= 160 * 1024) {
+            auto k3 = att3::rel_attention_v3_kernel<DK>;
+            static std::atomic<unsigned long long> lds_attr_v3{0};
+            TTSAMD_HIP(ensure_dynamic_lds(reinterpret_cast<const void *>(k3), (int)(160 * 1024), lds_attr_v3));
+            hipLaunchKernelGGL(k3, dim3((T + 15) / 16, heads, batch), dim3(att3::kThreads), lds_v3, st, out, q, k, v, bstride, mask,
+                               ek, ev, window, heads, dk, T);
+            TTSAMD_LAUNCH_CHECK();
+            return TTSAMD_OK;
+        }
     }
     {
         // small grids (a single request: 18 blocks at T = 257): the 8-wave kernel of attention_v2.h.  TTSAMD_ATT_V2=0 / 1 forces
