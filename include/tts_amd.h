@@ -218,7 +218,8 @@ int ttsamd_conv1d_set_small_grid(int mode);
  * in_mask).  Weights are the split-bf16 images of ttsamd_conv1d_pack_weights_split ([c, c, k] each); the intermediate
  * tensor stays in LDS (5 HBM tensor passes -> 2) and the arithmetic is product-for-product that of two ttsamd_conv1d
  * launches with w_split set: results are bitwise identical to the unfused pair.
- * Limits: c in {8, 16, 32, 64, 128}, kernel in {3, 7, 11}, dilation in {1, 3, 5} (ttsamd_resblock_pair_supported).
+ * Limits: c in {8, 16, 32, 64, 128} (and 256 with the two-part fp16 images), kernel in {3, 7, 11}, dilation in {1, 3, 5}
+ * (ttsamd_resblock_pair_supported / ttsamd_resblock_pair_h2_supported).
  * c = 8 / 16 (HiFiGAN-v2's late stages) run on the 32-channel tile: pass the split images of the weights ZERO-PADDED to
  * [32, 32, k] (tensors and biases keep their real channel count; equal to the unfused pair up to the sign of zeros). */
 typedef struct ttsamd_resblock_args {
@@ -251,6 +252,8 @@ size_t ttsamd_resblock_weight_bytes(int c, int kernel);
 size_t ttsamd_resblock_weight_h2_bytes(int c, int kernel);   /* = ttsamd_conv1d_packed_h2_bytes of the [max(c,32), max(c,32), kernel] weight */
 int ttsamd_resblock_pair(const ttsamd_resblock_args *args /* host */, void *stream);
 int ttsamd_resblock_pair_supported(int c, int kernel, int dilation);
+/* the same question for a call that carries the two-part fp16 images (w1_h2 / w2_h2): additionally c = 256 (ABI v4, round 6) */
+int ttsamd_resblock_pair_h2_supported(int c, int kernel, int dilation);
 /* The three branches of one MRF stage at one dilation — kernel sizes 3, 7, 11 in slots 0, 1, 2 of args3 (a slot with x == NULL is
  * absent), same c / t / batch / dilation — as ONE launch (hifigan_generator.py:255-261: the resblocks of a stage are independent).
  * For the small grids of a single sentence only (ttsamd_resblock_group_supported: c in {8,16,32,64} and t * batch within the

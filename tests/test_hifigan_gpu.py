@@ -26,7 +26,7 @@ def _make(cfg, in_ch, gpu, sd, **kw):
     return m.to(gpu)
 
 
-@pytest.mark.parametrize("variant", ["v1_c64", "v2", "rb2", "v1_full", "v1_full_long"])
+@pytest.mark.parametrize("variant", ["v1_c64", "v2", "rb2", "v1_full", "v1_full_long", "v1_full_batch"])
 def test_hifigan_inference_matches_oracle(gpu, variant):
     torch.set_num_threads(8)
     cfg = dict(W.HIFIGAN_V1)
@@ -40,15 +40,26 @@ def test_hifigan_inference_matches_oracle(gpu, variant):
     elif variant == "v1_full_long":       # full-width v1 (512 channels), several time tiles at every stage, two items
         T, B = 150, 2
         torch.set_num_threads(min(64, os.cpu_count() or 8))
+    elif variant == "v1_full_batch":      # full-width v1, 8 x 640 columns at the 256-channel stage: its k = 3 / k = 7 pairs run fused
+        T, B = 70, 8
+        torch.set_num_threads(min(64, os.cpu_count() or 8))
     else:
         T, B = 24, 1
     sd = O.make_hifigan_state(cfg, 80, seed=5)
     x = torch.randn(B, 80, T, generator=torch.Generator().manual_seed(0))
     want = O.hifigan_inference(sd, "", x, cfg)
-    got = _make(cfg, 80, gpu, sd).inference(x.to(gpu))
+    m = _make(cfg, 80, gpu, sd)
+    got = m.inference(x.to(gpu))
     assert got.shape == want.shape == (B, 1, (T + 10) * 256)
     rms, rel = _errs(got, want)
     assert rms < 1e-4 and rel < 1e-5, (rms, rel)
+    if variant == "v1_full_batch":
+        from tts_amd import ops
+        if ops.conv_precision() == "h2":  # ... and differ from the two-launch form only at fp32 rounding level (it IS another kernel)
+            assert m._fuse_limit(256, B * (T + 10) * 8) == 7 and m._fuse_limit(256, 4000) == 0
+            m.fuse_max_kernel = {128: 7, 256: 0}
+            two = m.inference(x.to(gpu))
+            assert not torch.equal(two, got) and _errs(got, two)[1] < 2e-6, _errs(got, two)
 
 
 def test_vits_decoder_shape_contract(gpu):
@@ -276,7 +287,7 @@ def test_hifigan_trained_like_weights_match_the_reference_golden(gpu, precision)
     assert _errs(got, got0)[1] < 1e-5
 
 
-@pytest.mark.parametrize("variant", ["v2_sentence", "v1_c256_batch", "rb2_c64", "untuned"])
+@pytest.mark.parametrize("variant", ["v2_sentence", "v1_c256_batch", "v1_full_batch", "rb2_c64", "untuned"])
 def test_native_vocoder_handle_equals_the_python_driven_path(gpu, variant):
     """The model-level C ABI (include/tts_amd.h: ttsamd_hifigan_{create,load,finalize,forward,destroy}; csrc/hifigan_model.hip)
     through ctypes: weights handed over in the reference's state_dict layout, folded / re-ordered / packed in C++, the launch
@@ -295,6 +306,9 @@ def test_native_vocoder_handle_equals_the_python_driven_path(gpu, variant):
     elif variant == "v1_c256_batch":             # large grids: three-product kernels on the 128- / 64- / 32-channel stages
         cfg["upsample_initial_channel"] = 256
         B, T = 3, 130
+    elif variant == "v1_full_batch":             # full width: the 256-channel stage's fused k = 3 / k = 7 pairs (>= 4096 columns)
+        B, T = 8, 60
+        torch.set_num_threads(min(64, os.cpu_count() or 8))
     elif variant == "rb2_c64":
         cfg.update(upsample_initial_channel=64, resblock_type="2", resblock_dilation_sizes=[[1, 3]] * 3)
     else:                                        # kernel sizes / strides without tuned instantiations: generic kernels
@@ -334,7 +348,7 @@ def test_native_vocoder_handle_equals_the_python_driven_path(gpu, variant):
         nat.forward(xg, use_graph=True, out=out)
         assert torch.equal(out, ref)
     if m.exact_hop and B > 1:                     # ragged-exact batching through the handle == through the Python host
-        lens = torch.tensor([T, max(1, T - 13), max(1, T // 2)][:B]).to(gpu)
+        lens = torch.tensor(([T, max(1, T - 13), max(1, T // 2)] + [max(1, T - 5 * i) for i in range(3, B)])[:B]).to(gpu)
         assert torch.equal(nat.forward(xg, lengths=lens), m.inference(xg, lengths=lens))
     # errors come back as codes + messages, nothing crashes
     import pytest as _pt

@@ -163,6 +163,36 @@ def test_fused_pair_h2_mask_accum_div_and_edges(gpu, case):
         assert _rel(y[i], ref[i]) < 1e-5, (i, _rel(y[i], ref[i]))
 
 
+@pytest.mark.parametrize("kd", [(K, D) for K in (3, 7, 11) for D in (1, 3, 5)], ids=lambda c: "k%d_d%d" % c)
+def test_fused_pair_h2_256_channels(gpu, kd):
+    """The 256-channel pair exists on the three-product arithmetic only (8 waves, one block per CU): against the two three-product
+    conv launches at fp32 rounding level, against torch at the conv tolerance; ragged masks + accumulate + division + a wide-range
+    input (item magnitudes 1e-3 .. 1e2) against an fp64 evaluation; the six-product dispatch does not offer it."""
+    K, D = kd
+    C, B, T = 256, 3, 300 + 17 * K + D
+    w, pc1, pc2, g = _pair(C, K, D, C + K + D, gpu)
+    assert not ops.resblock_pair_supported(pc1, pc2)                   # six products (the suite's default): two launches
+    x = torch.randn(B, C, T, generator=g) * (10.0 ** torch.linspace(-3, 2, B))[:, None, None]
+    lens = torch.tensor([max(1, T - 97 * i) for i in range(B)])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float()
+    acc = torch.randn(B, C, T, generator=g)
+    with _H2():
+        assert ops.resblock_pair_supported(pc1, pc2)
+        y0 = torch.full((B, C, T), float("nan"), device=gpu)
+        ops.resblock_pair(pc1, pc2, x.to(gpu), y0, slope=SLOPE)
+        want0 = _unfused(pc1, pc2, x.to(gpu), None, None, 0.0)
+        y = torch.full((B, C, T), float("nan"), device=gpu)
+        ops.resblock_pair(pc1, pc2, x.to(gpu), y, slope=SLOPE, mask=mask.to(gpu), accum=acc.to(gpu), out_div=3.0)
+        want = _unfused(pc1, pc2, x.to(gpu), mask.to(gpu), acc.to(gpu), 3.0)
+    assert torch.isfinite(y0).all() and torch.isfinite(y).all()
+    assert _rel(y0, want0) < 2e-6 and _rel(y, want) < 2e-6, (_rel(y0, want0), _rel(y, want))
+    w64 = tuple(t.double() for t in w)
+    ref0 = _torch_ref(w64, x.double(), None, None, 0.0, K, D)
+    ref = _torch_ref(w64, x.double(), mask.double(), acc.double(), 3.0, K, D)
+    for i in range(B):                                  # per item: the small-magnitude items keep their own relative accuracy
+        assert _rel(y0[i], ref0[i]) < 1e-5 and _rel(y[i], ref[i]) < 1e-5, (i, _rel(y0[i], ref0[i]), _rel(y[i], ref[i]))
+
+
 @pytest.mark.parametrize("ck", [(8, 3), (16, 7), (8, 11)])
 def test_fused_pair_h2_rows_beyond_the_tensor_read_as_zero(gpu, ck):
     """8- and 16-channel pairs run on a padded tile: the rows beyond the tensor's own channels must come back as zeros through the

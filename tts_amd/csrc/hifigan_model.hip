@@ -9,6 +9,9 @@
 // Ownership: the caller owns mel / lengths / wav (device pointers); the handle owns its packed weights (device) and a grow-only
 // activation workspace (device).  One caller and one stream at a time per handle (the reference's Synthesizer is not thread-safe
 // either, synthesizer.py:302-304); errors are return codes + ttsamd_last_error(), nothing throws across the ABI.
+#include <cstdio>
+#include <cstdlib>
+
 #include "model_common.h"
 
 using namespace ttsamd;
@@ -137,14 +140,36 @@ struct Workspace {
     }
 };
 
-// which (channels, kernel) pairs the generator fuses (tts_amd/hifigan.py: fuse_channels, fuse_max_kernel = {128: 3})
-bool fuse_pair(const Model &m, const PackedConv &c1, const PackedConv &c2)
+struct FuseLimits { int k128 = -1, k256 = -1; };
+static FuseLimits fuse_limits_from_env()
+{
+    FuseLimits l;
+    const char *e = getenv("TTSAMD_FUSE_LIMITS");
+    for (; e && *e; ) {
+        int c = 0, k = 0, n = 0;
+        if (sscanf(e, "%d:%d%n", &c, &k, &n) != 2) break;
+        if (c == 128) l.k128 = k;
+        if (c == 256) l.k256 = k;
+        e += n;
+        if (*e == ',') ++e;
+    }
+    return l;
+}
+
+// which (channels, kernel) pairs the generator fuses (tts_amd/hifigan.py: fuse_channels, fuse_max_kernel = {128: 7 | 3, 256: 3 | 0})
+bool fuse_pair(const Model &m, const PackedConv &c1, const PackedConv &c2, long cols)
 {
     if (m.precision == 2) return false;
     const int ch = c1.c_out;
     if (!(c1.c_in == ch && c2.c_in == ch && c2.c_out == ch && c1.kernel == c2.kernel && c2.dilation == 1)) return false;
-    if (ch == 128 && c1.kernel > (m.precision == 0 ? 7 : 3)) return false;     // tts_amd/hifigan.py: _fuse_limit
-    return ttsamd_resblock_pair_supported(ch, c1.kernel, c1.dilation) != 0;
+    // largest fused kernel size at 128 / 256 channels (tts_amd/hifigan.py: _fuse_limit, same table; TTSAMD_FUSE_LIMITS="128:7,256:7"
+    // overrides it in both hosts for A/B runs).  256 channels: three products only, and not on small grids (cols = T x batch: the
+    // 8-wave block is a large-grid tile)
+    static const FuseLimits lim = fuse_limits_from_env();
+    if (ch == 128 && c1.kernel > (lim.k128 >= 0 ? lim.k128 : (m.precision == 0 ? 7 : 3))) return false;
+    if (ch == 256 && (m.precision != 0 || c1.kernel > (lim.k256 >= 0 ? lim.k256 : 7) || cols < 4096)) return false;
+    return (m.precision == 0 ? ttsamd_resblock_pair_h2_supported(ch, c1.kernel, c1.dilation)
+                             : ttsamd_resblock_pair_supported(ch, c1.kernel, c1.dilation)) != 0;
 }
 
 void fill_pair_args(const Model &m, ttsamd_resblock_args &r, const PackedConv &c1, const PackedConv &c2, const float *x, float *y, const float *accum,
@@ -291,7 +316,7 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                         const std::string rp = "resblocks." + std::to_string(i * nk + j) + ".";
                         CONV(g1, rp + "convs1." + std::to_string(d));
                         CONV(g2, rp + "convs2." + std::to_string(d));
-                        if (!fuse_pair(m, g1, g2)) grouped = false;
+                        if (!fuse_pair(m, g1, g2, (long)T * B)) grouped = false;
                     }
             }
         }
@@ -348,7 +373,7 @@ int run(Model &m, Workspace &ws, const float *mel, int B, int T0, const int64_t 
                     if (c.resblock_type == 1) {
                         CONV(c1, rp + "convs1." + std::to_string(d));
                         CONV(c2, rp + "convs2." + std::to_string(d));
-                        if (fuse_pair(m, c1, c2)) {
+                        if (fuse_pair(m, c1, c2, (long)T * B)) {
                             if (join) TTSAMD_HIP(hipStreamWaitEvent(sj, prev_done, 0));
                             ttsamd_resblock_args r;
                             fill_pair_args(m, r, c1, c2, cur, dst, accum, msk, ch, T, B, div);

@@ -242,6 +242,13 @@ extern "C" int ttsamd_resblock_pair_supported(int c, int kernel, int dilation)
            (dilation == 1 || dilation == 3 || dilation == 5);
 }
 
+// ... with the two-part fp16 images (three-product arithmetic): additionally c = 256
+extern "C" int ttsamd_resblock_pair_h2_supported(int c, int kernel, int dilation)
+{
+    return (ttsamd_resblock_pair_supported(c, kernel, dilation) || c == 256) && (kernel == 3 || kernel == 7 || kernel == 11) &&
+           (dilation == 1 || dilation == 3 || dilation == 5);
+}
+
 extern "C" size_t ttsamd_resblock_weight_bytes(int c, int kernel)
 {
     const int cc = c < 32 ? 32 : c;

@@ -11,7 +11,8 @@ extern "C" int ttsamd_resblock_pair(const ttsamd_resblock_args *args, void *stre
     TTSAMD_CHECK_ARG(a.x != a.y, "resblock_pair: y must not alias x (neighbouring tiles read x's halo)");
     TTSAMD_CHECK_ARG(a.c > 0 && a.t >= 0 && a.batch >= 0, "resblock_pair: bad shape");
     TTSAMD_CHECK_ARG(a.slope >= 0.f && a.slope <= 1.f, "resblock_pair: leaky-ReLU slope %g outside [0, 1]", (double)a.slope);
-    if (!ttsamd_resblock_pair_supported(a.c, a.kernel, a.dilation)) {
+    if (!ttsamd_resblock_pair_supported(a.c, a.kernel, a.dilation) &&
+        !(a.w1_h2 && a.w2_h2 && a.variant != 2 && ttsamd_resblock_pair_h2_supported(a.c, a.kernel, a.dilation))) {
         set_error("resblock_pair: (c=%d, kernel=%d, dilation=%d) has no instantiation", a.c, a.kernel, a.dilation);
         return TTSAMD_ERR_UNSUPPORTED;
     }

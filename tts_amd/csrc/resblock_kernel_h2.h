@@ -427,8 +427,12 @@ int resblock_pair_h2_launch_kd(const ttsamd_resblock_args &a, hipStream_t st)
             // (scripts/h2_variants_ab.py); variant 1 selects the 8-wave tile for A/B
             if (a.variant == 1) return resblock_pair_h2_launch_cfg<K, D, 128, 4, 2, 2>(a, st);
             return resblock_pair_h2_launch_cfg<K, D, 128, 4, 1, 2>(a, st);
+        case 256:
+            // three-product arithmetic only (round 6): 8 waves x 32 rows, 64 mid columns, 76-117 KB of LDS, one block per CU.  The
+            // unfused 256-channel convs stage every x tile once per 128 output rows and per conv; here it is staged once per pair.
+            return resblock_pair_h2_launch_cfg<K, D, 256, 8, 1, 2>(a, st);
     }
-    set_error("resblock_pair: c = %d has no instantiation (8, 16, 32, 64, 128)", a.c);
+    set_error("resblock_pair: c = %d has no instantiation (8, 16, 32, 64, 128, 256)", a.c);
     return TTSAMD_ERR_UNSUPPORTED;
 }
 

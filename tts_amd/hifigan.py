@@ -164,15 +164,19 @@ class HifiganGenerator:
         # request, one stream when the request runs inside parallel.Lanes with two or more lanes (parallel.active_lanes)
         self.concurrent_branches = "auto"
         # ResBlock1 iterations (lrelu -> conv(k,d) -> lrelu -> conv(k,1) -> +x) run as ONE fused launch where the kernel
-        # covers the shape (C in {8,16,32,64,128} per `fuse_channels`, split-bf16 arithmetic): the intermediate tensor stays in
+        # covers the shape (C in {8,16,32,64,128,256} per `fuse_channels`, split-bf16 / two-part fp16 arithmetic): the intermediate tensor stays in
         # LDS, 5 HBM tensor passes -> 2.  Bitwise equal to the unfused pair.
         # Measured at the benchmark's stage shapes (scripts/resblock_ab.py, fused / unfused time): C=32 0.59-0.83,
         # C=64 0.66-0.92, C=128 0.88 (k=3), 1.00 (k=7), 1.07 (k=11) -> the 128-channel stage fuses its k=3 blocks only.
         self.fuse_resblocks = os.environ.get("TTSAMD_FUSE_RESBLOCKS", "1") != "0"
-        self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "8,16,32,64,128").split(",") if c)
+        self.fuse_channels = tuple(int(c) for c in os.environ.get("TTSAMD_FUSE_CHANNELS", "8,16,32,64,128,256").split(",") if c)
         # channel count -> largest kernel size fused (absent = all).  128 channels: k = 3 only on six products (round 2: k = 7 1.00,
         # k = 11 1.07 of the unfused pair); on three products the fused k = 7 pair is 0.90-0.91 of the two launches (its LDS image is
-        # 2/3 the size), k = 11 1.02 (scripts/h2_variants_ab.py) — `None` = pick by the conv precision at call time
+        # 2/3 the size), k = 11 1.02 (scripts/h2_variants_ab.py) — `None` = pick by the conv precision at call time.
+        # 256 channels (three products only, an 8-wave block per CU): launch by launch k = 3 is 0.85-0.92 of the two launches at
+        # B = 32 and 0.70-0.73 for a single utterance, k = 7 1.06-1.08 / 0.90, k = 11 1.20 / 1.00 (scripts/r6_pair256_ab.py); in the
+        # whole B = 32 step (same box, TTSAMD_FUSE_LIMITS): none 49.04, k <= 3 48.67, k <= 7 48.33, all 49.14 ms -> k <= 7
+        # (profiles/r06_pair256_ab.txt; the step gains more than the launches: one tensor pass less per pair under the power cap)
         self.fuse_max_kernel = None
         # small grids (a single sentence): the three MRF branches of a stage as ONE launch per ResBlock iteration instead of nine
         # launches on three branch streams (forward())
@@ -195,9 +199,17 @@ class HifiganGenerator:
         self._graph = graphs.GraphCache(self._inference_ragged, max_entries=12)
         self.weights_version = 0    # bumped by every re-pack: dependants (SentencePipeline) key their graphs on it
 
-    def _fuse_limit(self, ch):
-        """Largest kernel size whose ResBlock pairs run fused at `ch` channels (see fuse_max_kernel)."""
-        table = self.fuse_max_kernel if self.fuse_max_kernel is not None else ({128: 7} if ops.conv_precision() == "h2" else {128: 3})
+    def _fuse_limit(self, ch, cols=None):
+        """Largest kernel size whose ResBlock pairs run fused at `ch` channels (see fuse_max_kernel); `cols` = T x batch: the
+        256-channel pair is a large-grid tile (an 8-wave block per CU) and stays off below 4096 columns."""
+        if ch == 256 and cols is not None and cols < 4096:
+            return 0
+        table = self.fuse_max_kernel if self.fuse_max_kernel is not None else ({128: 7, 256: 7} if ops.conv_precision() == "h2" else {128: 3, 256: 0})
+        env = os.environ.get("TTSAMD_FUSE_LIMITS")         # "128:7,256:7": A/B override, read by the C handle too
+        if env and self.fuse_max_kernel is None:
+            table = {**table, **{int(c): int(k) for c, k in (item.split(":") for item in env.split(",") if item)}}
+            if ops.conv_precision() != "h2":
+                table[256] = 0
         return table.get(ch, 99)
 
     def hop_length(self):
@@ -325,7 +337,7 @@ class HifiganGenerator:
             return False
         for m in range(len(dils[0])):
             pairs = [(P["resblocks.%d.convs1.%d" % (i * nk + j, m)], P["resblocks.%d.convs2.%d" % (i * nk + j, m)]) for j in range(nk)]
-            if any(pc1.kernel > self._fuse_limit(ch) for pc1, _ in pairs) or not ops.resblock_group_supported(pairs, B, ch, T):
+            if any(pc1.kernel > self._fuse_limit(ch, B * T) for pc1, _ in pairs) or not ops.resblock_group_supported(pairs, B, ch, T):
                 return False
         return True
 
@@ -471,7 +483,7 @@ class HifiganGenerator:
                             dst, accum, div = (xa if cur is not xa else xb), None, 0.0
                         if self.resblock_type == "1":
                             pc1, pc2 = P[rp + "convs1.%d" % m], P[rp + "convs2.%d" % m]
-                            if (self.fuse_resblocks and ch in self.fuse_channels and pc1.kernel <= self._fuse_limit(ch)
+                            if (self.fuse_resblocks and ch in self.fuse_channels and pc1.kernel <= self._fuse_limit(ch, B * T)
                                     and ops.resblock_pair_supported(pc1, pc2)):
                                 if last and side and prev_done is not None:
                                     st.wait_event(prev_done)      # zsum holds the previous branches' sum

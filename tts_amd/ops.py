@@ -236,8 +236,9 @@ class ResblockArgs(ctypes.Structure):
 
 def resblock_pair_supported(pc1: PackedConv, pc2: PackedConv):
     """True when the fused ResBlock1-iteration kernel covers this conv pair (split-bf16 arithmetic only)."""
+    q = lib().ttsamd_resblock_pair_h2_supported if _PRECISION == "h2" else lib().ttsamd_resblock_pair_supported    # h2: also c = 256
     return (_PRECISION in ("x3", "h2") and pc1.c_in == pc1.c_out == pc2.c_in == pc2.c_out and pc1.kernel == pc2.kernel
-            and pc2.dilation == 1 and bool(lib().ttsamd_resblock_pair_supported(pc1.c_out, pc1.kernel, pc1.dilation)))
+            and pc2.dilation == 1 and bool(q(pc1.c_out, pc1.kernel, pc1.dilation)))
 
 
 def resblock_pair(pc1: PackedConv, pc2: PackedConv, x, y, *, slope, mask=None, accum=None, out_div=0.0, variant=0):
