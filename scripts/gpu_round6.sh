@@ -15,6 +15,7 @@ timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.jsonl 2> $OUT/
 for B in 32 256; do timeout 300 python bench.py --workload mas --mas-batch $B --steps 20 2>/dev/null | tail -1 > $OUT/bench_mas_b$B.json; cut -c1-200 $OUT/bench_mas_b$B.json; done
 { timeout 300 python scripts/b1_latency.py 1 2>&1 | grep -v amdgpu.ids; timeout 200 python scripts/b1_quick.py 2>&1 | grep -v amdgpu.ids; } > $OUT/b1_latency.txt; stamp $OUT/b1_latency.txt; cat $OUT/b1_latency.txt
 bash scripts/gpu_b1_tl.sh $TAG/tlb1 > /dev/null 2>&1; { echo "$HDR"; cat $OUT/tlb1/b1_timeline.txt; } > $OUT/b1_timeline.txt; head -2 $OUT/b1_timeline.txt; rm -rf $OUT/tlb1
+{ timeout 400 python scripts/att_ab.py 2>&1 | grep -v amdgpu.ids; } > $OUT/attention_v3_ab.txt; stamp $OUT/attention_v3_ab.txt; grep "T=257" $OUT/attention_v3_ab.txt
 timeout 400 python scripts/r6_pairs_ab.py pairs convs ups 2>&1 | grep -v amdgpu.ids > $OUT/kernels_at_headline_shapes.txt; stamp $OUT/kernels_at_headline_shapes.txt; head -4 $OUT/kernels_at_headline_shapes.txt
 cd /tmp && export TMPDIR=/tmp
 BENCH="$R/bench.py --serial-branches --lanes 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-live-pmc"
