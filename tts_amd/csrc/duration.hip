@@ -48,12 +48,26 @@ __global__ void convflow_pre_kernel(float *__restrict__ h, const float *__restri
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const float x0 = z[((long)b * 2 + z_ch) * T + t];
-    for (int c = blockIdx.y; c < C; c += gridDim.y) {
-        const long o = ((long)b * C + c) * T + t;
-        float v = w[c] * x0;
-        if (bias) v += bias[c];
-        if (g) v += g[o];
-        h[o] = v;
+    // four channels per pass with their loads in flight together (one channel per pass was one memory round trip per channel:
+    // twelve in a row at C = 192; the launch is a handful of blocks, so its time is that chain)
+    for (int c0 = blockIdx.y; c0 < C; c0 += 4 * gridDim.y) {
+        float wv[4], bv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * gridDim.y;
+            const int cc = c < C ? c : c0;                      // a pass's tail re-reads its first channel (never stored)
+            wv[u] = w[cc];
+            bv[u] = bias ? bias[cc] : 0.f;
+            gv[u] = g ? g[((long)b * C + cc) * T + t] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * gridDim.y;
+            float v = wv[u] * x0;
+            if (bias) v += bv[u];
+            if (g) v += gv[u];
+            if (c < C) h[((long)b * C + c) * T + t] = v;
+        }
     }
 }
 
@@ -88,10 +102,17 @@ __device__ __forceinline__ void spline_knots(float *knots, float *sizes, const f
     for (int k = 0; k < nb; ++k) sizes[k] = knots[k + 1] - knots[k];
 }
 
+// NBT > 0: the bin count as a compile-time constant (VITS: 10) — every loop unrolls, every array lives in registers (the generic
+// form keeps 224 bytes of scratch per thread and walks its 2 nb + 2 parameter loads as a chain of dependent round trips: 15 us per
+// launch for five blocks of work), all 3 nb - 1 parameters are requested together, and the bin's entries are picked by selects.
+// Same operations in the same order on the same operands: bitwise the generic kernel.
+template <int NBT>
 __global__ void convflow_spline_reverse_kernel(float *__restrict__ z_out, const float *__restrict__ z_in,
                                                const float *__restrict__ h, const float *__restrict__ mask,
-                                               int T, int nb, float sqrt_filter, float tail)
+                                               int T, int nb_arg, float sqrt_filter, float tail)
 {
+    const int nb = NBT > 0 ? NBT : nb_arg;
+    constexpr int NA = NBT > 0 ? NBT : kMaxBins;
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -101,26 +122,63 @@ __global__ void convflow_spline_reverse_kernel(float *__restrict__ z_out, const 
     float outv = x1;
     if (x1 >= -tail && x1 <= tail) {
         const float *hp = h + (long)b * (3 * nb - 1) * T + t;
-        float uw[kMaxBins], uh[kMaxBins], cw[kMaxBins + 1], ch[kMaxBins + 1], wd[kMaxBins], ht[kMaxBins];
-        for (int k = 0; k < nb; ++k) {
-            uw[k] = hp[(long)k * T] / sqrt_filter;
-            uh[k] = hp[(long)(nb + k) * T] / sqrt_filter;
+        float uw[NA], uh[NA], cw[NA + 1], ch[NA + 1], wd[NA], ht[NA];
+        float rd[NA];                                 // unnormalised derivatives of the interior knots (NBT > 0 only)
+        if constexpr (NBT > 0) {
+            float rw[NA], rh[NA];
+#pragma unroll
+            for (int k = 0; k < NBT; ++k) {
+                rw[k] = hp[(long)k * T];
+                rh[k] = hp[(long)(NBT + k) * T];
+                rd[k] = (k < NBT - 1) ? hp[(long)(2 * NBT + k) * T] : 0.f;      // (compile-time condition)
+            }
+#pragma unroll
+            for (int k = 0; k < NBT; ++k) {
+                uw[k] = rw[k] / sqrt_filter;
+                uh[k] = rh[k] / sqrt_filter;
+            }
+        } else {
+            for (int k = 0; k < nb; ++k) {
+                uw[k] = hp[(long)k * T] / sqrt_filter;
+                uh[k] = hp[(long)(nb + k) * T] / sqrt_filter;
+            }
         }
         spline_knots(cw, wd, uw, nb, kMinBinWidth, -tail, tail);
         spline_knots(ch, ht, uh, nb, kMinBinHeight, -tail, tail);
         // searchsorted(cumheights, x): count of knots <= x (last knot + 1e-6), minus one
         int bin = -1;
-        for (int k = 0; k <= nb; ++k) {
-            const float loc = (k == nb) ? ch[k] + 1e-6f : ch[k];
-            bin += (x1 >= loc) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k <= NA; ++k) {
+            if (k <= nb) {
+                const float loc = (k == nb) ? ch[k] + 1e-6f : ch[k];
+                bin += (x1 >= loc) ? 1 : 0;
+            }
         }
         bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
         const float edge = (float)log(exp(1.0 - (double)kMinDerivative) - 1.0);
-        const float ud0 = (bin == 0) ? edge : hp[(long)(2 * nb + bin - 1) * T];
-        const float ud1 = (bin == nb - 1) ? edge : hp[(long)(2 * nb + bin) * T];
+        float ud0, ud1, in_cw, in_w, in_ch, in_h;
+        if constexpr (NBT > 0) {
+            ud0 = edge;
+            ud1 = edge;
+            in_cw = cw[0], in_w = wd[0], in_ch = ch[0], in_h = ht[0];
+#pragma unroll
+            for (int k = 0; k < NBT; ++k) {
+                if (k >= 1) {
+                    ud0 = (bin == k) ? rd[k - 1] : ud0;
+                    in_cw = (bin == k) ? cw[k] : in_cw;
+                    in_w = (bin == k) ? wd[k] : in_w;
+                    in_ch = (bin == k) ? ch[k] : in_ch;
+                    in_h = (bin == k) ? ht[k] : in_h;
+                }
+                if (k < NBT - 1) ud1 = (bin == k) ? rd[k] : ud1;
+            }
+        } else {
+            ud0 = (bin == 0) ? edge : hp[(long)(2 * nb + bin - 1) * T];
+            ud1 = (bin == nb - 1) ? edge : hp[(long)(2 * nb + bin) * T];
+            in_cw = cw[bin], in_w = wd[bin], in_ch = ch[bin], in_h = ht[bin];
+        }
         const float d0 = kMinDerivative + softplus_f(ud0);
         const float d1 = kMinDerivative + softplus_f(ud1);
-        const float in_cw = cw[bin], in_w = wd[bin], in_ch = ch[bin], in_h = ht[bin];
         const float delta = in_h / in_w;
         const float dx = x1 - in_ch;
         const float s = d0 + d1 - 2.f * delta;
@@ -358,7 +416,7 @@ extern "C" int ttsamd_convflow_pre(float *h, const float *z, int z_ch, const flo
     TTSAMD_CHECK_ARG(h && z && w && (z_ch == 0 || z_ch == 1) && batch >= 0 && c > 0 && t >= 0, "convflow_pre: bad args");
     if (batch == 0 || t == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(batch <= 65535, "convflow_pre: batch > 65535");
-    hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(t, 64), min(c, 16), batch), dim3(64), 0, as_stream(stream), h, z,
+    hipLaunchKernelGGL(convflow_pre_kernel, dim3(cdiv(t, 64), min(c, 48), batch), dim3(64), 0, as_stream(stream), h, z,
                        z_ch, w, bias, g, c, t);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
@@ -377,8 +435,12 @@ extern "C" int ttsamd_convflow_spline_reverse(float *z_out, const float *z_in, c
     }
     if (batch == 0 || t == 0) return TTSAMD_OK;
     TTSAMD_CHECK_ARG(batch <= 65535, "convflow_spline_reverse: batch > 65535");
-    hipLaunchKernelGGL(convflow_spline_reverse_kernel, dim3(cdiv(t, 64), batch), dim3(64), 0, as_stream(stream), z_out,
-                       z_in, h, mask, t, num_bins, sqrtf(filter_channels), tail_bound);
+    if (num_bins == 10)      // VITS's stochastic duration predictor (stochastic_duration_predictor.py: num_bins = 10)
+        hipLaunchKernelGGL(convflow_spline_reverse_kernel<10>, dim3(cdiv(t, 64), batch), dim3(64), 0, as_stream(stream), z_out,
+                           z_in, h, mask, t, num_bins, sqrtf(filter_channels), tail_bound);
+    else
+        hipLaunchKernelGGL(convflow_spline_reverse_kernel<0>, dim3(cdiv(t, 64), batch), dim3(64), 0, as_stream(stream), z_out,
+                           z_in, h, mask, t, num_bins, sqrtf(filter_channels), tail_bound);
     TTSAMD_LAUNCH_CHECK();
     return TTSAMD_OK;
 }

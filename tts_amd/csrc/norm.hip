@@ -110,52 +110,78 @@ __global__ __launch_bounds__(1024) void channel_norm_small_kernel(const ttsamd_n
     const float *xb = a.x + (long)b * a.x_bstride;
     const float *im = a.in_mask ? a.in_mask + (long)b * a.t : nullptr;
 
+    // Every operand through a buffer resource, validity in the OFFSET (an invalid lane reads 0 from the range check): written as
+    // `if (valid) v = p[i]` / `valid ? p[i] : 0` hipcc splits the wave into two paths per element with a full s_waitcnt vmcnt(0)
+    // between consecutive loads — this launch was a chain of up to twelve memory round trips (round 6: 5-8 us -> the launch floor)
+    constexpr int kInv = (int)0x80000000u;
+    const long xslab = ((long)(a.c - 1) * a.x_rstride + a.t) * 4;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, xslab);
     float v[NC];
     bool cv[NC];
+    int cofs[NC];          // channel index * 4, or out of range
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         cv[i] = tv && (grp + i * 64 < a.c);
-        v[i] = 0.f;
+        cofs[i] = cv[i] ? (grp + i * 64) * 4 : kInv;
     }
     if (a.dw_w) {
         const int half = (a.dw_kernel - 1) / 2;
+        const __amdgpu_buffer_rsrc_t rdb = make_rsrc(a.dw_bias, a.dw_bias ? (long)a.c * 4 : 0);
+        const __amdgpu_buffer_rsrc_t rdw = make_rsrc(a.dw_w, (long)a.c * a.dw_kernel * 4);
+        const __amdgpu_buffer_rsrc_t rim = make_rsrc(im, im ? (long)a.t * 4 : 0);
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
-            if (cv[i] && a.dw_bias) v[i] = a.dw_bias[grp + i * 64];
-        for (int k = 0; k < a.dw_kernel; ++k) {
+        for (int i = 0; i < NC; ++i) v[i] = ld_buf(rdb, cofs[i], 0);
+        auto tap = [&](int k) {
             const int tt = t + (k - half) * a.dw_dilation;
             const bool ok = tt >= 0 && tt < a.t;
-            const float mk = (ok && im) ? im[tt] : 1.f;
+            const float mk = im ? ld_buf(rim, ok ? tt * 4 : kInv, 0) : 1.f;
+            float xv[NC], wv[NC];
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                if (cv[i] && ok) {
-                    const int c = grp + i * 64;
-                    float xv = xb[(long)c * a.x_rstride + tt];
-                    if (im) xv *= mk;
-                    v[i] += a.dw_w[c * a.dw_kernel + k] * xv;
-                }
+                xv[i] = ld_buf(rx, (cv[i] && ok) ? ((grp + i * 64) * (int)a.x_rstride + tt) * 4 : kInv, 0);
+                wv[i] = ld_buf(rdw, (cv[i] && ok) ? ((grp + i * 64) * a.dw_kernel + k) * 4 : kInv, 0);
             }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (im) xv[i] *= mk;
+                // (a tap outside the tensor contributed nothing before; it contributes w = 0 times x = 0 now: same value)
+                v[i] = (cv[i] && ok) ? v[i] + wv[i] * xv[i] : v[i];
+            }
+        };
+        if (a.dw_kernel == 3) {      // DDSConv's kernel size (stochastic_duration_predictor.py:46-63): all nine loads in flight together
+            tap(0);
+            tap(1);
+            tap(2);
+        } else {
+            for (int k = 0; k < a.dw_kernel; ++k) tap(k);
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
-            if (cv[i]) v[i] = xb[(long)(grp + i * 64) * a.x_rstride + t];
+        for (int i = 0; i < NC; ++i) v[i] = ld_buf(rx, cv[i] ? ((grp + i * 64) * (int)a.x_rstride + t) * 4 : kInv, 0);
     }
     if (a.pre_res) {
+        const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.pre_res + (long)b * a.pre_bstride, ((long)(a.c - 1) * a.pre_rstride + a.t) * 4);
+        float pr[NC];
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
-            if (cv[i]) v[i] += a.pre_res[(long)b * a.pre_bstride + (long)(grp + i * 64) * a.pre_rstride + t];
+        for (int i = 0; i < NC; ++i) pr[i] = ld_buf(rp, cv[i] ? ((grp + i * 64) * (int)a.pre_rstride + t) * 4 : kInv, 0);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) v[i] += pr[i];
     }
     // epilogue operands requested before the statistics passes (their latency hides under the two reductions)
     float gam[NC], bet[NC], pres[NC];
+    {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gamma, (long)a.c * 4), rbt = make_rsrc(a.beta, (long)a.c * 4);
+        const __amdgpu_buffer_rsrc_t rpo = make_rsrc(a.post_res ? a.post_res + (long)b * a.post_bstride : nullptr,
+                                                     a.post_res ? ((long)(a.c - 1) * a.post_rstride + a.t) * 4 : 0);
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = grp + i * 64;
-        gam[i] = cv[i] ? a.gamma[c] : 0.f;
-        bet[i] = cv[i] ? a.beta[c] : 0.f;
-        pres[i] = (cv[i] && a.post_res) ? a.post_res[(long)b * a.post_bstride + (long)c * a.post_rstride + t] : 0.f;
+        for (int i = 0; i < NC; ++i) {
+            gam[i] = ld_buf(rg, cofs[i], 0);
+            bet[i] = ld_buf(rbt, cofs[i], 0);
+            pres[i] = ld_buf(rpo, cv[i] ? ((grp + i * 64) * (int)a.post_rstride + t) * 4 : kInv, 0);
+        }
     }
-    const float om = (a.out_mask && tv) ? a.out_mask[(long)b * a.t + t] : 1.f;
+    const __amdgpu_buffer_rsrc_t rom = make_rsrc(a.out_mask ? a.out_mask + (long)b * a.t : nullptr, a.out_mask ? (long)a.t * 4 : 0);
+    const float om = a.out_mask ? ld_buf(rom, tv ? t * 4 : kInv, 0) : 1.f;
 
     float s = 0.f;
 #pragma unroll
@@ -284,7 +310,9 @@ extern "C" int ttsamd_channel_norm(const ttsamd_norm_args *args, void *stream)
         return TTSAMD_OK;
     }
     // text-length tensors: 16-column tiles (chosen by T alone, never by the batch: row b of a batch stays bitwise the B = 1 run)
-    if (a.t <= kNormSmallT) {
+    // (its operands go through 32-bit buffer offsets: per-item slabs below 2 GiB — always, short of a pathological row stride)
+    auto slab_ok = [&](long rstride) { return ((long)(a.c - 1) * rstride + a.t) * 4 < 0x7FFFFFF0l; };
+    if (a.t <= kNormSmallT && slab_ok(a.x_rstride) && (!a.pre_res || slab_ok(a.pre_rstride)) && (!a.post_res || slab_ok(a.post_rstride))) {
         const dim3 sgrid((a.t + 15) / 16, a.batch);
         if (a.c <= 192) hipLaunchKernelGGL((channel_norm_small_kernel<3>), sgrid, dim3(1024), 0, st, a);
         else if (a.c <= 256) hipLaunchKernelGGL((channel_norm_small_kernel<4>), sgrid, dim3(1024), 0, st, a);
