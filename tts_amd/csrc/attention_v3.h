@@ -6,13 +6,16 @@
 // four fp32 matrix pipes before any latency is paid, and a single request has 18 such blocks on a 256-CU chip (28-31 us per
 // launch, six launches per VITS request, profiles/r06_b1_timeline.txt).  Here
 //   * a block is 16 query rows (v_mfma_f32_16x16x4_f32): twice the blocks, half the serial matrix work per block;
-//   * Q K^T: one 16-key tile per wave and round, the next tile's K fragment requested before the current tile's MFMAs;
-//   * the relative-key logits R = Q Ek^T are ONE more 16x16 MFMA tile (the wave with the fewest key tiles takes it) kept in LDS
-//     and added while the softmax reads the scores: no scatter pass, one barrier less;
-//   * softmax: a wave owns 2 rows and keeps them in registers between its passes;
+//   * Q K^T: 16-column tiles dealt round-robin to the waves, a wave's first tiles requested before anything else; every load
+//     is straight-line code: the lane's column offset in the vector operand, the channel step in the scalar operand, absent
+//     columns / channels out of the buffer's range (`cond ? load(a) : load(b)` per element makes hipcc emit two divergent paths
+//     with a full wait between consecutive loads: the 32-query kernels' contraction was a chain of memory round trips);
+//   * the relative-key logits R = Q Ek^T are ONE more 16x16 MFMA tile dealt out with the key tiles, kept in LDS and added by
+//     the wave that owns the row just before its softmax: no scatter pass over the block, one barrier less;
+//   * softmax: a wave owns 2 rows and keeps them in registers between its passes; reductions on the DPP network;
 //   * P V: wave = (half of the channel tiles, every 4th 16-key step): one ds_read_b128 of P feeds DK / 32 x 4 MFMAs, V
-//     fragments are 16-byte global loads requested a step ahead; the four partial sums of an output meet in LDS in a fixed
-//     order and ALL 512 threads run the relative-value band and the store.
+//     fragments are 16-byte buffer loads requested BEFORE the softmax; the four partial sums of an output meet in LDS in a
+//     fixed order and ALL 512 threads run the relative-value band and the store.
 // T <= 1024 (the score strip lives in LDS); longer sequences keep rel_attention_long_kernel.  Included by attention.hip only.
 #pragma once
 

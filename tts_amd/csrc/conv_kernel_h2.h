@@ -29,6 +29,7 @@
 // during iteration c-1, its maximum known since the last barrier), then requests chunk c+2 into the same registers, and takes
 // that chunk's maximum just before the barrier.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_kernel_x3.h"
@@ -423,8 +424,18 @@ template <int K, int D, int MODE>
 int conv1d_h2_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
 {
     const int mtiles = (a.c_out + 31) / 32;
-    if (mtiles % 4 == 0) return conv1d_h2_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
-    if (mtiles % 2 == 0) return conv1d_h2_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);
+    // Awkward lengths (the headline's T = 257 text columns and 770 frames are 2 x 128 + 1 and 6 x 128 + 2): a tile half as wide when
+    // that removes >= 10 % of the padded columns the launch computes.  TTSAMD_H2_ADAPT_TILES=0: the fixed tiles (A/B switch).
+    static const bool adapt = !(getenv("TTSAMD_H2_ADAPT_TILES") && getenv("TTSAMD_H2_ADAPT_TILES")[0] == '0');
+    auto padded = [&](int bn) { return (long)((a.t_out + bn - 1) / bn) * bn; };
+    if (mtiles % 4 == 0) {
+        if (adapt && padded(64) * 10 <= padded(128) * 9) return conv1d_h2_launch_cfg<K, D, 1, 2, 4, 1, MODE>(a, st);      // 128 rows x 64 columns
+        return conv1d_h2_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
+    }
+    if (mtiles % 2 == 0) {
+        if (adapt && padded(128) * 10 <= padded(256) * 9) return conv1d_h2_launch_cfg<K, D, 1, 2, 2, 2, MODE>(a, st);     // 64 rows x 128 columns
+        return conv1d_h2_launch_cfg<K, D, TTSAMD_X3_CFG64, MODE>(a, st);
+    }
     return conv1d_h2_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
 }
 
