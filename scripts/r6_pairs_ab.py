@@ -1,6 +1,6 @@
 """One library's timings of the fused ResBlock pairs (three-product kernels) at the headline shapes, with an output digest per
 shape so that two libraries can be checked for bitwise agreement:
-    TTSAMD_LIB_PATH=tts_amd/libtts_amd_<tag>.so python scripts/r6_pairs_ab.py [pairs] [convs] [ups]
+    TTSAMD_LIB_PATH=tts_amd/libtts_amd_<tag>.so python scripts/r6_pairs_ab.py [pairs] [convs] [ups] [small]
 Prints one line per launch: name, microseconds (HIP events, 10 launches), TF-eq, digest."""
 import hashlib
 import os
@@ -13,7 +13,7 @@ from tts_amd import ops  # noqa: E402
 
 dev = "cuda:0"
 B = 32
-what = set(sys.argv[1:]) or {"pairs", "convs", "ups"}
+what = set(sys.argv[1:]) or {"pairs", "convs", "ups", "small"}
 variant = int(os.environ.get("PAIR_VARIANT", "0"))
 tag = os.path.basename(os.environ.get("TTSAMD_LIB_PATH", "libtts_amd.so")) + ("" if not variant else "/v%d" % variant)
 
@@ -101,3 +101,31 @@ if "ups" in what:
         floor = max(fl / 833.3e6, 4.0 * B * (cin * T + cout * T * u) / 8e6)
         print("%-16s convT %d->%d u=%d  %8.1f us  roofline %.3f  %s" % (tag, cin, cout, u, us, floor / us, digest(y)), flush=True)
         del x, y
+if "small" in what:
+    # the B = 32 step's sub-two-round launches: flow WaveNet (T = 770) and text encoder (T = 257) convs, res/skip epilogue included
+    for cin, cout, K, T, mode in ((192, 384, 5, 770, "gate"), (192, 384, 1, 770, "res_skip"), (192, 192, 1, 770, "plain"), (192, 768, 3, 257, "plain"),
+                                  (768, 192, 3, 257, "plain"), (192, 192, 1, 257, "plain"), (192, 576, 1, 257, "plain")):
+        g = torch.Generator().manual_seed(cin + K + T)
+        x = torch.randn(B, cin, T, generator=g).to(dev)
+        w = torch.randn(cout, cin, K, generator=g) / (cin * K) ** 0.5
+        if mode == "gate":
+            wg, bg = ops.gate_permute(w, torch.randn(cout, generator=g), cout // 2)
+            pc = ops.PackedConv(wg, bg, dev)
+            y = torch.empty(B, cout // 2, T, device=dev)
+            f = lambda: ops.conv1d(pc, x, y, mode=ops.CONV_GATE)  # noqa: E731
+        elif mode == "res_skip":
+            pc = ops.PackedConv(w, torch.randn(cout, generator=g), dev)
+            y = torch.empty(B, cout // 2, T, device=dev)
+            y2 = torch.zeros(B, cout // 2, T, device=dev)
+            xr = torch.randn(B, cout // 2, T, generator=g).to(dev)
+            f = lambda: ops.conv1d(pc, x, y, mode=ops.CONV_RES_SKIP, res=xr, y2=y2, accum=y2, split_row=cout // 2)  # noqa: E731
+        else:
+            pc = ops.PackedConv(w, torch.randn(cout, generator=g), dev)
+            y = torch.empty(B, cout, T, device=dev)
+            f = lambda: ops.conv1d(pc, x, y)  # noqa: E731
+        try:
+            us = time_us(f, 20)
+            fl = 2.0 * cin * cout * K * T * B
+            print("%-16s small %d->%d k=%d %s T=%d  %8.1f us  %6.1f TF-eq  %s" % (tag, cin, cout, K, mode, T, us, fl / us / 1e6, digest(y)), flush=True)
+        except Exception as e:  # noqa: BLE001
+            print("%-16s small %d->%d k=%d %s: %s" % (tag, cin, cout, K, mode, e))

@@ -58,16 +58,38 @@ struct ConvGeom {
 struct ConvTile {
     int nb, mb, b;   // time tile, m-block, batch item
 };
-__device__ __forceinline__ ConvTile conv_tile_of_block()
+// Round 6, `wbytes` (the launch's packed weight image, bytes; < 0: not given): a SMALL image (polyphase ups[1] 2.1 MB, the flow /
+// text convs 0.3-1.5 MB) fits every L2 next to the activations, and then it is the x tile that should be fetched once: all
+// m-blocks of an (item, time tile) pair run back to back on ONE XCD ("x-local"; the weights-local order made every XCD fetch the
+// whole of x: 8 x at ups[1]).  Larger images keep the weights-local order, now also for 16, 24 ... m-blocks (ups[0]: two per XCD).
+#ifndef TTSAMD_XLOCAL_WBYTES
+#define TTSAMD_XLOCAL_WBYTES (2560 * 1024)
+#endif
+__device__ __forceinline__ ConvTile conv_tile_of_block(long wbytes = -1)
 {
     ConvTile t{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
     const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
     const unsigned total = gx * gy * gz;
-    if ((total & 7u) == 0 && (gy == 1 || gy == 2 || gy == 4 || gy == 8)) {
-        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        const unsigned xcd = lin & 7u, i = lin >> 3, cnt = total >> 3;
+    if ((total & 7u) != 0) return t;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, i = lin >> 3, cnt = total >> 3;
+    const unsigned pairs = gx * gz;
+    if (gy > 1 && wbytes >= 0 && wbytes <= (long)TTSAMD_XLOCAL_WBYTES && (pairs & 7u) == 0) {
+        // x-local: XCD c walks a contiguous eighth of the (item, time tile) pairs, every m-block of a pair in a row
+        const unsigned q = i / gy;
+        t.mb = (int)(i - q * gy);
+        const unsigned u = xcd * (pairs >> 3) + q;
+        t.b = (int)(u / gx);
+        t.nb = (int)(u - (unsigned)t.b * gx);
+    } else if (gy == 1 || gy == 2 || gy == 4 || gy == 8) {
         t.mb = (int)(xcd % gy);
         const unsigned u = (xcd / gy) * cnt + i;     // index among the (item, time tile) pairs of this m-block
+        t.b = (int)(u / gx);
+        t.nb = (int)(u - (unsigned)t.b * gx);
+    } else if ((gy & 7u) == 0) {
+        const unsigned per = gy >> 3;                // m-blocks per XCD
+        const unsigned u = i / per;
+        t.mb = (int)(xcd * per + (i - u * per));
         t.b = (int)(u / gx);
         t.nb = (int)(u - (unsigned)t.b * gx);
     }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
     const int wn = wave % WN;
     const int h = lane >> 5;
     const int j = lane & 31;
-    const ConvTile tile = conv_tile_of_block();
+    const ConvTile tile = conv_tile_of_block((long)a.c_out * a.c_in * (K * 4));     // two fp16 parts: 4 bytes per weight
     const int b = tile.b;
     const int mb = tile.mb;
     const int t0 = tile.nb * G::kBN;
@@ -428,6 +428,8 @@ int conv1d_h2_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     // that removes >= 10 % of the padded columns the launch computes.  TTSAMD_H2_ADAPT_TILES=0: the fixed tiles (A/B switch).
     static const bool adapt = !(getenv("TTSAMD_H2_ADAPT_TILES") && getenv("TTSAMD_H2_ADAPT_TILES")[0] == '0');
     auto padded = [&](int bn) { return (long)((a.t_out + bn - 1) / bn) * bn; };
+    // (A tile half as wide for launches of less than two rounds of the wide one — the flow convs' 672 blocks — was measured and is
+    // not kept: gate conv 75 -> 71.5 us, res/skip 1x1 46 -> 50, whole step 48.81 -> 48.95 ms; profiles/r06_xlocal_ab.txt.)
     if (mtiles % 4 == 0) {
         if (adapt && padded(64) * 10 <= padded(128) * 9) return conv1d_h2_launch_cfg<K, D, 1, 2, 4, 1, MODE>(a, st);      // 128 rows x 64 columns
         return conv1d_h2_launch_cfg<K, D, TTSAMD_X3_CFG128, MODE>(a, st);
