@@ -107,7 +107,10 @@ MULTI_TILE = [
 # index mod m-blocks, contiguous (item, time tile) ranges per XCD.  1, 2, 4 and 8 m-blocks, and a grid that is not a
 # multiple of 8 (plain mapping).  (B, Cin, Cout, K, D, T)
 XCD_CASES = [(4, 32, 128, 3, 1, 16384), (2, 32, 256, 3, 1, 16384), (2, 16, 512, 3, 1, 4096), (1, 16, 1024, 1, 1, 1024),
-             (3, 32, 256, 3, 1, 5000), (8, 16, 64, 7, 1, 8192), (8, 16, 32, 7, 1, 16384)]
+             (3, 32, 256, 3, 1, 5000), (8, 16, 64, 7, 1, 8192), (8, 16, 32, 7, 1, 16384),
+             # round 6: small weight images take the x-local order (all m-blocks of a tile pair on one XCD) at ANY m-block count (3, 24);
+             # images above TTSAMD_XLOCAL_WBYTES keep the weights-local order (2 m-blocks), extended to 16 m-blocks (two per XCD)
+             (8, 32, 384, 3, 1, 1024), (1, 16, 3072, 1, 1, 1024), (1, 256, 256, 11, 1, 1024), (1, 512, 2048, 1, 1, 1024)]
 
 
 @pytest.mark.parametrize("case", XCD_CASES)
