@@ -62,6 +62,9 @@ struct ConvTile {
 // text convs 0.3-1.5 MB) fits every L2 next to the activations, and then it is the x tile that should be fetched once: all
 // m-blocks of an (item, time tile) pair run back to back on ONE XCD ("x-local"; the weights-local order made every XCD fetch the
 // whole of x: 8 x at ups[1]).  Larger images keep the weights-local order, now also for 16, 24 ... m-blocks (ups[0]: two per XCD).
+#ifndef TTSAMD_XCD_WIDE
+#define TTSAMD_XCD_WIDE 1      // 0 (with TTSAMD_XLOCAL_WBYTES=-1): the block order of rounds 2-5, for A/B builds
+#endif
 #ifndef TTSAMD_XLOCAL_WBYTES
 #define TTSAMD_XLOCAL_WBYTES (2560 * 1024)
 #endif
@@ -86,7 +89,7 @@ __device__ __forceinline__ ConvTile conv_tile_of_block(long wbytes = -1)
         const unsigned u = (xcd / gy) * cnt + i;     // index among the (item, time tile) pairs of this m-block
         t.b = (int)(u / gx);
         t.nb = (int)(u - (unsigned)t.b * gx);
-    } else if ((gy & 7u) == 0) {
+    } else if (TTSAMD_XCD_WIDE && (gy & 7u) == 0) {
         const unsigned per = gy >> 3;                // m-blocks per XCD
         const unsigned u = i / per;
         t.mb = (int)(xcd * per + (i - u * per));
