@@ -72,15 +72,32 @@ struct ConvGeomH2 {
     static_assert(WM * WN == 4 || WM * WN == 8, "the maximum slots are read four at a time");
 };
 
-// two values -> packed high parts and packed (2^11-scaled) low parts
+// two values -> packed high parts and packed (2^11-scaled) low parts.
+// lo = fp16((x - hi) * 2^11) as ONE mixed-precision fma per value, fp16(fma(hi, -2^11, x * 2^11)), reading hi straight from its
+// packed fp16 half: v_pk_mul + v_cvt_pk + v_fma_mixlo + v_fma_mixhi instead of v_cvt_pk + two v_cvt_f32_f16 + v_pk_add + v_pk_mul +
+// v_cvt_pk (hipcc keeps the convert-back form, and turns a C-level fma pair into v_pk_fma_f32 + the same conversions).  x * 2^11,
+// hi * 2^11 and their difference are exact, so both forms round once, to fp16, at the end: bitwise equal on 4 M random pairs over
+// fp16's normal, denormal and underflow range (scripts/ubench/split_mix.hip).  TTSAMD_SPLIT_MIX=0 builds the convert-back form.
+#ifndef TTSAMD_SPLIT_MIX
+#define TTSAMD_SPLIT_MIX 1
+#endif
 __device__ __forceinline__ void conv_split2x2(float x0, float x1, unsigned &whi, unsigned &wlo)
 {
     const f32x2v v = {x0, x1};
     const f16x2v hi = __builtin_convertvector(v, f16x2v);
+    whi = __builtin_bit_cast(unsigned, hi);
+#if TTSAMD_SPLIT_MIX
+    const f32x2v v2k = v * 2048.f;
+    const float m = -2048.f;
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(whi), "s"(m), "v"(v2k[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(whi), "s"(m), "v"(v2k[1]));
+    wlo = lo;
+#else
     const f32x2v hf = __builtin_convertvector(hi, f32x2v);
     const f32x2v r = (v - hf) * 2048.f;                                        // both steps exact
-    whi = __builtin_bit_cast(unsigned, hi);
     wlo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2v));
+#endif
 }
 
 // largest value of a wave (unsigned compare: magnitudes' bit patterns order like the magnitudes), wave-uniform result
