@@ -35,6 +35,8 @@ CASES = [  # (B, Cin, Cout, K, D, T)
     (1, 256, 256, 11, 5, 150), (2, 80, 512, 7, 1, 47), (2, 192, 384, 5, 1, 77), (3, 192, 96, 1, 1, 33),
     (2, 96, 192, 1, 1, 130), (2, 768, 192, 3, 1, 257), (1, 32, 1, 7, 1, 5000), (2, 192, 29, 1, 1, 50),
     (2, 3, 20, 3, 9, 40), (1, 17, 40, 5, 1, 1),
+    # mid-size grids (48 .. 128 of the 128 x 128-class blocks): the 128 x 64 tile on eight waves (conv1d_h2_launch_mid)
+    (1, 256, 256, 11, 1, 6160), (1, 128, 128, 7, 3, 8001), (2, 64, 128, 3, 5, 4000),
 ]
 
 

@@ -458,9 +458,16 @@ int conv1d_h2_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
     return conv1d_h2_launch_cfg<K, D, 1, 2, 1, 4, MODE>(a, st);
 }
 
+// Mid-size grids (48 .. 128 of the 128 x 128-class blocks: a lone request's 256-channel stage, 98 of them -> 200 blocks of 128 x 64 on
+// 256 CUs).  A CU holds at most one such block, so its four waves walk the whole K loop alone on their SIMDs; the same tile on EIGHT
+// waves (32 x 32 each) puts two waves on a SIMD and halves each one's MFMA / staging chain: VITS B = 1 request 3.31 -> 3.25 ms same
+// box (profiles/r06_w8_mid_ab.txt).  The 128 x 128 tile on eight waves for launches below one round (the 128-channel stage of that
+// request: 385 blocks) was measured with it and LOSES (3.31 -> 3.35 ms).  TTSAMD_H2_MID_W8=0: four waves (A/B switch).
 template <int K, int D, int MODE>
 int conv1d_h2_launch_mid(const ttsamd_conv1d_args &a, hipStream_t st)
 {
+    static const bool w8 = !(getenv("TTSAMD_H2_MID_W8") && getenv("TTSAMD_H2_MID_W8")[0] == '0');
+    if (w8) return conv1d_h2_launch_cfg<K, D, 1, 1, 4, 2, MODE>(a, st);
     return conv1d_h2_launch_cfg<K, D, 1, 2, 4, 1, MODE>(a, st);
 }
 
