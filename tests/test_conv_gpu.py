@@ -159,7 +159,8 @@ def test_conv1d_multi_tile(gpu, case, conv_precision):
     assert _rel(y, want) < TOL
 
 
-@pytest.mark.parametrize("case", [(2, 64, 32, 8, 50), (1, 128, 64, 2, 301), (2, 32, 16, 2, 64), (1, 512, 256, 8, 20)])
+@pytest.mark.parametrize("case", [(2, 64, 32, 8, 50), (1, 128, 64, 2, 301), (2, 32, 16, 2, 64), (1, 512, 256, 8, 20),
+                                  (1, 512, 256, 8, 770), (1, 256, 128, 8, 1500)])     # the last two: the mid-size (eight-wave) tile
 def test_conv_transpose_polyphase(gpu, case):
     B, Cin, Cout, u, T = case
     g = torch.Generator().manual_seed(sum(case))

@@ -23,6 +23,7 @@
 //   * one MFMA K-step = 16 channels of one tap; any kernel size works (no pairing constraint).
 //   * accumulators, residual folding and the fused epilogues are the fp32 path's (conv_acc_init / conv_epilogue).
 #pragma once
+#include <cstdlib>
 #include "conv_kernel.h"
 
 // Wave-tile arrangement <MI,NI,WM,WN> of the unpaired-row modes (build-time so that variants can be A/B-ed through
@@ -444,6 +445,12 @@ int conv1d_x3_launch_tiles(const ttsamd_conv1d_args &a, hipStream_t st)
             int rc = TTSAMD_OK;
             if (conv1d_x3o_launch<K, D, MODE>(a, st, &rc)) return rc;
         }
+        // a lone request's ups[0] (512 -> 256 x 8 rows at T = 770: 112 blocks of 128 x 128 on 256 CUs, 64 chunks each): the mid-size
+        // tile of the NORMAL convs below (128 x 64 on eight waves).  TTSAMD_H2_MID_SHUFFLE=0: the large-grid tile (A/B switch)
+        static const bool mid_shuffle = !(getenv("TTSAMD_H2_MID_SHUFFLE") && getenv("TTSAMD_H2_MID_SHUFFLE")[0] == '0');
+        if (mid_shuffle && a.w_h2 && conv_h2_offsets_ok(a) && g_conv_small_grid && mtiles % 4 == 0 && blocks_default >= g_conv_h2_mid_min &&
+            blocks_default <= kConvSmallGridBlocks)
+            return conv1d_h2_launch_mid<K, D, MODE>(a, st);
     }
     constexpr bool affine = (MODE == TTSAMD_CONV_COUPLE_AFFINE || MODE == TTSAMD_CONV_COUPLE_AFFINE_FWD || MODE == TTSAMD_CONV_COUPLE_AFFINE_MIX);
     if constexpr (MODE == TTSAMD_CONV_NORMAL || (affine && K == 1) ||
