@@ -345,6 +345,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
 #pragma unroll
             for (int i = 0; i < G::kNStage; ++i) stage_load_step(s1, i, c + 1 + kSets);
         }
+        // NI = 1 (the eight-wave mid-size tile): a tap is two LDS fragment reads and three MFMAs that wait for them — 96 cycles of matrix
+        // work behind a ~200-cycle read, every tap, and with one block per CU no third wave to cover it.  The activation fragments
+        // are requested a tap ahead too, like the weight fragments (TTSAMD_H2_BPREFETCH=0 builds the read-then-use form).
+#ifndef TTSAMD_H2_BPREFETCH
+#define TTSAMD_H2_BPREFETCH 1
+#endif
+        constexpr bool kBP = (NI == 1) && TTSAMD_H2_BPREFETCH;
+        u32x4 bq_n[2];
+        if constexpr (kBP) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bq_n[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes);
+        }
 #pragma unroll
         for (int tap = 0; tap < K; ++tap) {
             const long g = ((tap + 1 < K) ? ((long)c * K + tap + 1) : ((long)(c + 1) * K)) * (2 * 64);
@@ -352,6 +364,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) a_nxt[mi][q] = wp[mi][g + q * 64];
+            u32x4 bq_c[2];
+            if constexpr (kBP) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bq_c[q] = bq_n[q];
+                if (tap + 1 < K) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) bq_n[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + ((tap + 1) * D) * 16);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch a whole tap ahead of its use
             if constexpr (kPipe) {
                 if (tap < G::kNStage) {
@@ -363,7 +384,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv1d_h2_kernel(const ttsamd
             for (int ni = 0; ni < NI; ++ni) {
                 u32x4 bq[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * 16);
+                for (int q = 0; q < 2; ++q) {
+                    if constexpr (kBP) bq[q] = bq_c[q];
+                    else bq[q] = *reinterpret_cast<const u32x4 *>(cur + q * G::kPartBytes + (ni * 32 + tap * D) * 16);
+                }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const bool zero = decltype(first)::value && tap == 0;
