@@ -287,6 +287,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
             mk[ni] = has_mask ? ld_buf(rmask, ok ? t * 4 : kOob, 0) : (ok ? 1.f : 0.f);
         }
         const float usx = pow2f(-e_x);
+        // the mask pass runs only where a factor can differ from 1: a masked call, or a block whose mid columns reach outside the tensor
+        // (block-uniform branch around the whole pass: interior blocks of an unmasked call pay no multiply per value)
+        const bool need_mask = has_mask || (t0 - G::kH2 < 0) || (t0 - G::kH2 + G::kNM > T);
         float m = 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -300,12 +303,27 @@ __global__ __launch_bounds__(64 * WM * WN, (ResGeomH2<K, D, C, WM, WN, NI>::kOcc
                         const int r = 4 * rg + i;
                         // (x 2^-11 is exact: same bits as mul, add; x ru, a power of two, is exact too, so the fma below rounds what
                         // `(. * ru) + bias` rounded — one instruction less per value)
-                        float v = __builtin_fmaf(__builtin_fmaf(accx[mi][ni][r], 1.f / 2048.f, accm[mi][ni][r]) * usx, ru[i], bia[i]);
-                        v = conv_lrelu(v * mk[ni], a.slope);
-                        accm[mi][ni][r] = v;
-                        m = __builtin_fmaxf(m, __builtin_fabsf(v));
+                        accm[mi][ni][r] = __builtin_fmaf(__builtin_fmaf(accx[mi][ni][r], 1.f / 2048.f, accm[mi][ni][r]) * usx, ru[i], bia[i]);
                     }
             }
+        if (need_mask) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accm[mi][ni][r] *= mk[ni];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = conv_lrelu(accm[mi][ni][r], a.slope);
+                    accm[mi][ni][r] = v;
+                    m = __builtin_fmaxf(m, __builtin_fabsf(v));
+                }
         slots[8 + wave] = wave_max_u32(__builtin_bit_cast(unsigned, m));
         __syncthreads();                                               // every wave is done reading the x tile; the maxima are in
         e_m = h2_exp_for(block_max(1));
